@@ -1,0 +1,403 @@
+/*
+ * xs_oracle.c -- CPU restatement of the x-search literal hot path (plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY -- see xs_oracle.h.  Parity status: PINNED
+ * (reference unit-test known answers + cross-check against oracle/_ref).
+ *
+ * This is a restatement, not a copy: the reference's AVX2 routine is described
+ * here by what it computes.  For strstr that is a three-part decomposition
+ * (SURVEY 8a, row a2):
+ *
+ *   plen == 1            -> leftmost byte == pat[0]              (exact)
+ *   len  <  32 + plen    -> the reference's LOSSY scalar search  (quirk)
+ *   otherwise            -> exact leftmost occurrence starting in the first
+ *                           32*floor((len-plen)/32) bytes ("body"), and if
+ *                           there is none, the lossy scalar search on the rest.
+ *
+ * The body is vectorised with AVX2 when the host has it (runtime dispatch) so
+ * that the timed "port" CPU baseline is a fair one; the scalar body computes
+ * the same function.
+ */
+#define _GNU_SOURCE
+#include "xs_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define XSO_X86 1
+#else
+#define XSO_X86 0
+#endif
+
+static int g_exact = 0;
+static xso_findnext_fn g_findnext = NULL;
+static xso_findnl_fn g_findnl = NULL;
+
+void xso_set_exact(int exact) { g_exact = exact ? 1 : 0; }
+int xso_get_exact(void) { return g_exact; }
+void xso_use_primitives(xso_findnext_fn fn, xso_findnl_fn nl) {
+  g_findnext = fn;
+  g_findnl = nl;
+}
+
+/* ------------------------------------------------------------------------ */
+/* simd_search.cpp:58-78.  The reference resumes AFTER the mismatching byte
+ * (its read index has already been post-incremented), i.e. at shift+k+1 where
+ * k is the number of pattern bytes that matched -- not at shift+1.  That
+ * skips occurrences that overlap a partial prefix match. */
+const char* xso_scalar_strstr(const char* str, size_t len, const char* pat, size_t plen) {
+  size_t shift = 0;
+  while (shift < len) {
+    if (len - shift < plen) return NULL;
+    size_t k = 0;
+    while (k < plen && str[shift + k] == pat[k]) ++k;
+    if (k == plen) return str + shift;
+    shift += k + 1;
+  }
+  return NULL;
+}
+
+/* true leftmost occurrence (exact mode only) */
+static const char* exact_strstr(const char* str, size_t len, const char* pat, size_t plen) {
+  if (plen == 0 || len < plen) return NULL;
+  return (const char*)memmem(str, len, pat, plen);
+}
+
+/* simd_search.cpp:107-114 */
+const char* xso_scalar_strchr(const char* str, size_t len, int c) {
+  for (size_t i = 0; i < len; ++i)
+    if (str[i] == c) return str + i;
+  return NULL;
+}
+
+/* ---- bodies ------------------------------------------------------------- */
+/* leftmost i in [0, nblocks*32) with str[i]==c, or -1 */
+static int64_t chr_body_scalar(const char* str, size_t nblocks, char c) {
+  const char* r = (const char*)memchr(str, (unsigned char)c, nblocks * 32);
+  return r ? (int64_t)(r - str) : -1;
+}
+
+/* leftmost i in [0, nblocks*32) with str[i..i+plen) == pat, or -1.
+ * Caller guarantees nblocks*32 + plen <= len (all reads in range). */
+static int64_t str_body_scalar(const char* str, size_t nblocks, const char* pat, size_t plen) {
+  const size_t n = nblocks * 32;
+  const char first = pat[0], last = pat[plen - 1];
+  for (size_t i = 0; i < n; ++i) {
+    if (str[i] == first && str[i + plen - 1] == last && memcmp(str + i + 1, pat + 1, plen - 1) == 0) return (int64_t)i;
+  }
+  return -1;
+}
+
+#if XSO_X86
+__attribute__((target("avx2"))) static int64_t chr_body_avx2(const char* str, size_t nblocks, char c) {
+  const __m256i needle = _mm256_set1_epi8(c);
+  for (size_t b = 0; b < nblocks; ++b) {
+    const __m256i v = _mm256_loadu_si256((const __m256i*)(str + 32 * b));
+    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, needle));
+    if (m) return (int64_t)(32 * b + (size_t)__builtin_ctz(m));
+  }
+  return -1;
+}
+
+__attribute__((target("avx2"))) static int64_t str_body_avx2(const char* str, size_t nblocks, const char* pat,
+                                                              size_t plen) {
+  const __m256i vf = _mm256_set1_epi8(pat[0]);
+  const __m256i vl = _mm256_set1_epi8(pat[plen - 1]);
+  for (size_t b = 0; b < nblocks; ++b) {
+    const char* p = str + 32 * b;
+    const __m256i a = _mm256_loadu_si256((const __m256i*)p);
+    const __m256i z = _mm256_loadu_si256((const __m256i*)(p + plen - 1));
+    uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpeq_epi8(a, vf), _mm256_cmpeq_epi8(z, vl)));
+    while (m) {
+      const unsigned bit = (unsigned)__builtin_ctz(m);
+      if (memcmp(p + bit + 1, pat + 1, plen - 1) == 0) return (int64_t)(32 * b + bit);
+      m &= m - 1;
+    }
+  }
+  return -1;
+}
+static int have_avx2(void) {
+  static int cached = -1;
+  if (cached < 0) cached = __builtin_cpu_supports("avx2") ? 1 : 0;
+  return cached;
+}
+#endif
+
+static int64_t chr_body(const char* str, size_t nblocks, char c) {
+#if XSO_X86
+  if (have_avx2()) return chr_body_avx2(str, nblocks, c);
+#endif
+  return chr_body_scalar(str, nblocks, c);
+}
+static int64_t str_body(const char* str, size_t nblocks, const char* pat, size_t plen) {
+#if XSO_X86
+  if (have_avx2()) return str_body_avx2(str, nblocks, pat, plen);
+#endif
+  return str_body_scalar(str, nblocks, pat, plen);
+}
+
+/* simd_search.cpp:116-144: scalar below 32 bytes, else whole 32-byte blocks
+ * then scalar on the remainder.  Exact (leftmost byte == c). */
+const char* xso_strchr(const char* str, size_t len, char c) {
+  if (len < 32) return xso_scalar_strchr(str, len, c);
+  const size_t nblocks = len / 32;
+  const int64_t hit = chr_body(str, nblocks, c);
+  if (hit >= 0) return str + hit;
+  return xso_scalar_strchr(str + 32 * nblocks, len - 32 * nblocks, c);
+}
+
+/* simd_search.cpp:162-204 */
+const char* xso_strstr(const char* str, size_t len, const char* pat, size_t plen) {
+  if (plen == 1) return xso_strchr(str, len, pat[0]); /* :164-166 */
+  if (g_exact) return exact_strstr(str, len, pat, plen);
+  if (len < 32 + plen) return xso_scalar_strstr(str, len, pat, plen); /* :169-171 */
+  /* :179-202 loops while the remaining length is >= 32+plen, 32 bytes a step */
+  const size_t nblocks = (len - plen) / 32;
+  const int64_t hit = str_body(str, nblocks, pat, plen);
+  if (hit >= 0) return str + hit;
+  return xso_scalar_strstr(str + 32 * nblocks, len - 32 * nblocks, pat, plen); /* :203 */
+}
+
+/* simd_search.cpp:289-295 */
+int64_t xso_find_next(const char* pat, size_t plen, const char* str, size_t len, size_t shift) {
+  if (shift > len) return -1;
+  const char* m = xso_strstr(str + shift, len - shift, pat, plen);
+  return m == NULL ? -1 : (int64_t)(m - str);
+}
+
+/* simd_search.cpp:297-303 */
+int64_t xso_find_next_newline(const char* str, size_t len, size_t shift) {
+  if (shift > len) return -1;
+  const char* m = xso_strchr(str + shift, len - shift, '\n');
+  return m == NULL ? -1 : (int64_t)(m - str);
+}
+
+static inline int64_t FN(const char* pat, size_t plen, const char* str, size_t len, size_t shift) {
+  return g_findnext ? g_findnext(pat, plen, str, len, shift) : xso_find_next(pat, plen, str, len, shift);
+}
+static inline int64_t NL(const char* str, size_t len, size_t shift) {
+  return g_findnl ? g_findnl(str, len, shift) : xso_find_next_newline(str, len, shift);
+}
+
+/* simd_search.cpp:305-322 (declared as findAllPerLine, simd_search.h:77) */
+uint64_t xso_count_matching_lines(const char* pat, size_t plen, const char* str, size_t len) {
+  uint64_t count = 0;
+  size_t shift = 0;
+  for (;;) {
+    int64_t m = FN(pat, plen, str, len, shift);
+    if (m < 0) break;
+    ++count;
+    shift = (size_t)m + plen;
+    m = NL(str, len, shift);
+    if (m < 0) break;
+    shift = (size_t)m + 1;
+  }
+  return count;
+}
+
+/* simd_search.cpp:324-336 (declared as findAll, simd_search.h:88) */
+uint64_t xso_count_matches(const char* pat, size_t plen, const char* str, size_t len) {
+  uint64_t count = 0;
+  size_t shift = 0;
+  for (;;) {
+    const int64_t m = FN(pat, plen, str, len, shift);
+    if (m < 0) break;
+    ++count;
+    shift = (size_t)m + plen;
+  }
+  return count;
+}
+
+/* ------------------------------------------------------------------------ */
+/* search_wrappers.h:111-123.  Distance from the match back to the byte after
+ * the previous '\n' (or to offset 0).  Returns the LINE START (v - distance);
+ * the reference returns the distance and the caller subtracts (:151-153).
+ * A match whose own first byte is '\n' yields v+1 in the reference
+ * (relative_offset - 1 wraps); reproduced here. */
+static uint64_t line_start_of(const char* data, uint64_t v) {
+  uint64_t rel = 0;
+  for (;;) {
+    if (data[v - rel] == '\n') return v - (rel - 1); /* rel==0 -> v+1, as the reference */
+    if (rel >= v) return 0;
+    ++rel;
+  }
+}
+
+/* search_wrappers.h:29-52 (generic walk) and :136-139 */
+uint64_t xso_byte_offsets_match(const char* data, size_t len, const char* pat, size_t plen, int skip_to_nl,
+                                uint64_t* out, uint64_t cap) {
+  uint64_t n = 0;
+  size_t shift = 0;
+  while (shift < len) {
+    int64_t m = FN(pat, plen, data, len, shift);
+    if (m < 0) break;
+    if (n < cap) out[n] = (uint64_t)m;
+    ++n;
+    shift = (size_t)m + plen;
+    if (skip_to_nl) {
+      m = NL(data, len, shift);
+      if (m < 0) break;
+      shift = (size_t)m + 1;
+    }
+  }
+  return n;
+}
+
+/* search_wrappers.h:149-154 */
+uint64_t xso_byte_offsets_line(const char* data, size_t len, const char* pat, size_t plen, uint64_t* out,
+                               uint64_t cap) {
+  uint64_t n = 0;
+  size_t shift = 0;
+  while (shift < len) {
+    int64_t m = FN(pat, plen, data, len, shift);
+    if (m < 0) break;
+    if (n < cap) out[n] = line_start_of(data, (uint64_t)m);
+    ++n;
+    shift = (size_t)m + plen;
+    m = NL(data, len, shift);
+    if (m < 0) break;
+    shift = (size_t)m + 1;
+  }
+  return n;
+}
+
+/* search_wrappers.h:163-185 */
+uint64_t xso_count(const char* data, size_t len, const char* pat, size_t plen, int skip_to_nl) {
+  uint64_t n = 0;
+  size_t shift = 0;
+  while (shift < len) {
+    int64_t m = FN(pat, plen, data, len, shift);
+    if (m < 0) break;
+    ++n;
+    shift = (size_t)m + plen;
+    if (skip_to_nl) {
+      m = NL(data, len, shift);
+      if (m < 0) break;
+      shift = (size_t)m + 1;
+    }
+  }
+  return n;
+}
+
+/* search_wrappers.h:187-207.  A match on a last line without '\n' ends the
+ * walk WITHOUT emitting that line (:200-202). */
+uint64_t xso_lines(const char* data, size_t len, const char* pat, size_t plen, uint64_t* begin, uint64_t* length,
+                   uint64_t cap) {
+  uint64_t n = 0;
+  size_t shift = 0;
+  while (shift < len) {
+    const int64_t m = FN(pat, plen, data, len, shift);
+    if (m < 0) break;
+    const uint64_t b = line_start_of(data, (uint64_t)m);
+    shift = (size_t)m + plen;
+    const int64_t e = NL(data, len, shift);
+    if (e < 0) break;
+    shift = (size_t)e + 1;
+    if (n < cap) {
+      begin[n] = b;
+      length[n] = (uint64_t)e - b;
+    }
+    ++n;
+  }
+  return n;
+}
+
+uint64_t xso_count_newlines(const char* data, size_t len) {
+  uint64_t n = 0;
+  const char* p = data;
+  const char* end = data + len;
+  while (p < end) {
+    const char* q = (const char*)memchr(p, '\n', (size_t)(end - p));
+    if (!q) break;
+    ++n;
+    p = q + 1;
+  }
+  return n;
+}
+
+/* xs::line_indices (no reference implementation; see header). */
+uint64_t xso_line_indices(const char* data, size_t len, const char* pat, size_t plen, uint64_t line_base,
+                          uint64_t* out, uint64_t cap) {
+  uint64_t n = 0;
+  size_t shift = 0;
+  uint64_t counted_to = 0; /* newlines in data[0, counted_to) == nl_seen */
+  uint64_t nl_seen = 0;
+  while (shift < len) {
+    int64_t m = FN(pat, plen, data, len, shift);
+    if (m < 0) break;
+    const uint64_t b = line_start_of(data, (uint64_t)m);
+    if (b > counted_to) {
+      nl_seen += xso_count_newlines(data + counted_to, b - counted_to);
+      counted_to = b;
+    }
+    if (n < cap) out[n] = line_base + nl_seen;
+    ++n;
+    shift = (size_t)m + plen;
+    m = NL(data, len, shift);
+    if (m < 0) break;
+    shift = (size_t)m + 1;
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const char* base;
+  const uint64_t* offsets;
+  const uint64_t* lengths;
+  uint64_t n;
+  const char* pat;
+  size_t plen;
+  int skip_to_nl;
+  uint64_t next; /* shared work counter */
+  uint64_t* counts_out;
+  uint64_t total;
+  pthread_mutex_t mu;
+} mt_job;
+
+static void* mt_worker(void* arg) {
+  mt_job* job = (mt_job*)arg;
+  uint64_t local = 0;
+  for (;;) {
+    const uint64_t i = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
+    if (i >= job->n) break;
+    const uint64_t c = xso_count(job->base + job->offsets[i], job->lengths[i], job->pat, job->plen, job->skip_to_nl);
+    if (job->counts_out) job->counts_out[i] = c;
+    local += c;
+  }
+  pthread_mutex_lock(&job->mu);
+  job->total += local;
+  pthread_mutex_unlock(&job->mu);
+  return NULL;
+}
+
+/* Searcher.h:100-120: workers loop "next chunk -> search -> add" until the
+ * reader is exhausted; here the reader is the shared index. */
+uint64_t xso_count_chunks_mt(const char* base, const uint64_t* offsets, const uint64_t* lengths, uint64_t n,
+                             const char* pat, size_t plen, int skip_to_nl, int nthreads, uint64_t* counts_out) {
+  mt_job job;
+  memset(&job, 0, sizeof job);
+  job.base = base;
+  job.offsets = offsets;
+  job.lengths = lengths;
+  job.n = n;
+  job.pat = pat;
+  job.plen = plen;
+  job.skip_to_nl = skip_to_nl;
+  job.counts_out = counts_out;
+  pthread_mutex_init(&job.mu, NULL);
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads == 1) {
+    mt_worker(&job);
+  } else {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, mt_worker, &job);
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    free(th);
+  }
+  pthread_mutex_destroy(&job.mu);
+  return job.total;
+}

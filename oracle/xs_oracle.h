@@ -1,0 +1,88 @@
+/*
+ * xs_oracle.h -- CPU restatement of the x-search literal hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under x-search_amd/ (the product) may
+ * include, link or call this.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and there only as the checker / the
+ * reported CPU baseline.
+ *
+ * Parity status: PINNED.  Every known-answer value of the reference's own
+ * unit tests (test/src/string_search/simd_searchTest.cpp:36-99 and
+ * test/src/string_search/search_wrappersTest.cpp:26,39,52,64-69) reproduces
+ * (tests/test_oracle_golden.py), and the primitives are cross-checked against
+ * oracle/_ref/libxsref.so, which is the reference's own
+ * src/string_search/simd_search.cpp compiled unmodified (oracle/Makefile).
+ *
+ * Each function cites the reference file:line whose behaviour it restates.
+ * All paths are relative to the reference tree.
+ */
+#ifndef XS_ORACLE_H
+#define XS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- semantics switch -------------------------------------------------- */
+/* 0 (default): reference semantics, including the lossy scalar tail of
+ *              simd::strstr (src/string_search/simd_search.cpp:58-78,203).
+ * 1          : "exact" semantics: every call returns the true leftmost
+ *              occurrence (what the reference intends; used to test the
+ *              quirk-off mode of the product). */
+void xso_set_exact(int exact);
+int xso_get_exact(void);
+
+/* Optional: route the wrappers through foreign primitives (used to drive the
+ * restated wrappers on top of oracle/_ref's findNext / findNextNewLine).
+ * Pass NULL to go back to the restated primitives. */
+typedef int64_t (*xso_findnext_fn)(const char* pat, size_t plen, const char* str, size_t len, size_t shift);
+typedef int64_t (*xso_findnl_fn)(const char* str, size_t len, size_t shift);
+void xso_use_primitives(xso_findnext_fn fn, xso_findnl_fn nl);
+
+/* ---- L0 primitives (src/string_search/simd_search.cpp) ------------------ */
+const char* xso_scalar_strstr(const char* str, size_t len, const char* pat, size_t plen);   /* :58-78  */
+const char* xso_scalar_strchr(const char* str, size_t len, int c);                          /* :107-114 */
+const char* xso_strchr(const char* str, size_t len, char c);                                /* :116-144 */
+const char* xso_strstr(const char* str, size_t len, const char* pat, size_t plen);          /* :162-204 */
+int64_t xso_find_next(const char* pat, size_t plen, const char* str, size_t len, size_t shift);  /* :289-295 */
+int64_t xso_find_next_newline(const char* str, size_t len, size_t shift);                   /* :297-303 */
+uint64_t xso_count_matching_lines(const char* pat, size_t plen, const char* str, size_t len);    /* :305-322 */
+uint64_t xso_count_matches(const char* pat, size_t plen, const char* str, size_t len);      /* :324-336 */
+
+/* ---- L1 wrappers (include/xsearch/string_search/search_wrappers.h) ------ */
+/* All "list" functions write at most `cap` entries and return the number of
+ * entries the reference would have produced (call with cap == 0 to size). */
+
+/* byte_offsets_match (:136-139) == _byte_offsets(data, pattern, skip_to_nl) (:29-52) */
+uint64_t xso_byte_offsets_match(const char* data, size_t len, const char* pat, size_t plen, int skip_to_nl,
+                                uint64_t* out, uint64_t cap);
+/* byte_offsets_line (:149-154) with previous_new_line_offset_relative_to_match (:111-123) */
+uint64_t xso_byte_offsets_line(const char* data, size_t len, const char* pat, size_t plen, uint64_t* out,
+                               uint64_t cap);
+/* count (:163-185) */
+uint64_t xso_count(const char* data, size_t len, const char* pat, size_t plen, int skip_to_nl);
+/* line (:187-207): line i is data[begin[i], begin[i]+length[i]) -- excludes '\n' (:204) */
+uint64_t xso_lines(const char* data, size_t len, const char* pat, size_t plen, uint64_t* begin, uint64_t* length,
+                   uint64_t cap);
+/* xs::line_indices -- no implementation in the reference snapshot; semantics
+ * pinned by test/src/xsearchTest.cpp:95-125 + the .meta fixtures:
+ * 0-based count of '\n' before the start of each matching line, plus
+ * `line_base` (the number of '\n' in all preceding chunks). */
+uint64_t xso_line_indices(const char* data, size_t len, const char* pat, size_t plen, uint64_t line_base,
+                          uint64_t* out, uint64_t cap);
+uint64_t xso_count_newlines(const char* data, size_t len);
+
+/* ---- chunk driver (include/xsearch/Searcher.h:100-120 worker loop) ------- */
+/* N worker threads pull chunk indices from a shared counter (work stealing,
+ * like run_thread), each runs count() on its chunk; returns the sum.
+ * counts_out (optional, n entries) receives the per-chunk results. */
+uint64_t xso_count_chunks_mt(const char* base, const uint64_t* offsets, const uint64_t* lengths, uint64_t n,
+                             const char* pat, size_t plen, int skip_to_nl, int nthreads, uint64_t* counts_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XS_ORACLE_H */

@@ -1,0 +1,280 @@
+"""ctypes front-end of the CPU oracle (oracle/xs_oracle.c) and of oracle/_ref.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product under x-search_amd/.
+
+`Oracle`     wraps libxs_oracle.so (the restatement; semantics cited per function
+             in xs_oracle.h).
+`Reference`  wraps oracle/_ref/libxsref.so = the reference's own
+             src/string_search/simd_search.cpp compiled unmodified (C++-mangled
+             names); only usable on hosts with AVX2.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+_LIB = HERE / "libxs_oracle.so"
+_REF = HERE / "_ref" / "libxsref.so"
+
+_u64p = C.POINTER(C.c_uint64)
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and oracle/_ref when /root/reference is mounted)."""
+    if force or not _LIB.exists() or _LIB.stat().st_mtime < (HERE / "xs_oracle.c").stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(HERE), "--no-print-directory"], stdout=subprocess.DEVNULL)
+    elif not _REF.exists() and Path("/root/reference/src/string_search/simd_search.cpp").exists():
+        subprocess.check_call(["make", "-C", str(HERE), "--no-print-directory", "ref"], stdout=subprocess.DEVNULL)
+
+
+def host_has_avx2() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            return " avx2 " in f.read().replace("\n", " ")
+    except OSError:
+        return False
+
+
+def _as_bytes(x) -> bytes:
+    if isinstance(x, bytes):
+        return x
+    if isinstance(x, str):
+        return x.encode("latin-1")
+    if isinstance(x, np.ndarray):
+        return x.tobytes()
+    return bytes(x)
+
+
+class _Buf:
+    """Keeps a bytes/ndarray alive and exposes (char*, len) without copying arrays."""
+
+    def __init__(self, data):
+        if isinstance(data, np.ndarray):
+            assert data.dtype == np.uint8 and data.flags.c_contiguous
+            self.keep = data
+            self.ptr = C.cast(data.ctypes.data, C.c_char_p) if data.size else C.c_char_p(b"")
+            self.addr = data.ctypes.data
+            self.len = int(data.size)
+        else:
+            b = _as_bytes(data)
+            self.keep = b
+            self.ptr = C.c_char_p(b)
+            self.addr = C.cast(self.ptr, C.c_void_p).value
+            self.len = len(b)
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        self.lib = lib = C.CDLL(str(_LIB))
+        cp, sz, i64, u64, ci = C.c_char_p, C.c_size_t, C.c_int64, C.c_uint64, C.c_int
+        vp = C.c_void_p
+        lib.xso_set_exact.argtypes = [ci]
+        lib.xso_get_exact.restype = ci
+        lib.xso_use_primitives.argtypes = [vp, vp]
+        for name in ("xso_scalar_strstr", "xso_strstr"):
+            getattr(lib, name).argtypes = [vp, sz, cp, sz]
+            getattr(lib, name).restype = vp
+        lib.xso_strchr.argtypes = [vp, sz, C.c_char]
+        lib.xso_strchr.restype = vp
+        lib.xso_find_next.argtypes = [cp, sz, vp, sz, sz]
+        lib.xso_find_next.restype = i64
+        lib.xso_find_next_newline.argtypes = [vp, sz, sz]
+        lib.xso_find_next_newline.restype = i64
+        for name in ("xso_count_matching_lines", "xso_count_matches"):
+            getattr(lib, name).argtypes = [cp, sz, vp, sz]
+            getattr(lib, name).restype = u64
+        lib.xso_byte_offsets_match.argtypes = [vp, sz, cp, sz, ci, _u64p, u64]
+        lib.xso_byte_offsets_match.restype = u64
+        lib.xso_byte_offsets_line.argtypes = [vp, sz, cp, sz, _u64p, u64]
+        lib.xso_byte_offsets_line.restype = u64
+        lib.xso_count.argtypes = [vp, sz, cp, sz, ci]
+        lib.xso_count.restype = u64
+        lib.xso_lines.argtypes = [vp, sz, cp, sz, _u64p, _u64p, u64]
+        lib.xso_lines.restype = u64
+        lib.xso_line_indices.argtypes = [vp, sz, cp, sz, u64, _u64p, u64]
+        lib.xso_line_indices.restype = u64
+        lib.xso_count_newlines.argtypes = [vp, sz]
+        lib.xso_count_newlines.restype = u64
+        lib.xso_count_chunks_mt.argtypes = [vp, _u64p, _u64p, u64, cp, sz, ci, ci, _u64p]
+        lib.xso_count_chunks_mt.restype = u64
+
+    # -- configuration ------------------------------------------------------
+    def set_exact(self, exact: bool) -> None:
+        self.lib.xso_set_exact(1 if exact else 0)
+
+    def use_reference_primitives(self, ref: "Reference | None") -> None:
+        """Route the restated wrappers through oracle/_ref's findNext/findNextNewLine."""
+        if ref is None:
+            self.lib.xso_use_primitives(None, None)
+        else:
+            self.lib.xso_use_primitives(C.cast(ref.fn_findnext, C.c_void_p), C.cast(ref.fn_findnl, C.c_void_p))
+
+    # -- primitives ---------------------------------------------------------
+    def strstr(self, data, pat) -> int:
+        """offset of the match or -1 (the C function returns a pointer)."""
+        b, p = _Buf(data), _as_bytes(pat)
+        r = self.lib.xso_strstr(b.addr, b.len, p, len(p))
+        return -1 if not r else r - b.addr
+
+    def scalar_strstr(self, data, pat) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        r = self.lib.xso_scalar_strstr(b.addr, b.len, p, len(p))
+        return -1 if not r else r - b.addr
+
+    def strchr(self, data, c) -> int:
+        b = _Buf(data)
+        r = self.lib.xso_strchr(b.addr, b.len, _as_bytes(c))
+        return -1 if not r else r - b.addr
+
+    def find_next(self, pat, data, shift=0) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self.lib.xso_find_next(p, len(p), b.addr, b.len, shift)
+
+    def find_next_newline(self, data, shift=0) -> int:
+        b = _Buf(data)
+        return self.lib.xso_find_next_newline(b.addr, b.len, shift)
+
+    def count_matches(self, pat, data) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self.lib.xso_count_matches(p, len(p), b.addr, b.len)
+
+    def count_matching_lines(self, pat, data) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self.lib.xso_count_matching_lines(p, len(p), b.addr, b.len)
+
+    # -- wrappers -----------------------------------------------------------
+    def _list(self, fn, *args) -> np.ndarray:
+        n = fn(*args, None, 0)
+        out = np.empty(n, dtype=np.uint64)
+        if n:
+            fn(*args, out.ctypes.data_as(_u64p), n)
+        return out
+
+    def byte_offsets_match(self, data, pat, skip_to_nl=False) -> np.ndarray:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self._list(self.lib.xso_byte_offsets_match, b.addr, b.len, p, len(p), 1 if skip_to_nl else 0)
+
+    def byte_offsets_line(self, data, pat) -> np.ndarray:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self._list(self.lib.xso_byte_offsets_line, b.addr, b.len, p, len(p))
+
+    def count(self, data, pat, skip_to_nl=True) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self.lib.xso_count(b.addr, b.len, p, len(p), 1 if skip_to_nl else 0)
+
+    def lines_spans(self, data, pat):
+        b, p = _Buf(data), _as_bytes(pat)
+        n = self.lib.xso_lines(b.addr, b.len, p, len(p), None, None, 0)
+        beg = np.empty(n, dtype=np.uint64)
+        ln = np.empty(n, dtype=np.uint64)
+        if n:
+            self.lib.xso_lines(b.addr, b.len, p, len(p), beg.ctypes.data_as(_u64p), ln.ctypes.data_as(_u64p), n)
+        return beg, ln
+
+    def lines(self, data, pat) -> list[bytes]:
+        raw = _as_bytes(data) if not isinstance(data, np.ndarray) else data
+        beg, ln = self.lines_spans(data, pat)
+        if isinstance(raw, np.ndarray):
+            return [raw[int(s):int(s + l)].tobytes() for s, l in zip(beg, ln)]
+        return [raw[int(s):int(s + l)] for s, l in zip(beg, ln)]
+
+    def line_indices(self, data, pat, line_base=0) -> np.ndarray:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self._list(self.lib.xso_line_indices, b.addr, b.len, p, len(p), int(line_base))
+
+    def count_newlines(self, data) -> int:
+        b = _Buf(data)
+        return self.lib.xso_count_newlines(b.addr, b.len)
+
+    def count_chunks_mt(self, data: np.ndarray, offsets, lengths, pat, skip_to_nl=False, nthreads=1):
+        b, p = _Buf(data), _as_bytes(pat)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        per = np.zeros(len(off), dtype=np.uint64)
+        tot = self.lib.xso_count_chunks_mt(b.addr, off.ctypes.data_as(_u64p), ln.ctypes.data_as(_u64p), len(off), p,
+                                           len(p), 1 if skip_to_nl else 0, int(nthreads), per.ctypes.data_as(_u64p))
+        return int(tot), per
+
+
+class Reference:
+    """The reference's own simd_search.cpp, compiled unmodified (oracle/Makefile)."""
+
+    SYM = {
+        "findNext": "_ZN2xs6search4simd8findNextEPKcmS3_mm",
+        "findNextNewLine": "_ZN2xs6search4simd15findNextNewLineEPKcmm",
+        "countMatches": "_ZN2xs6search4simd12countMatchesEPKcmS3_m",
+        "countMatchingLines": "_ZN2xs6search4simd18countMatchingLinesEPKcmS3_m",
+        "strstr": "_ZN2xs6search4simd6strstrEPKcmS3_m",
+        "strchr": "_ZN2xs6search4simd6strchrEPKcmc",
+        "scalar_strstr": "_ZN2xs6search4simd13scalar_strstrEPKcmS3_m",
+    }
+
+    @staticmethod
+    def available() -> bool:
+        build()
+        return _REF.exists() and host_has_avx2()
+
+    def __init__(self):
+        if not Reference.available():
+            raise RuntimeError("oracle/_ref/libxsref.so missing or host lacks AVX2")
+        self.lib = lib = C.CDLL(str(_REF))
+        cp, sz, i64, u64, vp = C.c_char_p, C.c_size_t, C.c_int64, C.c_uint64, C.c_void_p
+        self.fn_findnext = getattr(lib, self.SYM["findNext"])
+        self.fn_findnext.argtypes = [cp, sz, vp, sz, sz]
+        self.fn_findnext.restype = i64
+        self.fn_findnl = getattr(lib, self.SYM["findNextNewLine"])
+        self.fn_findnl.argtypes = [vp, sz, sz]
+        self.fn_findnl.restype = i64
+        self.fn_count = getattr(lib, self.SYM["countMatches"])
+        self.fn_count.argtypes = [cp, sz, vp, sz]
+        self.fn_count.restype = u64
+        self.fn_count_lines = getattr(lib, self.SYM["countMatchingLines"])
+        self.fn_count_lines.argtypes = [cp, sz, vp, sz]
+        self.fn_count_lines.restype = u64
+        self.fn_strstr = getattr(lib, self.SYM["strstr"])
+        self.fn_strstr.argtypes = [vp, sz, cp, sz]
+        self.fn_strstr.restype = vp
+        self.fn_strchr = getattr(lib, self.SYM["strchr"])
+        self.fn_strchr.argtypes = [vp, sz, C.c_char]
+        self.fn_strchr.restype = vp
+        self.fn_scalar_strstr = getattr(lib, self.SYM["scalar_strstr"])
+        self.fn_scalar_strstr.argtypes = [vp, sz, cp, sz]
+        self.fn_scalar_strstr.restype = vp
+
+    def find_next(self, pat, data, shift=0) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self.fn_findnext(p, len(p), b.addr, b.len, shift)
+
+    def find_next_newline(self, data, shift=0) -> int:
+        b = _Buf(data)
+        return self.fn_findnl(b.addr, b.len, shift)
+
+    def count_matches(self, pat, data) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self.fn_count(p, len(p), b.addr, b.len)
+
+    def count_matching_lines(self, pat, data) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        return self.fn_count_lines(p, len(p), b.addr, b.len)
+
+    def strstr(self, data, pat) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        r = self.fn_strstr(b.addr, b.len, p, len(p))
+        return -1 if not r else r - b.addr
+
+    def strchr(self, data, c) -> int:
+        b = _Buf(data)
+        r = self.fn_strchr(b.addr, b.len, _as_bytes(c))
+        return -1 if not r else r - b.addr
+
+    def scalar_strstr(self, data, pat) -> int:
+        b, p = _Buf(data), _as_bytes(pat)
+        r = self.fn_scalar_strstr(b.addr, b.len, p, len(p))
+        return -1 if not r else r - b.addr

@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_generated_vectors.json from the REFERENCE itself.
+
+Run in the build container: needs oracle/_ref/libxsref.so, i.e. the reference's
+src/string_search/simd_search.cpp compiled unmodified by oracle/Makefile.
+
+For every case the expected values are produced by the reference's own
+primitives (findNext / findNextNewLine / countMatches / countMatchingLines);
+the five wrapper outputs come from the wrapper loops of
+include/xsearch/string_search/search_wrappers.h (restated in oracle/xs_oracle.c,
+RE2 is not in the image so that header itself cannot be compiled) driven on
+top of the reference's findNext/findNextNewLine.  `line_indices` has no
+reference implementation: it is the defined semantics
+"number of '\\n' before the line start" computed by the oracle.
+
+Inputs are either stored literally (small) or regenerated from (generator,
+seed, n) by x-search_amd/corpus.py; a sha256 of the input pins the generator.
+"""
+import hashlib
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "oracle"))
+sys.path.insert(0, str(ROOT / "x-search_amd"))
+import corpus  # noqa: E402
+from xs_oracle import Oracle, Reference  # noqa: E402
+
+
+def make_input(spec) -> np.ndarray:
+    kind = spec["kind"]
+    if kind == "literal":
+        return np.frombuffer(spec["text"].encode("latin-1"), dtype=np.uint8).copy()
+    if kind == "small_alphabet":
+        return corpus.small_alphabet(spec["seed"], spec["n"], spec["alphabet"].encode("latin-1"), spec.get("terminate", False))
+    if kind == "text_block":
+        a = corpus.text_block(spec["seed"], spec["index"], spec["n"], needle=spec.get("needle", "Sherlock").encode("latin-1"),
+                              needle_rate=spec.get("needle_rate", 2.76e-6))
+        if spec.get("unterminated"):
+            a = a[:-1].copy()
+        for pos, s in spec.get("splice", []):
+            b = s.encode("latin-1")
+            p = pos if pos >= 0 else len(a) + pos
+            a[p:p + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        return a
+    raise ValueError(kind)
+
+
+def cases():
+    out = []
+
+    def lit(name, text, pats):
+        out.append({"name": name, "input": {"kind": "literal", "text": text}, "patterns": pats})
+
+    # --- tiny / edge inputs
+    lit("empty", "", ["a", "ab"])
+    lit("one_newline", "\n", ["a", "\n"])
+    lit("first_byte_newline", "\nabc abc\nxx abc", ["abc", "x", "c"])
+    lit("no_trailing_newline", "foo bar\nbar foo\nlast bar", ["bar", "foo", "last bar"])
+    lit("only_pattern", "Sherlock", ["Sherlock", "S", "k"])
+    lit("pattern_longer_than_text", "abc", ["abcd"])
+    # --- overlap / bordered patterns (greedy non-overlap, simd_search.cpp:333)
+    lit("aaaa", "aaaa", ["aa", "aaa", "a"])
+    lit("abab_run", "abababababab\nababab x abab\n", ["abab", "aba", "ab", "bab"])
+    lit("aa_lines", "aaaaa\naa\na\naaaa aaa\n" * 3, ["aa", "aaa"])
+    # --- lossy scalar tail (simd_search.cpp:58-78): documented measured cases
+    lit("tail_quirk_aaab", "aaab", ["aab"])
+    lit("tail_quirk_SheSherlock", "x" * 100 + "SheSherlock", ["Sherlock"])
+    lit("tail_quirk_padded_found", "x" * 100 + "SheSherlock" + "y" * 64, ["Sherlock"])
+    lit("tail_quirk_newline_terminated", "x" * 100 + "SheSherlock\n", ["Sherlock"])
+    lit("tail_two_matches", "q" * 90 + "\nab ab aab ab\naab\n", ["ab", "aab"])
+    # --- pattern lengths 1/2/8/110 on the reference's own unit-test text shape
+    long_line = ("smooth-bellied chirognostic inkos BVM antigraphy pagne bicorne complementizer commorant "
+                 "ever-endingly sheikhly")
+    lit("plen110", "glam predamaged\n" + long_line + "\nrefrangible terebras " + long_line + " tail\nend\n",
+        [long_line, "e", "ly", "terebras"])
+
+    # --- seeded small-alphabet inputs (dense matches, many newlines, both terminated and not)
+    pats = ["a", "aa", "ab", "aba", "abab", "ba\n"[:2], "bb", "aab"]
+    for i, n in enumerate([31, 32, 33, 63, 64, 65, 100, 257, 1000, 4096, 5000]):
+        out.append({"name": f"ab_nl_{n}", "input": {"kind": "small_alphabet", "seed": 100 + i, "n": n, "alphabet": "ab\n",
+                                                    "terminate": bool(i & 1)}, "patterns": pats})
+    for i, n in enumerate([200, 3000]):
+        out.append({"name": f"abc_sp_{n}", "input": {"kind": "small_alphabet", "seed": 200 + i, "n": n,
+                                                     "alphabet": "abc  \n", "terminate": True},
+                    "patterns": ["abc", "ab", "c a", "cab", "bca"]})
+
+    # --- realistic text blocks (the bench generator), incl. tail decoys spliced at the very end
+    out.append({"name": "text_64k", "input": {"kind": "text_block", "seed": 7, "index": 0, "n": 65536,
+                                               "needle_rate": 1e-3}, "patterns": ["Sherlock", "She", "the", "e", "lock"]})
+    out.append({"name": "text_1m", "input": {"kind": "text_block", "seed": 7, "index": 1, "n": 1 << 20,
+                                              "needle_rate": 2e-4}, "patterns": ["Sherlock", "Holmes", "detective street"]})
+    out.append({"name": "text_64k_unterminated", "input": {"kind": "text_block", "seed": 7, "index": 2, "n": 65536,
+                                                            "needle_rate": 1e-3, "unterminated": True,
+                                                            "splice": [[-9, " Sherlock"]]},
+                "patterns": ["Sherlock", "She"]})
+    out.append({"name": "text_64k_tail_decoy", "input": {"kind": "text_block", "seed": 7, "index": 3, "n": 65536,
+                                                          "needle_rate": 1e-3,
+                                                          "splice": [[-13, " SheSherlock\n"], [-40, "Sherlock"]]},
+                "patterns": ["Sherlock"]})
+    return out
+
+
+def main():
+    orc = Oracle()
+    ref = Reference()
+    orc.use_reference_primitives(ref)
+    doc = {"generator": "tests/golden/gen_golden.py", "produced_by": "oracle/_ref/libxsref.so (reference simd_search.cpp)",
+           "cases": []}
+    for c in cases():
+        data = make_input(c["input"])
+        entry = {"name": c["name"], "input": c["input"], "len": int(data.size),
+                 "sha256": hashlib.sha256(data.tobytes()).hexdigest(), "expect": []}
+        for pat in c["patterns"]:
+            p = pat.encode("latin-1")
+            has_nl = b"\n" in p
+            e = {
+                "pattern": pat,
+                "countMatches": int(ref.count_matches(p, data)),
+                "countMatchingLines": int(ref.count_matching_lines(p, data)),
+                "count_skip": int(orc.count(data, p, True)),
+                "count_noskip": int(orc.count(data, p, False)),
+                "byte_offsets_match": [int(x) for x in orc.byte_offsets_match(data, p)],
+            }
+            assert e["countMatches"] == e["count_noskip"]
+            assert e["countMatchingLines"] == e["count_skip"]
+            if not has_nl:
+                beg, ln = orc.lines_spans(data, p)
+                e["byte_offsets_line"] = [int(x) for x in orc.byte_offsets_line(data, p)]
+                e["lines_begin"] = [int(x) for x in beg]
+                e["lines_len"] = [int(x) for x in ln]
+                e["line_indices"] = [int(x) for x in orc.line_indices(data, p, 0)]
+            # a few raw findNext probes (absolute offsets), incl. shifts next to the end
+            probes = sorted({0, 1, max(0, data.size - 40), max(0, data.size - len(p) - 1), int(data.size)})
+            e["findNext"] = [[int(s), int(ref.find_next(p, data, s))] for s in probes]
+            entry["expect"].append(e)
+        doc["cases"].append(entry)
+    orc.use_reference_primitives(None)
+    out = Path(__file__).resolve().parent / "ref_generated_vectors.json"
+    out.write_text(json.dumps(doc, separators=(",", ":")))
+    print("wrote", out, out.stat().st_size, "bytes;", len(doc["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()

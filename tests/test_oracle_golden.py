@@ -1,0 +1,129 @@
+"""The oracle (oracle/xs_oracle.c) against the reference's own known answers and
+against vectors produced by the reference build (oracle/_ref) -- CPU only."""
+import numpy as np
+import pytest
+
+import golden_util as G
+
+
+def _b(s):
+    return s.encode("latin-1")
+
+
+def test_reference_simd_search_known_answers(oracle):
+    # test/src/string_search/simd_searchTest.cpp:36-99 (27 assertions)
+    ka = G.load("ref_simd_search_known_answers.json")
+    text = _b(ka["text"])
+    assert len(text) == ka["text_len"] == 1240
+    n = 0
+    for c, want in ka["strchr"]:
+        assert oracle.strchr(text, _b(c)) == want; n += 1
+    for p, want in ka["strstr"]:
+        assert oracle.strstr(text, _b(p)) == want; n += 1
+    for p, shift, want in ka["findNext"]:
+        assert oracle.find_next(_b(p), text, shift) == want; n += 1
+    for shift, want in ka["findNextNewLine"]:
+        assert oracle.find_next_newline(text, shift) == want; n += 1
+    for p, want in ka["countMatchingLines"]:
+        assert oracle.count_matching_lines(_b(p), text) == want; n += 1
+    for p, want in ka["countMatches"]:
+        assert oracle.count_matches(_b(p), text) == want; n += 1
+    assert n == 32  # 4 + 5 + 7 + 4 + 6 + 6
+
+
+def test_reference_search_wrappers_known_answers(oracle):
+    # test/src/string_search/search_wrappersTest.cpp:26,39,52,64-69
+    ka = G.load("ref_search_wrappers_known_answers.json")
+    text, pat = _b(ka["text"]), _b(ka["pattern"])
+    assert oracle.byte_offsets_match(text, pat).tolist() == ka["byte_offsets_match"]
+    assert oracle.byte_offsets_line(text, pat).tolist() == ka["byte_offsets_line"]
+    assert oracle.count(text, pat) == ka["count"]
+    assert oracle.lines(text, pat) == [_b(s) for s in ka["line"]]
+    # the stale expectation differs only by the trailing newline
+    assert [l + b"\n" for l in oracle.lines(text, pat)] == [_b(s) for s in ka["line_as_asserted_stale"]]
+    assert oracle.line_indices(text, pat).tolist() == [0, 2, 3, 8]
+
+
+def test_generated_vectors(oracle):
+    n = 0
+    for name, data, e in G.generated_cases():
+        p = _b(e["pattern"])
+        ctx = f"{name} pat={e['pattern']!r}"
+        assert oracle.count_matches(p, data) == e["countMatches"], ctx
+        assert oracle.count_matching_lines(p, data) == e["countMatchingLines"], ctx
+        assert oracle.count(data, p, True) == e["count_skip"], ctx
+        assert oracle.count(data, p, False) == e["count_noskip"], ctx
+        assert oracle.byte_offsets_match(data, p).tolist() == e["byte_offsets_match"], ctx
+        if "byte_offsets_line" in e:
+            assert oracle.byte_offsets_line(data, p).tolist() == e["byte_offsets_line"], ctx
+            beg, ln = oracle.lines_spans(data, p)
+            assert beg.tolist() == e["lines_begin"] and ln.tolist() == e["lines_len"], ctx
+            assert oracle.line_indices(data, p).tolist() == e["line_indices"], ctx
+        for shift, want in e["findNext"]:
+            assert oracle.find_next(p, data, shift) == want, ctx
+        n += 1
+    assert n > 100
+
+
+def test_lossy_tail_is_reproduced(oracle):
+    # measured behaviour of the reference
+    assert oracle.find_next(b"aab", b"aaab") == -1
+    assert oracle.find_next(b"Sherlock", b"x" * 100 + b"SheSherlock") == -1
+    assert oracle.find_next(b"Sherlock", b"x" * 100 + b"SheSherlock" + b"y" * 64) == 103
+    oracle.set_exact(True)
+    try:
+        assert oracle.find_next(b"aab", b"aaab") == 1
+        assert oracle.find_next(b"Sherlock", b"x" * 100 + b"SheSherlock") == 103
+    finally:
+        oracle.set_exact(False)
+
+
+def test_restatement_equals_reference_build_on_random_inputs(oracle, reference):
+    """Live cross-check against oracle/_ref (only where the reference build exists)."""
+    rng = np.random.default_rng(12345)
+    pats = [b"a", b"aa", b"ab", b"aba", b"abab", b"bab", b"aab", b"abc", b"ab\n"]
+    alph = np.frombuffer(b"ab\n", dtype=np.uint8)
+    for it in range(4000):
+        n = int(rng.integers(0, 300))
+        data = alph[rng.integers(0, 3 if it % 3 else 2, size=n)].copy()
+        p = pats[int(rng.integers(0, len(pats)))]
+        shift = int(rng.integers(0, n + 2))
+        assert oracle.find_next(p, data, shift) == reference.find_next(p, data, shift)
+        assert oracle.find_next_newline(data, shift) == reference.find_next_newline(data, shift)
+        assert oracle.count_matches(p, data) == reference.count_matches(p, data)
+        assert oracle.count_matching_lines(p, data) == reference.count_matching_lines(p, data)
+        assert oracle.scalar_strstr(data, p) == reference.scalar_strstr(data, p)
+
+
+def test_wrappers_over_reference_primitives_equal_restated(oracle, reference):
+    rng = np.random.default_rng(777)
+    alph = np.frombuffer(b"ab \n", dtype=np.uint8)
+    pats = [b"a", b"aa", b"ab", b"aba", b"abab", b"b a", b"aab"]
+    for it in range(1500):
+        n = int(rng.integers(0, 500))
+        data = alph[rng.integers(0, 4, size=n)].copy()
+        p = pats[int(rng.integers(0, len(pats)))]
+        got = (oracle.byte_offsets_match(data, p).tolist(), oracle.byte_offsets_line(data, p).tolist(),
+               oracle.count(data, p, True), oracle.count(data, p, False),
+               [x.tolist() for x in oracle.lines_spans(data, p)], oracle.line_indices(data, p).tolist())
+        oracle.use_reference_primitives(reference)
+        try:
+            want = (oracle.byte_offsets_match(data, p).tolist(), oracle.byte_offsets_line(data, p).tolist(),
+                    oracle.count(data, p, True), oracle.count(data, p, False),
+                    [x.tolist() for x in oracle.lines_spans(data, p)], oracle.line_indices(data, p).tolist())
+        finally:
+            oracle.use_reference_primitives(None)
+        assert got == want
+
+
+def test_chunk_driver_matches_single_thread(oracle):
+    import corpus
+    blocks = [corpus.text_block(3, i, 200_000 + 1000 * i, needle_rate=1e-3) for i in range(7)]
+    off, ln, cap = corpus.chunk_table([b.size for b in blocks])
+    buf = np.zeros(cap, dtype=np.uint8)
+    for o, b in zip(off, blocks):
+        buf[int(o):int(o) + b.size] = b
+    want = [oracle.count(b, b"Sherlock", False) for b in blocks]
+    for nt in (1, 4):
+        tot, per = oracle.count_chunks_mt(buf, off, ln, b"Sherlock", False, nt)
+        assert per.tolist() == want and tot == sum(want)
