@@ -1,0 +1,164 @@
+/*
+ * xsg.h -- C ABI of the MI355X literal-scan engine (libxsg.so).
+ *
+ * This is the drop-in boundary for the hot path of lfreist/x-search: the
+ * per-chunk literal search that the reference implements in
+ *   src/string_search/simd_search.cpp                       (AVX2 primitives)
+ *   include/xsearch/string_search/search_wrappers.h:29-207  (per-chunk walks)
+ * and calls from the task functors include/xsearch/tasks/searchers.h:38-93
+ * inside the worker loop include/xsearch/Searcher.h:100-120.
+ *
+ * Everything here is plain C: opaque handles, pointers and sizes.  No torch
+ * or C++ types cross this boundary.  The C++ surface the reference's users see
+ * (xs::extern_search<Tag>(...)->join()/getResult()) is the header-only layer
+ * include/xsearch/xsearch.h on top of this ABI; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Results are bit-identical to the reference's CPU path on the same chunk
+ * bytes, including its end-of-chunk behaviour (see XSG_FLAG_EXACT_TAIL).
+ *
+ * Threading: a ctx may be used from several host threads as long as each
+ * thread works on its own shard; calls on ONE shard must not overlap.
+ * All functions return XSG_OK (0) or a negative XSG_E* code;
+ * xsg_last_error() gives the message of the calling thread's last failure.
+ * There is NO CPU fallback: without a usable HIP device every compute entry
+ * point fails with XSG_ENODEV.
+ */
+#ifndef XSG_H
+#define XSG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XSG_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define XSG_OK 0
+#define XSG_EINVAL (-1)   /* bad argument (empty pattern, misaligned chunk, ...) */
+#define XSG_ENODEV (-2)   /* no HIP device / device index out of range */
+#define XSG_EHIP (-3)     /* a HIP runtime call failed (message has the HIP error) */
+#define XSG_ENOMEM (-4)   /* host or device allocation failed */
+#define XSG_ENOTSUP (-5)  /* valid request this entry point cannot serve (see docs) */
+#define XSG_EIO (-6)      /* file open/read/parse failure */
+#define XSG_ESTATE (-7)   /* call sequence error (e.g. result fetched before search) */
+
+/* ---- what to compute: one value per xs:: tag ----------------------------- */
+/* README.md:71-81 / test/src/xsearchTest.cpp:344 name the tags; the function
+ * of search_wrappers.h each one maps to is given on the right. */
+enum xsg_mode {
+  XSG_COUNT_MATCHES = 0,      /* xs::count, xs::count_matches -> search::count(data, p, false)   (:163-185) */
+  XSG_COUNT_LINES = 1,        /* xs::count_lines              -> search::count(data, p, true)    (:163-185) */
+  XSG_MATCH_BYTE_OFFSETS = 2, /* xs::match_byte_offsets       -> search::byte_offsets_match      (:136-139) */
+  XSG_LINE_BYTE_OFFSETS = 3,  /* xs::line_byte_offsets        -> search::byte_offsets_line       (:149-154) */
+  XSG_LINE_INDICES = 4,       /* xs::line_indices             -> (no reference impl)     */
+  XSG_LINES = 5               /* xs::lines                    -> search::line                    (:187-207) */
+};
+
+/* ---- pattern flags ------------------------------------------------------- */
+/* Default (0): reproduce the reference exactly, including the lossy scalar
+ * search it applies to the last <plen+32 bytes of every chunk
+ * (simd_search.cpp:58-78,203).  With XSG_FLAG_EXACT_TAIL every occurrence in
+ * the chunk is reported (what the reference intends). */
+#define XSG_FLAG_EXACT_TAIL 0x1u
+
+#define XSG_MAX_PATTERN 1024u
+
+/* ---- counters written by the count entry points --------------------------- */
+#define XSG_CTR_MATCHES 0  /* XSG_COUNT_MATCHES result */
+#define XSG_CTR_LINES 1    /* XSG_COUNT_LINES result   */
+#define XSG_CTR_NEWLINES 2 /* number of '\n' in the shard (only if requested) */
+#define XSG_CTR_BYTES 3    /* bytes scanned */
+#define XSG_NUM_COUNTERS 4
+
+/* OR into `mode` of the count entry points to also count '\n' (needed to
+ * derive line-index bases across GPUs). */
+#define XSG_WITH_NEWLINES 0x100u
+
+/* line_base value meaning "derive from the preceding chunks of this shard" */
+#define XSG_LINE_BASE_AUTO UINT64_MAX
+
+typedef struct xsg_ctx xsg_ctx;     /* one per (process, device): streams, pattern, scratch */
+typedef struct xsg_shard xsg_shard; /* a set of chunks resident in device memory */
+
+/* A chunk = what the reference's reader hands to a searcher functor
+ * (tasks/readers.h:39-48 -> tasks/searchers.h:49): a run of bytes that is
+ * searched on its own.  No match or line spans two chunks. */
+typedef struct xsg_chunk {
+  uint64_t offset;        /* byte offset of the chunk inside the shard buffer; multiple of 16 */
+  uint64_t length;        /* chunk length in bytes (< 2^40) */
+  uint64_t global_offset; /* offset of the chunk in the (uncompressed) file: added to every reported byte offset */
+  uint64_t line_base;     /* number of '\n' in the file before this chunk, or XSG_LINE_BASE_AUTO */
+} xsg_chunk;
+
+/* ---- library ------------------------------------------------------------- */
+int xsg_abi_version(void);
+const char* xsg_strerror(int code);
+const char* xsg_last_error(void);
+int xsg_device_count(int* count);
+
+/* ---- context -------------------------------------------------------------- */
+int xsg_ctx_create(int device, xsg_ctx** out);
+void xsg_ctx_destroy(xsg_ctx* ctx);
+/* Literal pattern, 1..XSG_MAX_PATTERN bytes, any byte values.  Patterns
+ * containing '\n' are accepted for XSG_COUNT_MATCHES / XSG_MATCH_BYTE_OFFSETS
+ * only (the line modes return XSG_ENOTSUP for them). */
+int xsg_set_pattern(xsg_ctx* ctx, const void* pattern, size_t plen, uint32_t flags);
+
+/* ---- shards ---------------------------------------------------------------- */
+/* d_base/capacity: device memory owned by the caller (hipMalloc, a torch
+ * tensor's data_ptr(), ...), must stay valid and unchanged while searches run.
+ * Requirements: d_base 16-byte aligned; for every chunk offset % 16 == 0 and
+ * offset + round_up(length,16) <= capacity; chunks must not overlap and must
+ * be listed in increasing offset order.  The table is copied. */
+int xsg_shard_create(xsg_ctx* ctx, const void* d_base, uint64_t capacity, const xsg_chunk* chunks, uint64_t nchunks,
+                     xsg_shard** out);
+/* Re-point an existing shard at a new chunk table (same or different buffer)
+ * without re-allocating its scratch when the new table is not larger. */
+int xsg_shard_rebind(xsg_shard* shard, const void* d_base, uint64_t capacity, const xsg_chunk* chunks,
+                     uint64_t nchunks);
+void xsg_shard_destroy(xsg_shard* shard);
+/* line-index base of the whole shard for XSG_LINE_BASE_AUTO chunks (default 0):
+ * the number of '\n' in all shards that precede this one in the file. */
+int xsg_shard_set_line_base(xsg_shard* shard, uint64_t line_base);
+
+/* ---- counting (replaces search::count, search_wrappers.h:163-185) ---------- */
+/* Asynchronous: enqueues the scan on `stream` (a hipStream_t, NULL = the
+ * ctx's own stream) and returns.  d_counters: device memory for
+ * XSG_NUM_COUNTERS uint64 values, overwritten by the call.  Serves
+ * XSG_COUNT_MATCHES (optionally | XSG_WITH_NEWLINES) for patterns that cannot
+ * overlap themselves, and XSG_COUNT_LINES; otherwise XSG_ENOTSUP -> use xsg_count. */
+int xsg_count_async(xsg_shard* shard, uint32_t mode, void* stream, uint64_t* d_counters);
+/* Synchronous, any pattern, XSG_COUNT_MATCHES or XSG_COUNT_LINES
+ * (| XSG_WITH_NEWLINES): result in host memory. */
+int xsg_count(xsg_shard* shard, uint32_t mode, uint64_t counters[XSG_NUM_COUNTERS]);
+
+/* ---- list results (replace byte_offsets_match/_line, line; :136-154,187-207) */
+/* Runs the search for one of the list modes on the ctx stream and waits.
+ * *n_results = number of elements (offsets / indices / lines).  Results stay
+ * in device memory owned by the shard until the next search on it. */
+int xsg_search(xsg_shard* shard, uint32_t mode, uint64_t* n_results);
+/* Copy the uint64 results of the last XSG_MATCH_BYTE_OFFSETS /
+ * XSG_LINE_BYTE_OFFSETS / XSG_LINE_INDICES search, ascending, to host memory. */
+int xsg_result_u64(xsg_shard* shard, uint64_t* out, uint64_t cap);
+/* After an XSG_LINES search: total number of line bytes (no '\n's). */
+int xsg_result_lines_size(xsg_shard* shard, uint64_t* n_lines, uint64_t* total_bytes);
+/* line i = bytes[ starts[i] .. starts[i] + lengths[i] ), in file order;
+ * `offsets` (optional) receives the global byte offset of each line start. */
+int xsg_result_lines(xsg_shard* shard, uint64_t* lengths, char* bytes, uint64_t bytes_cap, uint64_t* offsets);
+
+/* ---- diagnostics ------------------------------------------------------------ */
+/* Name of the device the ctx is bound to (e.g. "gfx950..."), CU count. */
+int xsg_ctx_info(xsg_ctx* ctx, char* arch, size_t arch_cap, int* compute_units, uint64_t* hbm_bytes);
+/* Time the dominant kernel alone: runs the bulk scan kernel of the given count
+ * mode `iters` times back to back on the ctx stream between two HIP events and
+ * returns the average milliseconds per launch (bench.py's roofline figure). */
+int xsg_time_scan_kernel(xsg_shard* shard, uint32_t mode, int iters, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XSG_H */

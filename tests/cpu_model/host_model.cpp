@@ -1,0 +1,151 @@
+// host_model.cpp -- TEST INFRASTRUCTURE.  Replays, on the CPU, the exact
+// decomposition the GPU path uses, built from the product's own host/device
+// headers (xsg_tail.h, xsg_linesum.h):
+//
+//   bulk  : every occurrence starting at o < limit, decided position by position
+//   keep  : greedy non-overlap (match modes) / first occurrence per line (line modes)
+//   tail  : the reference walk replayed over [limit, L) by xsg::tail_walk
+//   lines : per-16-byte-unit summaries reduced with xsg::sum_combine in tile order
+//
+// tests/test_host_model.py checks it against the oracle on many random inputs,
+// so that the algorithm is known to be right before it ever runs on a GPU.
+// It is NOT a fallback: nothing under x-search_amd/ links or loads this.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../x-search_amd/csrc/xsg_linesum.h"
+#include "../../x-search_amd/csrc/xsg_tail.h"
+
+using namespace xsg;
+
+static uint64_t bulk_limit(uint64_t L, uint32_t plen, int exact) {
+  if (exact) return L >= plen ? L - plen + 1 : 0;
+  return tail_zone_begin(L, plen);
+}
+
+static std::vector<uint64_t> bulk_occ(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t plen, int exact) {
+  std::vector<uint64_t> v;
+  const uint64_t lim = bulk_limit(L, plen, exact);
+  for (uint64_t o = 0; o < lim; ++o)
+    if (memcmp(d + o, p, plen) == 0) v.push_back(o);
+  return v;
+}
+
+static uint64_t line_start(const uint8_t* d, uint64_t o) {
+  while (o > 0 && d[o - 1] != '\n') --o;
+  return o;
+}
+
+static uint64_t walk_entry(const uint8_t* d, uint64_t L, uint64_t last_end, bool skip) {
+  if (last_end == 0) return 0;
+  if (!skip) return last_end;
+  const int64_t nl = next_newline(d, last_end, L);
+  return nl < 0 ? UINT64_MAX : (uint64_t)nl + 1;
+}
+
+// final list of (line start | match offset, first match of the line)
+static void model_list(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t plen, int exact, int line_mode,
+                       std::vector<uint64_t>& pos, std::vector<uint64_t>& first_match) {
+  std::vector<uint64_t> occ = bulk_occ(d, L, p, plen, exact);
+  uint64_t last_end = 0;
+  if (line_mode) {
+    uint64_t prev_ls = UINT64_MAX;
+    for (uint64_t o : occ) {
+      const uint64_t ls = line_start(d, o);
+      if (ls != prev_ls) {
+        pos.push_back(ls);
+        first_match.push_back(o);
+        last_end = o + plen;
+        prev_ls = ls;
+      }
+    }
+  } else {
+    uint64_t last = 0;
+    bool have = false;
+    for (uint64_t o : occ) {
+      if (!have || o >= last + plen) {
+        pos.push_back(o);
+        first_match.push_back(o);
+        last = o;
+        have = true;
+        last_end = o + plen;
+      }
+    }
+  }
+  if (!exact && plen > 1) {
+    std::vector<uint64_t> t(tail_max_matches(plen) + 1);
+    const uint32_t n = tail_walk(d, L, p, plen, walk_entry(d, L, last_end, line_mode != 0), line_mode != 0, t.data(),
+                                 (uint32_t)t.size());
+    for (uint32_t k = 0; k < n; ++k) {
+      pos.push_back(line_mode ? line_start(d, t[k]) : t[k]);
+      first_match.push_back(t[k]);
+    }
+  }
+}
+
+extern "C" {
+
+uint64_t hm_list(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t plen, int exact, int line_mode, uint64_t* out,
+                 uint64_t cap) {
+  std::vector<uint64_t> pos, fm;
+  model_list(d, L, p, plen, exact, line_mode, pos, fm);
+  for (uint64_t i = 0; i < pos.size() && i < cap; ++i) out[i] = pos[i];
+  return pos.size();
+}
+
+// XSG_LINES: (begin,len) of reported lines; unterminated last line dropped
+uint64_t hm_lines(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t plen, int exact, uint64_t* beg,
+                  uint64_t* len, uint64_t cap) {
+  std::vector<uint64_t> pos, fm;
+  model_list(d, L, p, plen, exact, 1, pos, fm);
+  uint64_t n = 0;
+  for (size_t i = 0; i < pos.size(); ++i) {
+    const int64_t e = next_newline(d, fm[i] + plen, L);
+    if (e < 0) continue;
+    if (n < cap) {
+      beg[n] = pos[i];
+      len[n] = (uint64_t)e - pos[i];
+    }
+    ++n;
+  }
+  return n;
+}
+
+// the async count path: per-tile counts + chunk_last_end + tail walk
+uint64_t hm_count_matches_borderfree(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t plen, int exact) {
+  std::vector<uint64_t> occ = bulk_occ(d, L, p, plen, exact);
+  uint64_t n = occ.size();
+  const uint64_t last_end = occ.empty() ? 0 : occ.back() + plen;
+  if (!exact && plen > 1) n += tail_walk(d, L, p, plen, walk_entry(d, L, last_end, false), false, nullptr, 0);
+  return n;
+}
+
+// the async count_lines path: unit summaries reduced in groups of `group`
+// units (any grouping must give the same answer), + tail walk
+uint64_t hm_count_lines(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t plen, int exact, uint32_t group) {
+  std::vector<uint64_t> occ = bulk_occ(d, L, p, plen, exact);
+  const uint64_t nunits = (L + 15) / 16;
+  std::vector<uint32_t> us(nunits, 0);
+  std::vector<uint32_t> h(nunits, 0), n(nunits, 0);
+  for (uint64_t o : occ) h[o / 16] |= 1u << (o % 16);
+  for (uint64_t i = 0; i < L; ++i)
+    if (d[i] == '\n') n[i / 16] |= 1u << (i % 16);
+  for (uint64_t u = 0; u < nunits; ++u) us[u] = sum_of_unit(h[u], n[u]);
+  if (group < 1) group = 1;
+  // two-level reduction like lanes -> tiles -> chunk
+  uint32_t total = 0;
+  bool have = false;
+  for (uint64_t g = 0; g < nunits; g += group) {
+    uint32_t s = us[g];
+    for (uint64_t u = g + 1; u < g + group && u < nunits; ++u) s = sum_combine(s, us[u]);
+    total = have ? sum_combine(total, s) : s;
+    have = true;
+  }
+  uint64_t lines = have ? sum_total_lines(total) : 0;
+  const uint64_t last_end = occ.empty() ? 0 : occ.back() + plen;
+  if (!exact && plen > 1) lines += tail_walk(d, L, p, plen, walk_entry(d, L, last_end, true), true, nullptr, 0);
+  return lines;
+}
+
+}  // extern "C"

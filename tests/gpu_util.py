@@ -1,0 +1,89 @@
+"""Helpers for the -m gpu tests: put chunks into device memory (torch is only
+the allocator here) and run the C-ABI searches through x-search_amd/xsg.py."""
+import numpy as np
+
+import corpus
+import xsg
+
+
+def upload(blocks, global_offsets=None, line_bases=None):
+    """blocks: list of uint8 arrays -> (device tensor, chunk table)."""
+    import torch
+    lengths = [int(b.size) for b in blocks]
+    off, ln, cap = corpus.chunk_table(lengths)
+    host = np.zeros(max(cap, 256), dtype=np.uint8)
+    for o, b in zip(off, blocks):
+        host[int(o):int(o) + b.size] = b
+    t = torch.from_numpy(host).to("cuda:0")
+    chunks = xsg.make_chunks(off, ln, global_offsets, line_bases)
+    return t, chunks
+
+
+class GpuSearch:
+    """One context + one shard, re-bound per case."""
+
+    def __init__(self):
+        self.ctx = xsg.Context(0)
+        self.shard = None
+        self.keep = None
+
+    def bind(self, blocks, global_offsets=None, line_bases=None):
+        t, chunks = upload(blocks, global_offsets, line_bases)
+        self.keep = t
+        if self.shard is None:
+            self.shard = xsg.Shard(self.ctx, t.data_ptr(), t.numel(), chunks)
+        else:
+            self.shard.rebind(t.data_ptr(), t.numel(), chunks)
+        return chunks
+
+    def all_modes(self, pattern: bytes, flags=0, lines=True):
+        """-> dict with every xs:: tag's result for the bound shard."""
+        self.ctx.set_pattern(pattern, flags)
+        s = self.shard
+        out = {}
+        c = s.count(xsg.COUNT_MATCHES | xsg.WITH_NEWLINES)
+        out["count_matches"] = int(c[xsg.CTR_MATCHES])
+        out["newlines"] = int(c[xsg.CTR_NEWLINES])
+        out["bytes"] = int(c[xsg.CTR_BYTES])
+        out["match_byte_offsets"] = s.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
+        if lines and b"\n" not in pattern:
+            out["count_lines"] = int(s.count(xsg.COUNT_LINES)[xsg.CTR_LINES])
+            out["line_byte_offsets"] = s.search_u64(xsg.LINE_BYTE_OFFSETS).tolist()
+            out["line_indices"] = s.search_u64(xsg.LINE_INDICES).tolist()
+            ls, lo = s.search_lines()
+            out["lines"] = ls
+            out["lines_offsets"] = lo.tolist()
+        return out
+
+
+def oracle_all_modes(oracle, blocks, pattern: bytes, exact=False, global_offsets=None, line_bases=None):
+    """The same dict from the CPU oracle, chunk by chunk (chunks are independent
+    units: include/xsearch/Searcher.h:100-120 hands each to the searcher alone)."""
+    oracle.set_exact(bool(exact))
+    try:
+        out = {"count_matches": 0, "newlines": 0, "bytes": 0, "match_byte_offsets": [], "count_lines": 0,
+               "line_byte_offsets": [], "line_indices": [], "lines": [], "lines_offsets": []}
+        goff, nl_before = 0, 0
+        for i, b in enumerate(blocks):
+            g = goff if global_offsets is None else int(global_offsets[i])
+            lb = nl_before if line_bases is None else int(line_bases[i])
+            out["count_matches"] += oracle.count(b, pattern, False)
+            out["match_byte_offsets"] += [int(x) + g for x in oracle.byte_offsets_match(b, pattern)]
+            if b"\n" not in pattern:
+                out["count_lines"] += oracle.count(b, pattern, True)
+                out["line_byte_offsets"] += [int(x) + g for x in oracle.byte_offsets_line(b, pattern)]
+                out["line_indices"] += [int(x) for x in oracle.line_indices(b, pattern, lb)]
+                beg, ln = oracle.lines_spans(b, pattern)
+                out["lines"] += [b[int(s):int(s + l)].tobytes() for s, l in zip(beg, ln)]
+                out["lines_offsets"] += [int(s) + g for s in beg]
+            nl = oracle.count_newlines(b)
+            out["newlines"] += nl
+            out["bytes"] += int(b.size)
+            goff += int(b.size)
+            nl_before += nl
+        if b"\n" in pattern:
+            for k in ("count_lines", "line_byte_offsets", "line_indices", "lines", "lines_offsets"):
+                out.pop(k)
+        return out
+    finally:
+        oracle.set_exact(False)

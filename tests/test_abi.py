@@ -1,0 +1,49 @@
+"""CPU-side checks of the drop-in boundary: libxsg.so loads, exports every
+symbol include/xsg.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import xsg
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_functions():
+    src = (ROOT / "include" / "xsg.h").read_text()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(xsg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(str(xsg.lib_path()))
+    names = declared_functions()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/xsg.h but not exported by libxsg.so"
+    assert sorted(xsg.EXPORTS) == names, "x-search_amd/xsg.py binds a different set than include/xsg.h declares"
+    assert lib.xsg_abi_version() == 1
+
+
+def test_chunk_struct_layout_matches_header():
+    assert xsg.CHUNK_DTYPE.itemsize == 32
+    assert [xsg.CHUNK_DTYPE.fields[k][1] for k in ("offset", "length", "global_offset", "line_base")] == [0, 8, 16, 24]
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the loud-failure path is for GPU-less hosts")
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.Context(0)
+    assert e.value.code == xsg.ENODEV
+    assert "device" in str(e.value).lower()
+
+
+def test_strerror_covers_all_codes():
+    lib = xsg.load()
+    for code in (0, -1, -2, -3, -4, -5, -6, -7):
+        assert lib.xsg_strerror(code) not in (None, b"unknown error")

@@ -1,0 +1,195 @@
+"""Parity of the HIP path (through the C ABI, libxsg.so) with the oracle and
+with the committed golden vectors.  Bit-exact: this is integer/byte work.
+Run on the GPU box: python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+
+import corpus
+import golden_util as G
+import xsg
+from gpu_util import GpuSearch, oracle_all_modes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gs():
+    return GpuSearch()
+
+
+def _b(s):
+    return s.encode("latin-1")
+
+
+def assert_same(got, want, ctx=""):
+    for k in want:
+        assert got[k] == want[k], f"{ctx}: {k} differs: got {str(got[k])[:200]} want {str(want[k])[:200]}"
+
+
+def test_library_is_the_hip_one(gs):
+    info = gs.ctx.info()
+    assert info["arch"].startswith("gfx950"), info
+    assert info["compute_units"] >= 200
+
+
+def test_reference_unit_test_known_answers(gs):
+    # test/src/string_search/simd_searchTest.cpp:83-99, search_wrappersTest.cpp:26-69
+    ka = G.load("ref_simd_search_known_answers.json")
+    text = np.frombuffer(_b(ka["text"]), dtype=np.uint8)
+    gs.bind([text])
+    for p, want in ka["countMatches"]:
+        gs.ctx.set_pattern(_b(p))
+        assert int(gs.shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == want, p
+    for p, want in ka["countMatchingLines"]:
+        gs.ctx.set_pattern(_b(p))
+        assert int(gs.shard.count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == want, p
+    for p, shift, want in ka["findNext"]:
+        if shift == 0:
+            gs.ctx.set_pattern(_b(p))
+            offs = gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
+            assert (offs[0] if offs else -1) == want, p
+    kw = G.load("ref_search_wrappers_known_answers.json")
+    gs.bind([np.frombuffer(_b(kw["text"]), dtype=np.uint8)])
+    r = gs.all_modes(_b(kw["pattern"]))
+    assert r["match_byte_offsets"] == kw["byte_offsets_match"]
+    assert r["line_byte_offsets"] == kw["byte_offsets_line"]
+    assert r["count_lines"] == kw["count"]
+    assert r["lines"] == [_b(s) for s in kw["line"]]
+    assert r["line_indices"] == [0, 2, 3, 8]
+
+
+def test_golden_vectors_from_the_reference_build(gs):
+    """tests/golden/ref_generated_vectors.json was produced by oracle/_ref
+    (the reference's simd_search.cpp compiled unmodified)."""
+    last = None
+    n = 0
+    for name, data, e in G.generated_cases():
+        if name != last:
+            gs.bind([data])
+            last = name
+        p = _b(e["pattern"])
+        r = gs.all_modes(p)
+        ctx = f"{name} pat={e['pattern']!r}"
+        assert r["count_matches"] == e["countMatches"], ctx
+        assert r["match_byte_offsets"] == e["byte_offsets_match"], ctx
+        if "byte_offsets_line" in e:
+            assert r["count_lines"] == e["countMatchingLines"], ctx
+            assert r["line_byte_offsets"] == e["byte_offsets_line"], ctx
+            assert r["line_indices"] == e["line_indices"], ctx
+            assert r["lines_offsets"] == e["lines_begin"], ctx
+            assert [len(x) for x in r["lines"]] == e["lines_len"], ctx
+            assert r["lines"] == [data[b:b + l].tobytes() for b, l in zip(e["lines_begin"], e["lines_len"])], ctx
+        n += 1
+    assert n > 100
+
+
+PATTERNS = [b"a", b"ab", b"aa", b"aba", b"abab", b"bab", b"abc ", b"ab ab", b"abcabca", b"abababab", b"ab ab ab a",
+            b"a" * 17, b"b\na"]
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_random_multi_chunk_shards_vs_oracle(gs, oracle, exact):
+    rng = np.random.default_rng(4242 + int(exact))
+    alph = np.frombuffer(b"ab \nc", dtype=np.uint8)
+    flags = xsg.FLAG_EXACT_TAIL if exact else 0
+    for it in range(12):
+        nchunks = int(rng.integers(1, 6))
+        blocks = []
+        for _ in range(nchunks):
+            n = int(rng.choice([0, 1, 15, 16, 17, 1023, 1024, 1025, 4096, 16383, 16384, 16385, 40000,
+                                int(rng.integers(2, 70000))]))
+            blocks.append(alph[rng.integers(0, 3 + it % 3, size=n)].copy())
+        gs.bind(blocks)
+        for p in PATTERNS:
+            got = gs.all_modes(p, flags)
+            want = oracle_all_modes(oracle, blocks, p, exact)
+            assert_same(got, want, f"it={it} exact={exact} pat={p!r} sizes={[b.size for b in blocks]}")
+
+
+def test_text_blocks_all_pattern_kinds(gs, oracle):
+    blocks = [corpus.text_block(11, i, 300_000 + 4111 * i, needle_rate=3e-4) for i in range(5)]
+    blocks[2] = blocks[2][:-1].copy()  # an unterminated chunk end
+    long_pat = bytes(blocks[1][1000:1110])
+    assert b"\n" not in long_pat or True
+    gs.bind(blocks)
+    pats = [b"e", b"th", b"the", b"that", b"She", b"lock", b"Sherl", b"Holmes", b"Sherlock", b"detective",
+            b"detective street", b"Sherlock Holmes", b"\x00", b"\xff\xfe", bytes(blocks[0][77:77 + 33])]
+    if b"\n" not in long_pat:
+        pats.append(long_pat)
+    for exact in (False, True):
+        for p in pats:
+            got = gs.all_modes(p, xsg.FLAG_EXACT_TAIL if exact else 0)
+            want = oracle_all_modes(oracle, blocks, p, exact)
+            assert_same(got, want, f"exact={exact} pat={p[:20]!r}")
+
+
+def test_global_offsets_and_explicit_line_bases(gs, oracle):
+    blocks = [corpus.text_block(5, i, 70_000, needle_rate=1e-3) for i in range(3)]
+    goffs = [1_000_000, 5_000_000_000, 5_000_070_000]
+    lbases = [10, 1_000_000, 1_000_000 + 7]
+    gs.bind(blocks, goffs, lbases)
+    got = gs.all_modes(b"Sherlock")
+    want = oracle_all_modes(oracle, blocks, b"Sherlock", False, goffs, lbases)
+    assert_same(got, want)
+    # AUTO bases + a shard base (what a rank with preceding shards would set)
+    gs.bind(blocks)
+    gs.shard.set_line_base(12345)
+    gs.ctx.set_pattern(b"Sherlock")
+    got = gs.shard.search_u64(xsg.LINE_INDICES).tolist()
+    want = oracle_all_modes(oracle, blocks, b"Sherlock")["line_indices"]
+    assert got == [x + 12345 for x in want]
+    gs.shard.set_line_base(0)
+
+
+def test_empty_and_degenerate_shards(gs, oracle):
+    z = np.zeros(0, dtype=np.uint8)
+    for blocks in ([], [z], [z, z], [np.frombuffer(b"x", dtype=np.uint8)], [np.frombuffer(b"Sherlock", dtype=np.uint8)]):
+        gs.bind(blocks)
+        for p in (b"x", b"Sherlock", b"Sherlock Holmes"):
+            assert_same(gs.all_modes(p), oracle_all_modes(oracle, blocks, p), f"{[b.size for b in blocks]} {p!r}")
+
+
+def test_argument_errors(gs):
+    with pytest.raises(xsg.XsgError) as e:
+        gs.ctx.set_pattern(b"")
+    assert e.value.code == xsg.EINVAL
+    with pytest.raises(xsg.XsgError):
+        gs.ctx.set_pattern(b"x" * (xsg.MAX_PATTERN + 1))
+    gs.bind([np.frombuffer(b"a\nb\n", dtype=np.uint8)])
+    gs.ctx.set_pattern(b"a\n")
+    with pytest.raises(xsg.XsgError) as e:
+        gs.shard.search_u64(xsg.LINE_BYTE_OFFSETS)
+    assert e.value.code == xsg.ENOTSUP
+    # misaligned chunk offset
+    import torch
+    t = torch.zeros(4096, dtype=torch.uint8, device="cuda:0")
+    bad = xsg.make_chunks([8], [100])
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.Shard(gs.ctx, t.data_ptr(), t.numel(), bad)
+    assert e.value.code == xsg.EINVAL
+    bad = xsg.make_chunks([0], [5000])
+    with pytest.raises(xsg.XsgError):
+        xsg.Shard(gs.ctx, t.data_ptr(), t.numel(), bad)
+
+
+def test_async_count_on_a_caller_stream(gs, oracle):
+    import torch
+    blocks = [corpus.text_block(21, i, 1 << 20, needle_rate=2e-4) for i in range(4)]
+    gs.bind(blocks)
+    gs.ctx.set_pattern(b"Sherlock")
+    ctr = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        gs.shard.count_async(xsg.COUNT_MATCHES | xsg.WITH_NEWLINES, st.cuda_stream, ctr.data_ptr())
+        gs.shard.count_async(xsg.COUNT_MATCHES | xsg.WITH_NEWLINES, st.cuda_stream, ctr.data_ptr())
+    st.synchronize()
+    want = oracle_all_modes(oracle, blocks, b"Sherlock")
+    got = ctr.cpu().numpy().astype(np.uint64)
+    assert int(got[xsg.CTR_MATCHES]) == want["count_matches"]
+    assert int(got[xsg.CTR_NEWLINES]) == want["newlines"]
+    assert int(got[xsg.CTR_BYTES]) == want["bytes"]
+    # bordered pattern: the async entry point refuses, the sync one answers
+    gs.ctx.set_pattern(b"abab")
+    with pytest.raises(xsg.XsgError) as e:
+        gs.shard.count_async(xsg.COUNT_MATCHES, 0, ctr.data_ptr())
+    assert e.value.code == xsg.ENOTSUP

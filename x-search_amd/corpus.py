@@ -82,6 +82,8 @@ def chunk_table(lengths) -> tuple[np.ndarray, np.ndarray, int]:
     """Pack chunks of the given lengths at 256-byte aligned offsets.
     Returns (offsets, lengths, capacity) -- the shard layout xsg_shard_create expects."""
     lengths = np.asarray(lengths, dtype=np.uint64)
+    if lengths.size == 0:
+        return np.zeros(0, dtype=np.uint64), lengths, 0
     padded = (lengths + np.uint64(255)) // np.uint64(256) * np.uint64(256)
     # keep at least 256 readable bytes after every chunk
     padded = padded + np.uint64(256)

@@ -1,0 +1,708 @@
+// xsg_api.cpp -- the C ABI of include/xsg.h: contexts, shards, count and list
+// searches on device-resident chunks.  Host glue only; the kernels are in
+// xsg_kernels.hip.  There is no CPU fallback anywhere in this file: every
+// compute entry point needs a HIP device and fails with XSG_ENODEV/XSG_EHIP
+// otherwise.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "xsg_internal.h"
+#include "xsg_tail.h"
+
+using namespace xsg;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) return fail(XSG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                      __FILE__, __LINE__);                                              \
+  } while (0)
+
+#define XSG_TRY(expr)        \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != XSG_OK) return _r; \
+  } while (0)
+
+extern "C" int xsg_abi_version(void) { return XSG_ABI_VERSION; }
+
+extern "C" const char* xsg_strerror(int code) {
+  switch (code) {
+    case XSG_OK: return "ok";
+    case XSG_EINVAL: return "invalid argument";
+    case XSG_ENODEV: return "no usable HIP device";
+    case XSG_EHIP: return "HIP runtime error";
+    case XSG_ENOMEM: return "out of memory";
+    case XSG_ENOTSUP: return "not supported by this entry point";
+    case XSG_EIO: return "I/O error";
+    case XSG_ESTATE: return "call sequence error";
+    default: return "unknown error";
+  }
+}
+extern "C" const char* xsg_last_error(void) { return g_err; }
+
+extern "C" int xsg_device_count(int* count) {
+  if (!count) return fail(XSG_EINVAL, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(XSG_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return XSG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device buffers (grow-only)
+// ---------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap && p) return XSG_OK;
+    if (bytes == 0) bytes = 16;
+    // grow geometrically so that repeated searches with slowly growing results do not re-allocate
+    size_t want = std::max(bytes, cap + cap / 2);
+    want = (want + 255) & ~(size_t)255;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(XSG_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return XSG_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct xsg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<uint8_t> pattern;
+  uint32_t flags = 0;
+  bool bordered = false;  // the pattern can overlap itself
+  PatternDev pat{};
+  DevBuf d_pat;
+  char arch[128] = "";
+  int cus = 0;
+  uint64_t hbm = 0;
+};
+
+extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
+  if (!out) return fail(XSG_EINVAL, "out is null");
+  *out = nullptr;
+  int n = 0;
+  XSG_TRY(xsg_device_count(&n));
+  if (n <= 0) return fail(XSG_ENODEV, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(XSG_ENODEV, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  xsg_ctx* c = new (std::nothrow) xsg_ctx();
+  if (!c) return fail(XSG_ENOMEM, "host allocation failed");
+  c->device = device;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(XSG_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  }
+  snprintf(c->arch, sizeof c->arch, "%s", prop.gcnArchName);
+  c->cus = prop.multiProcessorCount;
+  c->hbm = prop.totalGlobalMem;
+  if (strncmp(c->arch, "gfx950", 6) != 0) {
+    // the code objects in this library are gfx950 only
+    std::string a = c->arch;
+    delete c;
+    return fail(XSG_ENODEV, "device %d is %s; this library carries gfx950 (MI355X) code only", device, a.c_str());
+  }
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(XSG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return XSG_OK;
+}
+
+extern "C" void xsg_ctx_destroy(xsg_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+  }
+  c->d_pat.release();
+  delete c;
+}
+
+extern "C" int xsg_ctx_info(xsg_ctx* c, char* arch, size_t arch_cap, int* compute_units, uint64_t* hbm_bytes) {
+  if (!c) return fail(XSG_EINVAL, "ctx is null");
+  if (arch && arch_cap) snprintf(arch, arch_cap, "%s", c->arch);
+  if (compute_units) *compute_units = c->cus;
+  if (hbm_bytes) *hbm_bytes = c->hbm;
+  return XSG_OK;
+}
+
+static uint32_t le32(const uint8_t* p, size_t n) {
+  uint32_t v = 0;
+  for (size_t i = 0; i < 4 && i < n; ++i) v |= (uint32_t)p[i] << (8 * i);
+  return v;
+}
+static uint32_t mask32(size_t n) { return n >= 4 ? 0xffffffffu : (n == 0 ? 0u : ((1u << (8 * n)) - 1u)); }
+
+extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uint32_t flags) {
+  if (!c) return fail(XSG_EINVAL, "ctx is null");
+  if (!pattern || plen == 0) return fail(XSG_EINVAL, "empty pattern");
+  if (plen > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "pattern longer than %u bytes", XSG_MAX_PATTERN);
+  if (flags & ~XSG_FLAG_EXACT_TAIL) return fail(XSG_EINVAL, "unknown pattern flags 0x%x", flags);
+  HIP_TRY(hipSetDevice(c->device));
+  const uint8_t* p = static_cast<const uint8_t*>(pattern);
+  c->pattern.assign(p, p + plen);
+  c->flags = flags;
+  // border <=> the pattern can overlap itself (KMP failure function of the last position > 0)
+  std::vector<uint32_t> pi(plen, 0);
+  for (size_t i = 1, k = 0; i < plen; ++i) {
+    while (k > 0 && p[i] != p[k]) k = pi[k - 1];
+    if (p[i] == p[k]) ++k;
+    pi[i] = (uint32_t)k;
+  }
+  c->bordered = pi[plen - 1] > 0;
+
+  // padded device copy (the long-pattern verify and the tail walk read it)
+  XSG_TRY(c->d_pat.ensure(XSG_MAX_PATTERN + 16));
+  std::vector<uint8_t> padded(XSG_MAX_PATTERN + 16, 0);
+  memcpy(padded.data(), p, plen);
+  HIP_TRY(hipMemcpyAsync(c->d_pat.p, padded.data(), padded.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+
+  PatternDev& P = c->pat;
+  P.plen = (uint32_t)plen;
+  P.p0 = le32(p, plen);
+  P.m0 = mask32(plen);
+  P.p1 = plen > 4 ? le32(p + 4, plen - 4) : 0u;
+  P.m1 = plen > 4 ? mask32(plen - 4) : 0u;
+  P.kind = plen < 4 ? kMask1 : plen == 4 ? kOne : plen < 8 ? kMask2 : plen == 8 ? kTwo : kLong;
+  P.d_pat = c->d_pat.as<uint8_t>();
+  P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;
+  P.has_newline = memchr(p, '\n', plen) != nullptr;
+  return XSG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// shards
+// ---------------------------------------------------------------------------
+struct xsg_shard {
+  xsg_ctx* ctx = nullptr;
+  const uint8_t* base = nullptr;
+  uint64_t capacity = 0;
+  std::vector<xsg_chunk> chunks;
+  std::vector<uint64_t> chunk_tile0;
+  uint64_t ntiles = 0;
+  uint64_t total_bytes = 0;
+  uint64_t shard_line_base = 0;
+
+  DevBuf d_chunks, d_tile_chunk, d_chunk_tile0;
+  DevBuf d_tile_cnt, d_tile_nl, d_tile_sum, d_chunk_last, d_counters;
+  DevBuf d_tile_off, d_tile_nl_off, d_scan_tmp;
+  DevBuf d_m_pos, d_m_chunk, d_m_ls, d_keep, d_keep_pre;
+  DevBuf d_chunk_shift0, d_tail_cnt, d_tail_pos, d_tail_pre;
+  DevBuf d_f_pos, d_f_match, d_f_chunk, d_out_u64, d_line_len, d_line_off, d_line_bytes;
+
+  int last_mode = -1;
+  uint64_t total = 0;       // elements of the last list search
+  uint64_t line_bytes = 0;  // XSG_LINES: packed bytes
+  std::vector<uint64_t> h_line_len, h_line_off;
+
+  void release_all() {
+    DevBuf* all[] = {&d_chunks, &d_tile_chunk, &d_chunk_tile0, &d_tile_cnt, &d_tile_nl, &d_tile_sum, &d_chunk_last,
+                     &d_counters, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls, &d_keep,
+                     &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
+                     &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes};
+    for (DevBuf* b : all) b->release();
+  }
+};
+
+static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const xsg_chunk* chunks, uint64_t nchunks) {
+  xsg_ctx* c = s->ctx;
+  if (nchunks && !chunks) return fail(XSG_EINVAL, "chunks is null");
+  if (nchunks && !d_base) return fail(XSG_EINVAL, "d_base is null");
+  if (((uintptr_t)d_base & 15u) != 0) return fail(XSG_EINVAL, "d_base is not 16-byte aligned");
+  if (nchunks >= (1ull << 32)) return fail(XSG_EINVAL, "too many chunks");
+  uint64_t prev_end = 0, ntiles = 0, total = 0;
+  std::vector<uint64_t> tile0(nchunks + 1, 0);
+  for (uint64_t i = 0; i < nchunks; ++i) {
+    const xsg_chunk& k = chunks[i];
+    if (k.offset & 15u) return fail(XSG_EINVAL, "chunk %llu: offset %llu is not a multiple of 16", (unsigned long long)i,
+                                    (unsigned long long)k.offset);
+    if (k.length >= (1ull << 40)) return fail(XSG_EINVAL, "chunk %llu: length too large", (unsigned long long)i);
+    const uint64_t rl = (k.length + 15u) & ~(uint64_t)15u;
+    if (k.offset < prev_end) return fail(XSG_EINVAL, "chunk %llu overlaps its predecessor or is out of order",
+                                         (unsigned long long)i);
+    if (k.offset + rl > capacity || k.offset + rl < k.offset)
+      return fail(XSG_EINVAL, "chunk %llu: offset+round_up(length,16) exceeds the shard capacity",
+                  (unsigned long long)i);
+    prev_end = k.offset + k.length;
+    tile0[i] = ntiles;
+    ntiles += (k.length + kTile - 1) / kTile;
+    total += k.length;
+  }
+  tile0[nchunks] = ntiles;
+  HIP_TRY(hipSetDevice(c->device));
+
+  s->base = static_cast<const uint8_t*>(d_base);
+  s->capacity = capacity;
+  s->chunks.assign(chunks, chunks + nchunks);
+  s->chunk_tile0 = std::move(tile0);
+  s->ntiles = ntiles;
+  s->total_bytes = total;
+  s->last_mode = -1;
+  s->total = 0;
+
+  XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
+  XSG_TRY(s->d_chunk_last.ensure(8 * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_tile_cnt.ensure(4 * std::max<uint64_t>(ntiles, 1)));
+  XSG_TRY(s->d_counters.ensure(8 * XSG_NUM_COUNTERS));
+  static_assert(sizeof(ChunkDev) == sizeof(xsg_chunk), "layout");
+  if (nchunks)
+    HIP_TRY(hipMemcpyAsync(s->d_chunks.p, s->chunks.data(), sizeof(xsg_chunk) * nchunks, hipMemcpyHostToDevice,
+                           c->stream));
+  HIP_TRY(hipMemcpyAsync(s->d_chunk_tile0.p, s->chunk_tile0.data(), 8 * (nchunks + 1), hipMemcpyHostToDevice,
+                         c->stream));
+  if (nchunks > 1) {
+    std::vector<uint32_t> map(ntiles);
+    for (uint64_t i = 0; i < nchunks; ++i)
+      for (uint64_t t = s->chunk_tile0[i]; t < s->chunk_tile0[i + 1]; ++t) map[t] = (uint32_t)i;
+    XSG_TRY(s->d_tile_chunk.ensure(4 * std::max<uint64_t>(ntiles, 1)));
+    if (ntiles) HIP_TRY(hipMemcpyAsync(s->d_tile_chunk.p, map.data(), 4 * ntiles, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `map` is a local
+  } else {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return XSG_OK;
+}
+
+extern "C" int xsg_shard_create(xsg_ctx* c, const void* d_base, uint64_t capacity, const xsg_chunk* chunks,
+                                uint64_t nchunks, xsg_shard** out) {
+  if (!c) return fail(XSG_EINVAL, "ctx is null");
+  if (!out) return fail(XSG_EINVAL, "out is null");
+  *out = nullptr;
+  xsg_shard* s = new (std::nothrow) xsg_shard();
+  if (!s) return fail(XSG_ENOMEM, "host allocation failed");
+  s->ctx = c;
+  int r = bind_shard(s, d_base, capacity, chunks, nchunks);
+  if (r != XSG_OK) {
+    s->release_all();
+    delete s;
+    return r;
+  }
+  *out = s;
+  return XSG_OK;
+}
+
+extern "C" int xsg_shard_rebind(xsg_shard* s, const void* d_base, uint64_t capacity, const xsg_chunk* chunks,
+                                uint64_t nchunks) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  return bind_shard(s, d_base, capacity, chunks, nchunks);
+}
+
+extern "C" void xsg_shard_destroy(xsg_shard* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  s->release_all();
+  delete s;
+}
+
+extern "C" int xsg_shard_set_line_base(xsg_shard* s, uint64_t line_base) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  s->shard_line_base = line_base;
+  return XSG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// counting
+// ---------------------------------------------------------------------------
+static ScanArgs scan_args(xsg_shard* s) {
+  ScanArgs a{};
+  a.base = s->base;
+  a.chunks = s->d_chunks.as<ChunkDev>();
+  a.tile_chunk = s->chunks.size() > 1 ? s->d_tile_chunk.as<uint32_t>() : nullptr;
+  a.chunk_tile0 = s->d_chunk_tile0.as<uint64_t>();
+  a.ntiles = s->ntiles;
+  a.pat = s->ctx->pat;
+  a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
+  a.tile_nl = s->d_tile_nl.as<uint32_t>();
+  a.tile_sum = s->d_tile_sum.as<uint32_t>();
+  a.chunk_last_end = s->d_chunk_last.as<unsigned long long>();
+  return a;
+}
+
+static int check_ready(xsg_shard* s) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  if (s->ctx->pattern.empty()) return fail(XSG_ESTATE, "xsg_set_pattern has not been called");
+  return XSG_OK;
+}
+
+static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool want_nl, hipStream_t st,
+                         uint64_t* d_counters) {
+  if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
+  if (want_lines) XSG_TRY(s->d_tile_sum.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
+  const uint64_t nchunks = s->chunks.size();
+  HIP_TRY(hipMemsetAsync(s->d_chunk_last.p, 0, 8 * std::max<uint64_t>(nchunks, 1), st));
+  HIP_TRY(hipMemsetAsync(d_counters, 0, 8 * XSG_NUM_COUNTERS, st));
+  ScanArgs a = scan_args(s);
+  HIP_TRY(launch_scan_count(a, want_nl, want_lines, st));
+  FinishArgs f{};
+  f.base = s->base;
+  f.chunks = a.chunks;
+  f.chunk_tile0 = a.chunk_tile0;
+  f.nchunks = nchunks;
+  f.ntiles = s->ntiles;
+  f.pat = a.pat;
+  f.tile_cnt = a.tile_cnt;
+  f.tile_nl = a.tile_nl;
+  f.tile_sum = a.tile_sum;
+  f.chunk_last_end = a.chunk_last_end;
+  f.counters = d_counters;
+  f.want_nl = want_nl;
+  f.want_lines = want_lines;
+  f.want_matches = want_matches;
+  HIP_TRY(launch_count_finish(f, st));
+  return XSG_OK;
+}
+
+extern "C" int xsg_count_async(xsg_shard* s, uint32_t mode, void* stream, uint64_t* d_counters) {
+  XSG_TRY(check_ready(s));
+  if (!d_counters) return fail(XSG_EINVAL, "d_counters is null");
+  const uint32_t m = mode & 0xffu;
+  const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
+  if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+  if (m == XSG_COUNT_MATCHES) {
+    if (c->bordered)
+      return fail(XSG_ENOTSUP, "pattern can overlap itself: the greedy non-overlap count needs xsg_count()");
+    return enqueue_count(s, true, false, want_nl, st, d_counters);
+  }
+  if (m == XSG_COUNT_LINES) {
+    if (c->pat.has_newline) return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+    return enqueue_count(s, false, true, want_nl, st, d_counters);
+  }
+  return fail(XSG_EINVAL, "xsg_count_async: mode %u is not a count mode", m);
+}
+
+static int run_list(xsg_shard* s, uint32_t mode, bool outputs);
+
+extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_COUNTERS]) {
+  XSG_TRY(check_ready(s));
+  if (!counters) return fail(XSG_EINVAL, "counters is null");
+  const uint32_t m = mode & 0xffu;
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  if (m != XSG_COUNT_MATCHES && m != XSG_COUNT_LINES) return fail(XSG_EINVAL, "mode %u is not a count mode", m);
+  if (m == XSG_COUNT_MATCHES && c->bordered) {
+    // greedy non-overlap needs the ordered occurrence list
+    XSG_TRY(run_list(s, XSG_MATCH_BYTE_OFFSETS, false));
+    memset(counters, 0, 8 * XSG_NUM_COUNTERS);
+    counters[XSG_CTR_MATCHES] = s->total;
+    counters[XSG_CTR_BYTES] = s->total_bytes;
+    if (mode & XSG_WITH_NEWLINES) {
+      uint64_t tmp[XSG_NUM_COUNTERS];
+      XSG_TRY(enqueue_count(s, false, false, true, c->stream, s->d_counters.as<uint64_t>()));
+      HIP_TRY(hipMemcpyAsync(tmp, s->d_counters.p, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      counters[XSG_CTR_NEWLINES] = tmp[XSG_CTR_NEWLINES];
+    }
+    s->last_mode = -1;
+    return XSG_OK;
+  }
+  XSG_TRY(xsg_count_async(s, mode, c->stream, s->d_counters.as<uint64_t>()));
+  HIP_TRY(hipMemcpyAsync(counters, s->d_counters.p, 8 * XSG_NUM_COUNTERS, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XSG_OK;
+}
+
+extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, float* avg_ms) {
+  XSG_TRY(check_ready(s));
+  if (!avg_ms || iters <= 0) return fail(XSG_EINVAL, "bad iters/avg_ms");
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  const uint32_t m = mode & 0xffu;
+  const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
+  const bool want_lines = m == XSG_COUNT_LINES;
+  if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
+  if (want_lines) XSG_TRY(s->d_tile_sum.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
+  HIP_TRY(hipMemsetAsync(s->d_chunk_last.p, 0, 8 * std::max<size_t>(s->chunks.size(), 1), c->stream));
+  ScanArgs a = scan_args(s);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(launch_scan_count(a, want_nl, want_lines, c->stream));  // warm-up
+  HIP_TRY(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch_scan_count(a, want_nl, want_lines, c->stream));
+  HIP_TRY(hipEventRecord(e1, c->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / (float)iters;
+  return XSG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// list searches
+// ---------------------------------------------------------------------------
+static int d2h_u64(xsg_ctx* c, const uint64_t* d, uint64_t* h) {
+  HIP_TRY(hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XSG_OK;
+}
+
+static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
+  xsg_ctx* c = s->ctx;
+  hipStream_t st = c->stream;
+  const bool line_mode = mode != XSG_MATCH_BYTE_OFFSETS;
+  const bool want_nl = mode == XSG_LINE_INDICES;
+  const uint64_t nchunks = s->chunks.size();
+  const uint64_t ntiles = s->ntiles;
+  if (line_mode && c->pat.has_newline)
+    return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+
+  s->last_mode = -1;
+  s->total = 0;
+  s->line_bytes = 0;
+
+  // 1. bulk count per tile
+  if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(ntiles, 1)));
+  HIP_TRY(hipMemsetAsync(s->d_chunk_last.p, 0, 8 * std::max<uint64_t>(nchunks, 1), st));
+  ScanArgs a = scan_args(s);
+  HIP_TRY(launch_scan_count(a, want_nl, false, st));
+
+  // 2. ranks
+  XSG_TRY(s->d_tile_off.ensure(8 * (ntiles + 1)));
+  XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(std::max<uint64_t>(ntiles, nchunks) + 1)));
+  HIP_TRY(launch_exclusive_scan_u32(a.tile_cnt, s->d_tile_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(), st));
+  uint64_t M = 0;
+  XSG_TRY(d2h_u64(c, s->d_tile_off.as<uint64_t>() + ntiles, &M));
+
+  // 3. ordered emission of every bulk occurrence
+  XSG_TRY(s->d_m_pos.ensure(8 * std::max<uint64_t>(M, 1)));
+  XSG_TRY(s->d_m_chunk.ensure(4 * std::max<uint64_t>(M, 1)));
+  a.tile_off = s->d_tile_off.as<uint64_t>();
+  a.m_pos = s->d_m_pos.as<uint64_t>();
+  a.m_chunk = s->d_m_chunk.as<uint32_t>();
+  if (M) HIP_TRY(launch_scan_emit(a, st));
+
+  // 4. which occurrences the reference walk reports
+  XSG_TRY(s->d_keep.ensure(4 * std::max<uint64_t>(M, 1)));
+  XSG_TRY(s->d_keep_pre.ensure(8 * (M + 1)));
+  XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(std::max<uint64_t>(M, std::max<uint64_t>(ntiles, nchunks)) + 1)));
+  if (line_mode) XSG_TRY(s->d_m_ls.ensure(8 * std::max<uint64_t>(M, 1)));
+  const uint32_t tail_cap = std::max<uint32_t>(tail_max_matches(c->pat.plen), 1u);
+  XSG_TRY(s->d_chunk_shift0.ensure(8 * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_tail_cnt.ensure(4 * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_tail_pos.ensure(8 * std::max<uint64_t>(nchunks, 1) * tail_cap));
+  XSG_TRY(s->d_tail_pre.ensure(8 * (nchunks + 1)));
+
+  ListArgs l{};
+  l.base = s->base;
+  l.chunks = a.chunks;
+  l.chunk_tile0 = a.chunk_tile0;
+  l.nchunks = nchunks;
+  l.pat = c->pat;
+  l.M = M;
+  l.m_pos = a.m_pos;
+  l.m_chunk = a.m_chunk;
+  l.tile_off = a.tile_off;
+  l.m_ls = s->d_m_ls.as<uint64_t>();
+  l.keep = s->d_keep.as<uint32_t>();
+  l.keep_pre = s->d_keep_pre.as<uint64_t>();
+  l.chunk_shift0 = s->d_chunk_shift0.as<uint64_t>();
+  l.tail_cnt = s->d_tail_cnt.as<uint32_t>();
+  l.tail_pos = s->d_tail_pos.as<uint64_t>();
+  l.tail_cap = tail_cap;
+  l.tail_pre = s->d_tail_pre.as<uint64_t>();
+  l.line_mode = line_mode ? 1u : 0u;
+
+  if (line_mode) {
+    HIP_TRY(launch_line_starts(l, st));
+    HIP_TRY(launch_line_keep(l, st));
+  } else if (c->bordered) {
+    HIP_TRY(launch_greedy_keep(l, st));
+  } else {
+    HIP_TRY(launch_keep_all(l, st));
+  }
+  HIP_TRY(launch_exclusive_scan_u32(l.keep, s->d_keep_pre.as<uint64_t>(), M, s->d_scan_tmp.as<uint64_t>(), st));
+
+  // 5. the tail zone of every chunk, replayed as the reference walks it
+  HIP_TRY(launch_chunk_shift0(l, st));
+  HIP_TRY(launch_tail_list(l, st));
+  HIP_TRY(launch_exclusive_scan_u32(l.tail_cnt, s->d_tail_pre.as<uint64_t>(), nchunks, s->d_scan_tmp.as<uint64_t>(), st));
+  uint64_t kept = 0, tails = 0;
+  HIP_TRY(hipMemcpyAsync(&kept, s->d_keep_pre.as<uint64_t>() + M, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&tails, s->d_tail_pre.as<uint64_t>() + nchunks, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint64_t total = kept + tails;
+  s->total = total;
+  if (!outputs) return XSG_OK;
+
+  // 6. final list, in file order
+  XSG_TRY(s->d_f_pos.ensure(8 * std::max<uint64_t>(total, 1)));
+  XSG_TRY(s->d_f_match.ensure(8 * std::max<uint64_t>(total, 1)));
+  XSG_TRY(s->d_f_chunk.ensure(4 * std::max<uint64_t>(total, 1)));
+  XSG_TRY(s->d_out_u64.ensure(8 * std::max<uint64_t>(total, 1)));
+  l.f_pos = s->d_f_pos.as<uint64_t>();
+  l.f_match = s->d_f_match.as<uint64_t>();
+  l.f_chunk = s->d_f_chunk.as<uint32_t>();
+  l.total = total;
+  HIP_TRY(launch_assemble(l, st));
+
+  LineOutArgs o{};
+  o.base = s->base;
+  o.chunks = a.chunks;
+  o.chunk_tile0 = a.chunk_tile0;
+  o.nchunks = nchunks;
+  o.pat = c->pat;
+  o.total = total;
+  o.f_pos = l.f_pos;
+  o.f_match = l.f_match;
+  o.f_chunk = l.f_chunk;
+  o.out_u64 = s->d_out_u64.as<uint64_t>();
+  o.shard_line_base = s->shard_line_base;
+
+  if (mode == XSG_MATCH_BYTE_OFFSETS || mode == XSG_LINE_BYTE_OFFSETS) {
+    HIP_TRY(launch_globalize(o, st));
+  } else if (mode == XSG_LINE_INDICES) {
+    XSG_TRY(s->d_tile_nl_off.ensure(8 * (ntiles + 1)));
+    HIP_TRY(launch_exclusive_scan_u32(a.tile_nl, s->d_tile_nl_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(),
+                                      st));
+    o.tile_nl_off = s->d_tile_nl_off.as<uint64_t>();
+    HIP_TRY(launch_line_indices(o, st));
+  } else {  // XSG_LINES
+    XSG_TRY(s->d_line_len.ensure(8 * std::max<uint64_t>(total, 1)));
+    XSG_TRY(s->d_line_off.ensure(8 * (total + 1)));
+    XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(total + 1)));
+    o.line_len = s->d_line_len.as<uint64_t>();
+    HIP_TRY(launch_line_lengths(o, st));
+    HIP_TRY(launch_exclusive_scan_u64(o.line_len, s->d_line_off.as<uint64_t>(), total, s->d_scan_tmp.as<uint64_t>(), st));
+    uint64_t nbytes = 0;
+    XSG_TRY(d2h_u64(c, s->d_line_off.as<uint64_t>() + total, &nbytes));
+    XSG_TRY(s->d_line_bytes.ensure(std::max<uint64_t>(nbytes, 1)));
+    o.line_out_off = s->d_line_off.as<uint64_t>();
+    o.line_bytes = s->d_line_bytes.as<uint8_t>();
+    HIP_TRY(launch_line_gather(o, st));
+    s->line_bytes = nbytes;
+    s->h_line_len.resize(total);
+    s->h_line_off.resize(total + 1);
+    if (total) HIP_TRY(hipMemcpyAsync(s->h_line_len.data(), o.line_len, 8 * total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_line_off.data(), o.line_out_off, 8 * (total + 1), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (mode == XSG_LINES) {
+    // lines without a terminating '\n' are not reported (search_wrappers.h:199-202)
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < total; ++i) n += s->h_line_len[i] != UINT64_MAX;
+    s->total = n;
+  }
+  s->last_mode = (int)mode;
+  return XSG_OK;
+}
+
+extern "C" int xsg_search(xsg_shard* s, uint32_t mode, uint64_t* n_results) {
+  XSG_TRY(check_ready(s));
+  if (mode != XSG_MATCH_BYTE_OFFSETS && mode != XSG_LINE_BYTE_OFFSETS && mode != XSG_LINE_INDICES &&
+      mode != XSG_LINES)
+    return fail(XSG_EINVAL, "xsg_search: mode %u is not a list mode", mode);
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  XSG_TRY(run_list(s, mode, true));
+  if (n_results) *n_results = s->total;
+  return XSG_OK;
+}
+
+extern "C" int xsg_result_u64(xsg_shard* s, uint64_t* out, uint64_t cap) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  if (s->last_mode != XSG_MATCH_BYTE_OFFSETS && s->last_mode != XSG_LINE_BYTE_OFFSETS &&
+      s->last_mode != XSG_LINE_INDICES)
+    return fail(XSG_ESTATE, "no uint64 list result is pending on this shard");
+  if (cap < s->total) return fail(XSG_EINVAL, "output capacity %llu < %llu results", (unsigned long long)cap,
+                                  (unsigned long long)s->total);
+  if (s->total == 0) return XSG_OK;
+  if (!out) return fail(XSG_EINVAL, "out is null");
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(out, s->d_out_u64.p, 8 * s->total, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XSG_OK;
+}
+
+extern "C" int xsg_result_lines_size(xsg_shard* s, uint64_t* n_lines, uint64_t* total_bytes) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  if (s->last_mode != XSG_LINES) return fail(XSG_ESTATE, "no XSG_LINES result is pending on this shard");
+  if (n_lines) *n_lines = s->total;
+  if (total_bytes) *total_bytes = s->line_bytes;
+  return XSG_OK;
+}
+
+extern "C" int xsg_result_lines(xsg_shard* s, uint64_t* lengths, char* bytes, uint64_t bytes_cap, uint64_t* offsets) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  if (s->last_mode != XSG_LINES) return fail(XSG_ESTATE, "no XSG_LINES result is pending on this shard");
+  if (bytes_cap < s->line_bytes) return fail(XSG_EINVAL, "bytes_cap too small");
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  const uint64_t raw = s->h_line_len.size();
+  std::vector<uint64_t> goff;
+  if (offsets && raw) {
+    goff.resize(raw);
+    HIP_TRY(hipMemcpyAsync(goff.data(), s->d_out_u64.p, 8 * raw, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (s->line_bytes) {
+    if (!bytes) return fail(XSG_EINVAL, "bytes is null");
+    HIP_TRY(hipMemcpyAsync(bytes, s->d_line_bytes.p, s->line_bytes, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // dropped (unterminated) lines own no bytes, so the packed bytes are already contiguous
+  uint64_t k = 0;
+  for (uint64_t i = 0; i < raw; ++i) {
+    if (s->h_line_len[i] == UINT64_MAX) continue;
+    if (lengths) lengths[k] = s->h_line_len[i];
+    if (offsets) offsets[k] = goff[i];
+    ++k;
+  }
+  return XSG_OK;
+}

@@ -1,0 +1,157 @@
+// xsg_internal.h -- shared between the HIP kernels (xsg_kernels.hip) and the
+// C-ABI host code (xsg_api.cpp).  Not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/xsg.h"
+
+namespace xsg {
+
+// ---- tile geometry ---------------------------------------------------------
+// A workgroup of 4 wave64s scans one tile.  Each lane reads kLoads 16-byte
+// units; a wave-instruction therefore covers 1 KiB of consecutive bytes
+// (fully coalesced global_load_dwordx4), a wave covers a contiguous span of
+// kLoads KiB and the tile is the 4 spans back to back.
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kLoads = 4;
+constexpr uint32_t kUnit = 16;
+constexpr uint32_t kWaveLoad = 64 * kUnit;
+constexpr uint32_t kWaveSpan = kWaveLoad * kLoads;
+constexpr uint32_t kTile = kWaveSpan * kWaves;
+
+// Same layout as xsg_chunk (include/xsg.h).
+struct ChunkDev {
+  uint64_t offset;
+  uint64_t length;
+  uint64_t global_offset;
+  uint64_t line_base;
+};
+
+// Candidate filter shapes (how many of the first 8 pattern bytes the
+// in-register window compare covers; longer patterns are verified from memory).
+enum FilterKind : int {
+  kMask1 = 0,  // plen 1..3 : one masked dword compare
+  kOne = 1,    // plen 4    : one dword compare
+  kMask2 = 2,  // plen 5..7 : one dword + one masked dword
+  kTwo = 3,    // plen 8    : two dword compares (exact)
+  kLong = 4    // plen > 8  : two dword compares + byte verify of the rest
+};
+
+struct PatternDev {
+  uint32_t plen;
+  uint32_t kind;
+  uint32_t p0, m0, p1, m1;  // first 8 pattern bytes as little-endian dwords and their byte masks
+  const uint8_t* d_pat;     // device copy of the pattern
+  uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL
+  uint32_t has_newline;     // pattern contains '\n'
+};
+
+// Per-tile line summaries (XSG_COUNT_LINES): see xsg_linesum.h.
+
+struct ScanArgs {
+  const uint8_t* base;          // shard buffer
+  const ChunkDev* chunks;       // device chunk table
+  const uint32_t* tile_chunk;   // tile -> chunk (null when the shard has one chunk)
+  const uint64_t* chunk_tile0;  // first tile of every chunk (nchunks + 1 entries)
+  uint64_t ntiles;
+  PatternDev pat;
+  // outputs of the counting pass
+  uint32_t* tile_cnt;                  // matches starting in the tile (o < limit)
+  uint32_t* tile_nl;                   // '\n' in the tile              (WANT_NL)
+  uint32_t* tile_sum;                  // line summary                  (WANT_LINES)
+  unsigned long long* chunk_last_end;  // max (match offset + plen) per chunk, chunk-local
+  // inputs/outputs of the emit pass
+  const uint64_t* tile_off;  // exclusive prefix of tile_cnt
+  uint64_t* m_pos;           // chunk-local offset of every match, ascending
+  uint32_t* m_chunk;         // its chunk
+};
+
+struct FinishArgs {
+  const uint8_t* base;
+  const ChunkDev* chunks;
+  const uint64_t* chunk_tile0;
+  uint64_t nchunks;
+  uint64_t ntiles;
+  PatternDev pat;
+  const uint32_t* tile_cnt;
+  const uint32_t* tile_nl;
+  const uint32_t* tile_sum;
+  const unsigned long long* chunk_last_end;
+  uint64_t* counters;  // XSG_NUM_COUNTERS, zeroed before the launch
+  uint32_t want_nl;
+  uint32_t want_lines;
+  uint32_t want_matches;
+};
+
+// ---- launchers (xsg_kernels.hip) --------------------------------------------
+hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s);
+hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s);
+hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s);
+
+// exclusive scan: out[i] = sum_{k<i} in[k] for i in [0, n]; out has n+1 entries.
+// tmp must hold scan_tmp_elems(n) uint64 values.
+uint64_t scan_tmp_elems(uint64_t n);
+hipError_t launch_exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s);
+hipError_t launch_exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s);
+
+struct ListArgs {
+  const uint8_t* base;
+  const ChunkDev* chunks;
+  const uint64_t* chunk_tile0;
+  uint64_t nchunks;
+  PatternDev pat;
+  uint64_t M;                // raw matches (bulk, o < limit), ascending per chunk
+  const uint64_t* m_pos;     // chunk-local offsets
+  const uint32_t* m_chunk;
+  const uint64_t* tile_off;  // -> first raw index of each chunk = tile_off[chunk_tile0[c]]
+  uint64_t* m_ls;            // line start per raw match (line modes)
+  uint32_t* keep;            // 1 = survives the walk (greedy / first in line)
+  const uint64_t* keep_pre;  // exclusive prefix of keep (M + 1 entries)
+  uint64_t* chunk_shift0;    // per chunk: where the reference walk enters the tail zone
+  uint32_t* tail_cnt;        // per chunk
+  uint64_t* tail_pos;        // per chunk x tail_cap: chunk-local match offsets from the tail walk
+  uint32_t tail_cap;
+  const uint64_t* tail_pre;  // exclusive prefix of tail_cnt (nchunks + 1)
+  uint32_t line_mode;        // 0: matches, 1: lines (skip_to_nl)
+  // final list
+  uint64_t* f_pos;    // chunk-local: match offset (match mode) or line start (line modes)
+  uint64_t* f_match;  // chunk-local offset of the (first) match of that line
+  uint32_t* f_chunk;
+  uint64_t total;
+};
+
+hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s);
+hipError_t launch_line_starts(const ListArgs& a, hipStream_t s);
+hipError_t launch_line_keep(const ListArgs& a, hipStream_t s);
+hipError_t launch_keep_all(const ListArgs& a, hipStream_t s);
+hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s);
+hipError_t launch_tail_list(const ListArgs& a, hipStream_t s);
+hipError_t launch_assemble(const ListArgs& a, hipStream_t s);
+
+struct LineOutArgs {
+  const uint8_t* base;
+  const ChunkDev* chunks;
+  const uint64_t* chunk_tile0;
+  uint64_t nchunks;
+  PatternDev pat;
+  uint64_t total;
+  const uint64_t* f_pos;
+  const uint64_t* f_match;
+  const uint32_t* f_chunk;
+  uint64_t* out_u64;  // global offsets or line indices
+  // line indices
+  const uint64_t* tile_nl_off;  // exclusive prefix of tile_nl over all tiles of the shard
+  uint64_t shard_line_base;
+  // lines
+  uint64_t* line_len;  // length without '\n'; UINT64_MAX marks "no terminating newline" (dropped)
+  const uint64_t* line_out_off;
+  uint8_t* line_bytes;
+};
+hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s);
+hipError_t launch_line_indices(const LineOutArgs& a, hipStream_t s);
+hipError_t launch_line_lengths(const LineOutArgs& a, hipStream_t s);
+hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s);
+
+}  // namespace xsg

@@ -1,0 +1,800 @@
+// xsg_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the literal scan.
+//
+// What they replace in the reference (all byte/integer work, no MFMA):
+//   k_scan        simd::strstr body + the per-chunk walks that call it
+//                 (src/string_search/simd_search.cpp:162-204,
+//                  include/xsearch/string_search/search_wrappers.h:29-52,163-185)
+//   k_count_finish  the end-of-chunk part of those walks (simd_search.cpp:58-78,203)
+//   k_line_*      previous_new_line_offset_relative_to_match + findNextNewLine
+//                 (search_wrappers.h:111-123,187-207; simd_search.cpp:116-144,297-303)
+//
+// Design: the bulk scan is a pure HBM stream.  Every lane reads
+// 16-byte units with global_load_dwordx4 (a wave-instruction = 1 KiB
+// contiguous), fetches the first 8 bytes of its right neighbour's unit with one
+// DPP wave shift (no LDS traffic), builds the 20 unaligned dword windows of its
+// unit with v_alignbyte_b32 and compares them against the first 8 pattern bytes
+// held in SGPRs.  A wave-load whose 64 lanes see no candidate -- the normal
+// case at text match densities -- costs ~3 VALU ops per byte and leaves the
+// loop without touching LDS or memory again.  Everything else (exact
+// verification, popcounts, ordered compaction, line summaries) lives in a
+// wave-uniform slow path.
+#include "xsg_internal.h"
+#include "xsg_linesum.h"
+#include "xsg_tail.h"
+
+namespace xsg {
+
+// ---------------------------------------------------------------------------
+// cross-lane helpers (wave64)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// value of lane+1 (lane 63 receives `edge`)
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t x, uint32_t edge, uint32_t lane) {
+#if defined(XSG_USE_DPP_SHIFT)
+  // v_mov_b32_dpp wave_shl:1 -- lane i reads lane i+1 (gfx9 DPP wavefront shift)
+  uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false);
+#else
+  uint32_t y = (uint32_t)__shfl_down((int)x, 1);
+#endif
+  return lane == 63u ? edge : y;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += (uint32_t)__shfl_xor((int)v, s);
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    uint64_t o = (uint64_t)__shfl_xor((long long)v, s);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+// inclusive prefix sum over lanes
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    uint32_t o = (uint32_t)__shfl_up((int)v, s);
+    if (lane >= (uint32_t)s) v += o;
+  }
+  return v;
+}
+
+// ordered reduction over the 64 lanes; result valid in lane 0
+__device__ __forceinline__ uint32_t wave_sum_combine(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_down((int)v, s);
+    if ((lane & (uint32_t)(2 * s - 1)) == 0u) v = sum_combine(v, o);
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// per-unit byte tests
+// ---------------------------------------------------------------------------
+// exact 0x80-per-byte flags of bytes equal to '\n'
+__device__ __forceinline__ uint32_t nl_flags(uint32_t d) {
+  const uint32_t x = d ^ 0x0a0a0a0au;
+  const uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
+  return ~t;  // 0x80 in every byte that was '\n'
+}
+__device__ __forceinline__ uint32_t nl_count16(const uint32_t (&d)[6]) {
+  return (uint32_t)__popc(nl_flags(d[0])) + (uint32_t)__popc(nl_flags(d[1])) + (uint32_t)__popc(nl_flags(d[2])) +
+         (uint32_t)__popc(nl_flags(d[3]));
+}
+// bit b set <=> byte b of the unit is '\n'
+__device__ __forceinline__ uint32_t nl_mask16(const uint32_t (&d)[6]) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t f = nl_flags(d[q]) >> 7;  // bit 0, 8, 16, 24
+    const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
+    m |= nib << (4 * q);
+  }
+  return m;
+}
+__device__ __forceinline__ bool nl_any16(const uint32_t (&d)[6]) {
+  uint32_t acc = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t x = d[q] ^ 0x0a0a0a0au;
+    acc |= (x - 0x01010101u) & ~x;
+  }
+  return (acc & 0x80808080u) != 0;
+}
+
+template <int KIND>
+__device__ __forceinline__ void windows(const uint32_t (&d)[6], uint32_t (&w)[20]) {
+#pragma unroll
+  for (int b = 0; b < 20; ++b) {
+    const int q = b >> 2, r = b & 3;
+    w[b] = r ? __builtin_amdgcn_alignbyte(d[q + 1], d[q], (uint32_t)r) : d[q];
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ bool cand_at(const uint32_t (&w)[20], int b, const PatternDev& P) {
+  if (KIND == kMask1) return (w[b] & P.m0) == P.p0;
+  if (KIND == kOne) return w[b] == P.p0;
+  if (KIND == kMask2) return (w[b] == P.p0) & ((w[b + 4] & P.m1) == P.p1);
+  return (w[b] == P.p0) & (w[b + 4] == P.p1);
+}
+
+// true if any of the 16 positions of the unit passes the prefix filter
+template <int KIND>
+__device__ __forceinline__ bool cand_any(const uint32_t (&d)[6], const PatternDev& P) {
+  uint32_t w[20];
+  windows<KIND>(d, w);
+  bool any = false;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) any |= cand_at<KIND>(w, b, P);
+  return any;
+}
+
+template <int KIND>
+__device__ __forceinline__ uint32_t cand_mask16(const uint32_t (&d)[6], const PatternDev& P) {
+  uint32_t w[20];
+  windows<KIND>(d, w);
+  uint32_t m = 0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) m |= (uint32_t)cand_at<KIND>(w, b, P) << b;
+  return m;
+}
+
+// exact match-start bits of one unit: filter, position limit, long-pattern verify
+template <int KIND>
+__device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[6], const PatternDev& P, const uint8_t* cbase,
+                                                 uint64_t unit_off, uint64_t limit, const uint8_t* lds_pat) {
+  uint32_t m = cand_mask16<KIND>(d, P);
+  if (unit_off >= limit) return 0;
+  if (unit_off + kUnit > limit) m &= (1u << (uint32_t)(limit - unit_off)) - 1u;
+  if (KIND == kLong) {
+    uint32_t c = m;
+    while (c) {
+      const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
+      c &= c - 1u;
+      const uint8_t* s = cbase + unit_off + b;
+      bool ok = true;
+      for (uint32_t k = 8; k < P.plen; ++k) {
+        if (s[k] != lds_pat[k]) {
+          ok = false;
+          break;
+        }
+      }
+      if (!ok) m &= ~(1u << b);
+    }
+  }
+  return m;
+}
+
+// ---------------------------------------------------------------------------
+// k_scan: the bulk pass.  EMIT=false: per-tile counts / newline counts / line
+// summaries.  EMIT=true: the same decisions, writing every match offset at its
+// rank (tile_off[tile] + rank inside the tile).
+// ---------------------------------------------------------------------------
+template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT>
+__global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
+  __shared__ uint32_t s_cnt[kWaves];
+  __shared__ uint32_t s_nl[kWaves];
+  __shared__ uint32_t s_sum[kWaves];
+  __shared__ unsigned long long s_last[kWaves];
+  __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND == kLong ? XSG_MAX_PATTERN : 16];
+
+  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+  if (tile >= A.ntiles) return;
+  if (EMIT && A.tile_cnt[tile] == 0) return;
+
+  const PatternDev P = A.pat;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+
+  if (KIND == kLong) {
+    for (uint32_t k = tid; k < P.plen; k += kBlock) s_pat[k] = P.d_pat[k];
+    __syncthreads();
+  }
+
+  const uint32_t c = A.tile_chunk ? A.tile_chunk[tile] : 0u;
+  const ChunkDev ch = A.chunks[c];
+  const uint8_t* cbase = A.base + ch.offset;
+  const uint64_t L = ch.length;
+  const uint64_t Lr = (L + 15u) & ~(uint64_t)15u;
+  // positions o < limit are decided here; [limit, L) belongs to the tail walk
+  const uint64_t limit =
+      P.exact_tail ? (L >= P.plen ? L - P.plen + 1u : 0u) : tail_zone_begin(L, P.plen);
+  const uint64_t toff = (tile - A.chunk_tile0[c]) * (uint64_t)kTile;
+  const uint64_t wbase = toff + (uint64_t)wave * kWaveSpan;
+
+  // ---- issue all loads of the wave span up front (kLoads KiB in flight per wave).
+  // No branch around a load: units past the end of the chunk re-read its last
+  // unit (an L2 hit) and are cleared below, so the loads stay back to back.
+  const uint64_t last_unit = Lr - kUnit;  // L >= 1 here: a chunk of length 0 has no tiles
+  uint4 v[kLoads];
+#pragma unroll
+  for (int j = 0; j < kLoads; ++j) {
+    uint64_t off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
+    off = off < last_unit ? off : last_unit;
+    v[j] = *reinterpret_cast<const uint4*>(cbase + off);
+  }
+  // the 8 bytes that follow the span (wave-uniform address)
+  uint64_t eoff = wbase + kWaveSpan;
+  eoff = eoff < last_unit ? eoff : last_unit;
+  const uint2 edge = *reinterpret_cast<const uint2*>(cbase + eoff);
+  // keep every load ahead of the first use of any of them (otherwise the
+  // scheduler sinks a copy of load 0 between the loads and stalls the issue)
+  __builtin_amdgcn_sched_barrier(0);
+
+  uint32_t cnt = 0, nlc = 0;
+  uint64_t last_end = 0;
+  uint32_t wsum = 0;  // line summary of the wave span so far (lane 0)
+  uint32_t masks[kLoads];
+
+#pragma unroll
+  for (int j = 0; j < kLoads; ++j) {
+    const uint64_t unit_off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
+    uint32_t d[6] = {v[j].x, v[j].y, v[j].z, v[j].w, 0u, 0u};
+    // bytes at or beyond L are not part of the chunk: clear them once
+    if (unit_off + kUnit > L) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint64_t o = unit_off + 4u * q;
+        d[q] = o >= L ? 0u : (o + 4u > L ? d[q] & ((1u << (8u * (uint32_t)(L - o))) - 1u) : d[q]);
+      }
+    }
+    {
+      const uint32_t e0 = j + 1 < kLoads ? __builtin_amdgcn_readfirstlane(v[j + 1 < kLoads ? j + 1 : j].x) : edge.x;
+      const uint32_t e1 = j + 1 < kLoads ? __builtin_amdgcn_readfirstlane(v[j + 1 < kLoads ? j + 1 : j].y) : edge.y;
+      d[4] = from_next_lane(v[j].x, e0, lane);
+      d[5] = from_next_lane(v[j].y, e1, lane);
+    }
+
+    if (WANT_NL) nlc += nl_count16(d);
+
+    const bool any_c = cand_any<KIND>(d, P);
+    uint32_t m = 0;
+    if (__any(any_c)) m = match_mask16<KIND>(d, P, cbase, unit_off, limit, s_pat);
+    if (EMIT) {
+      masks[j] = m;
+      cnt += (uint32_t)__popc(m);
+    } else {
+      if (m) {
+        cnt += (uint32_t)__popc(m);
+        last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen;
+      }
+      if (WANT_LINES) {
+        uint32_t us;
+        if (__any(m != 0)) {
+          us = sum_of_unit(m, nl_mask16(d));
+        } else {
+          us = nl_any16(d) ? kSumNl : 0u;
+        }
+        us = wave_sum_combine(us, lane);
+        wsum = j == 0 ? us : sum_combine(wsum, us);
+      }
+    }
+  }
+
+  if (!EMIT) {
+    // ---- block reduction -> one store per output per tile
+    const uint32_t wc = wave_sum_u32(cnt);
+    const uint32_t wn = WANT_NL ? wave_sum_u32(nlc) : 0u;
+    const uint64_t wl = wc ? wave_max_u64(last_end) : 0u;
+    if (lane == 0) {
+      s_cnt[wave] = wc;
+      s_nl[wave] = wn;
+      s_last[wave] = wl;
+      s_sum[wave] = wsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t tc = 0, tn = 0, ts = s_sum[0];
+      unsigned long long tl = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        tc += s_cnt[w];
+        tn += s_nl[w];
+        tl = s_last[w] > tl ? s_last[w] : tl;
+        if (w) ts = sum_combine(ts, s_sum[w]);
+      }
+      A.tile_cnt[tile] = tc;
+      if (WANT_NL) A.tile_nl[tile] = tn;
+      if (WANT_LINES) A.tile_sum[tile] = ts;
+      if (tc) atomicMax(A.chunk_last_end + c, tl);
+    }
+  } else {
+    // ---- ordered emission: wave spans are consecutive, loads within a span
+    // are consecutive, lanes within a load are consecutive, bits ascend.
+    const uint32_t wc = wave_sum_u32(cnt);
+    if (lane == 0) s_cnt[wave] = wc;
+    __syncthreads();
+    uint64_t rank = A.tile_off[tile];
+    for (uint32_t w = 0; w < wave; ++w) rank += s_cnt[w];
+#pragma unroll
+    for (int j = 0; j < kLoads; ++j) {
+      const uint32_t m = masks[j];
+      const uint32_t pc = (uint32_t)__popc(m);
+      const uint32_t incl = wave_incl_scan_u32(pc, lane);
+      const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+      if (m) {
+        uint64_t r = rank + (incl - pc);
+        const uint64_t unit_off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
+        uint32_t mm = m;
+        while (mm) {
+          const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
+          mm &= mm - 1u;
+          A.m_pos[r] = unit_off + b;
+          A.m_chunk[r] = c;
+          ++r;
+        }
+      }
+      rank += total;
+    }
+  }
+}
+
+template <int KIND>
+static hipError_t launch_scan_kind(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, dim3 grid,
+                                   hipStream_t s) {
+  if (emit) {
+    hipLaunchKernelGGL((k_scan<KIND, false, false, true>), grid, dim3(kBlock), 0, s, a);
+  } else if (want_lines) {
+    if (want_nl)
+      hipLaunchKernelGGL((k_scan<KIND, true, true, false>), grid, dim3(kBlock), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_scan<KIND, false, true, false>), grid, dim3(kBlock), 0, s, a);
+  } else {
+    if (want_nl)
+      hipLaunchKernelGGL((k_scan<KIND, true, false, false>), grid, dim3(kBlock), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_scan<KIND, false, false, false>), grid, dim3(kBlock), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+static dim3 tile_grid(uint64_t ntiles) {
+  // grid.x is limited to 2^31-1 blocks; fold very large shards into y
+  const uint64_t maxx = 1u << 30;
+  if (ntiles <= maxx) return dim3((unsigned)ntiles, 1, 1);
+  return dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx), 1);
+}
+
+static hipError_t launch_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, hipStream_t s) {
+  if (a.ntiles == 0) return hipSuccess;
+  const dim3 grid = tile_grid(a.ntiles);
+  switch (a.pat.kind) {
+    case kMask1: return launch_scan_kind<kMask1>(a, want_nl, want_lines, emit, grid, s);
+    case kOne: return launch_scan_kind<kOne>(a, want_nl, want_lines, emit, grid, s);
+    case kMask2: return launch_scan_kind<kMask2>(a, want_nl, want_lines, emit, grid, s);
+    case kTwo: return launch_scan_kind<kTwo>(a, want_nl, want_lines, emit, grid, s);
+    default: return launch_scan_kind<kLong>(a, want_nl, want_lines, emit, grid, s);
+  }
+}
+
+hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s) {
+  return launch_scan(a, want_nl, want_lines, false, s);
+}
+hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s) { return launch_scan(a, false, false, true, s); }
+
+// ---------------------------------------------------------------------------
+// k_count_finish: sums the per-tile outputs and replays the reference walk
+// over every chunk's tail zone.  counters[] must be zero on entry.
+// ---------------------------------------------------------------------------
+constexpr int kFinishBlocks = 256;
+
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* sh) {
+  // sh: kWaves entries
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += (uint64_t)__shfl_xor((long long)v, s);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  uint64_t t = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < kWaves; ++w) t += sh[w];
+  __syncthreads();
+  return t;  // valid in thread 0
+}
+
+// where the reference walk stands when it reaches the tail zone of a chunk
+__device__ __forceinline__ uint64_t walk_entry(const uint8_t* d, uint64_t L, uint64_t last_end, bool skip_to_nl) {
+  if (last_end == 0) return 0;
+  if (!skip_to_nl) return last_end;
+  const int64_t nl = next_newline(d, last_end, L);
+  return nl < 0 ? UINT64_MAX : (uint64_t)nl + 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
+  __shared__ uint64_t sh[kWaves];
+  const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t gsz = (uint64_t)gridDim.x * kBlock;
+
+  uint64_t cm = 0, cn = 0;
+  for (uint64_t t = gid; t < A.ntiles; t += gsz) {
+    if (A.want_matches) cm += A.tile_cnt[t];
+    if (A.want_nl) cn += A.tile_nl[t];
+  }
+  uint64_t lines = 0, bytes = 0;
+  for (uint64_t c = gid; c < A.nchunks; c += gsz) {
+    const ChunkDev ch = A.chunks[c];
+    const uint8_t* d = A.base + ch.offset;
+    bytes += ch.length;
+    if (A.want_lines) {
+      // combine the tile summaries of the chunk in order
+      const uint64_t t0 = A.chunk_tile0[c], t1 = A.chunk_tile0[c + 1];
+      if (t1 > t0) {
+        uint32_t s = A.tile_sum[t0];
+        for (uint64_t t = t0 + 1; t < t1; ++t) s = sum_combine(s, A.tile_sum[t]);
+        lines += sum_total_lines(s);
+      }
+    }
+    if (!A.pat.exact_tail && A.pat.plen > 1) {
+      const uint64_t last_end = A.chunk_last_end[c];
+      if (A.want_matches) {
+        cm += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, false), false,
+                        nullptr, 0);
+      }
+      if (A.want_lines) {
+        lines += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, true), true,
+                           nullptr, 0);
+      }
+    }
+  }
+  uint64_t t;
+  t = block_sum_u64(cm, sh);
+  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_MATCHES], (unsigned long long)t);
+  t = block_sum_u64(lines, sh);
+  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_LINES], (unsigned long long)t);
+  t = block_sum_u64(cn, sh);
+  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_NEWLINES], (unsigned long long)t);
+  t = block_sum_u64(bytes, sh);
+  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_BYTES], (unsigned long long)t);
+}
+
+hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s) {
+  uint64_t work = a.ntiles > a.nchunks ? a.ntiles : a.nchunks;
+  uint64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks < 1) blocks = 1;
+  if (blocks > kFinishBlocks) blocks = kFinishBlocks;
+  hipLaunchKernelGGL(k_count_finish, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan (uint32 or uint64 in -> uint64 out), three small kernels
+// ---------------------------------------------------------------------------
+constexpr int kScanItems = 8;
+constexpr uint64_t kScanBlockElems = (uint64_t)kBlock * kScanItems;
+
+uint64_t scan_tmp_elems(uint64_t n) { return (n + kScanBlockElems - 1) / kScanBlockElems + 1; }
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, uint32_t lane) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    uint64_t o = (uint64_t)__shfl_up((long long)v, s);
+    if (lane >= (uint32_t)s) v += o;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, *total = block sum
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* sh, uint64_t* total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint64_t incl = wave_incl_scan_u64(v, lane);
+  if (lane == 63) sh[wave] = incl;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    if ((uint32_t)w < wave) base += sh[w];
+    tot += sh[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+// UINT64_MAX in a uint64 input is the "dropped line" marker of k_line_lengths: it scans as 0
+__device__ __forceinline__ uint64_t scan_val(uint32_t v) { return v; }
+__device__ __forceinline__ uint64_t scan_val(uint64_t v) { return v == UINT64_MAX ? 0 : v; }
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scan_block_sums(const T* in, uint64_t n, uint64_t* block_sums) {
+  __shared__ uint64_t sh[kWaves];
+  const uint64_t b0 = (uint64_t)blockIdx.x * kScanBlockElems + (uint64_t)threadIdx.x * kScanItems;
+  uint64_t v = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (b0 + k < n) v += scan_val(in[b0 + k]);
+  uint64_t tot;
+  block_excl_scan_u64(v, sh, &tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block_sums in place (nb entries), total appended at [nb]
+__global__ __launch_bounds__(kBlock) void k_scan_top(uint64_t* block_sums, uint64_t nb) {
+  __shared__ uint64_t sh[kWaves];
+  uint64_t carry = 0;
+  for (uint64_t i0 = 0; i0 < nb; i0 += kBlock) {
+    const uint64_t i = i0 + threadIdx.x;
+    const uint64_t v = i < nb ? block_sums[i] : 0;
+    uint64_t tot;
+    const uint64_t ex = block_excl_scan_u64(v, sh, &tot);
+    if (i < nb) block_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) block_sums[nb] = carry;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scan_write(const T* in, uint64_t n, const uint64_t* block_sums,
+                                                       uint64_t* out) {
+  __shared__ uint64_t sh[kWaves];
+  const uint64_t b0 = (uint64_t)blockIdx.x * kScanBlockElems + (uint64_t)threadIdx.x * kScanItems;
+  uint64_t x[kScanItems];
+  uint64_t v = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    x[k] = b0 + k < n ? scan_val(in[b0 + k]) : 0;
+    v += x[k];
+  }
+  uint64_t tot;
+  uint64_t run = block_sums[blockIdx.x] + block_excl_scan_u64(v, sh, &tot);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (b0 + k < n) out[b0 + k] = run;
+    run += x[k];
+  }
+  // the grand total goes to out[n]
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = block_sums[gridDim.x];
+}
+
+__global__ void k_set_u64(uint64_t* p, uint64_t v) { *p = v; }
+
+template <typename T>
+static hipError_t exclusive_scan_impl(const T* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s) {
+  if (n == 0) {
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, out, (uint64_t)0);
+    return hipGetLastError();
+  }
+  const uint64_t nb = (n + kScanBlockElems - 1) / kScanBlockElems;
+  hipLaunchKernelGGL((k_scan_block_sums<T>), dim3((unsigned)nb), dim3(kBlock), 0, s, in, n, tmp);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, tmp, nb);
+  hipLaunchKernelGGL((k_scan_write<T>), dim3((unsigned)nb), dim3(kBlock), 0, s, in, n, tmp, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s) {
+  return exclusive_scan_impl<uint32_t>(in, out, n, tmp, s);
+}
+hipError_t launch_exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s) {
+  return exclusive_scan_impl<uint64_t>(in, out, n, tmp, s);
+}
+
+// ---------------------------------------------------------------------------
+// list post-processing: one thread per raw match / per chunk.  Matches are
+// sparse at text densities (~5e-7 per byte), so these are latency-, not
+// bandwidth-bound and deliberately simple.
+// ---------------------------------------------------------------------------
+static inline dim3 grid_for(uint64_t n) {
+  uint64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+__global__ void k_keep_all(const ListArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < A.M) A.keep[i] = 1u;
+}
+
+// Greedy non-overlap (shift = match + plen, simd_search.cpp:333 /
+// search_wrappers.h:42): only patterns with a border can overlap themselves.
+// An occurrence >= plen after its predecessor is always kept and starts a
+// chain; the thread owning a chain head walks its chain.
+__global__ void k_greedy_keep(const ListArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.M) return;
+  const uint32_t plen = A.pat.plen;
+  const uint32_t c = A.m_chunk[i];
+  const bool head = i == 0 || A.m_chunk[i - 1] != c || A.m_pos[i] - A.m_pos[i - 1] >= plen;
+  if (!head) return;
+  A.keep[i] = 1u;
+  uint64_t last = A.m_pos[i];
+  for (uint64_t j = i + 1; j < A.M; ++j) {
+    if (A.m_chunk[j] != c || A.m_pos[j] - A.m_pos[j - 1] >= plen) break;
+    const bool k = A.m_pos[j] >= last + plen;
+    A.keep[j] = k ? 1u : 0u;
+    if (k) last = A.m_pos[j];
+  }
+}
+
+// line start of every raw match: the byte after the previous '\n', or 0
+// (search_wrappers.h:111-123)
+__global__ void k_line_starts(const ListArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.M) return;
+  const uint8_t* d = A.base + A.chunks[A.m_chunk[i]].offset;
+  uint64_t p = A.m_pos[i];
+  while (p > 0 && d[p - 1] != '\n') --p;
+  A.m_ls[i] = p;
+}
+
+// a raw match survives the skip_to_nl walk iff it is the first of its line
+__global__ void k_line_keep(const ListArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.M) return;
+  const bool first = i == 0 || A.m_chunk[i - 1] != A.m_chunk[i] || A.m_ls[i - 1] != A.m_ls[i];
+  A.keep[i] = first ? 1u : 0u;
+}
+
+// per chunk: where the walk enters the tail zone, from the last kept bulk match
+__global__ void k_chunk_shift0(const ListArgs A) {
+  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= A.nchunks) return;
+  const uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
+  uint64_t last_end = 0;
+  // last kept raw match of the chunk (kept ones are never far from the end of a chain)
+  for (uint64_t i = r1; i > r0; --i) {
+    if (A.keep[i - 1]) {
+      last_end = A.m_pos[i - 1] + A.pat.plen;
+      break;
+    }
+  }
+  const ChunkDev ch = A.chunks[c];
+  A.chunk_shift0[c] = walk_entry(A.base + ch.offset, ch.length, last_end, A.line_mode != 0);
+}
+
+__global__ void k_tail_list(const ListArgs A) {
+  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= A.nchunks) return;
+  uint32_t n = 0;
+  if (!A.pat.exact_tail && A.pat.plen > 1) {
+    const ChunkDev ch = A.chunks[c];
+    n = tail_walk(A.base + ch.offset, ch.length, A.pat.d_pat, A.pat.plen, A.chunk_shift0[c], A.line_mode != 0,
+                  A.tail_pos + c * A.tail_cap, A.tail_cap);
+  }
+  A.tail_cnt[c] = n;
+}
+
+// final list = per chunk: kept bulk matches, then the tail walk's matches
+__global__ void k_assemble(const ListArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < A.M && A.keep[i]) {
+    const uint32_t c = A.m_chunk[i];
+    const uint64_t dst = A.keep_pre[i] + A.tail_pre[c];
+    A.f_pos[dst] = A.line_mode ? A.m_ls[i] : A.m_pos[i];
+    A.f_match[dst] = A.m_pos[i];
+    A.f_chunk[dst] = c;
+  }
+  if (i < A.nchunks) {
+    const uint64_t c = i;
+    const uint32_t n = A.tail_cnt[c];
+    if (n) {
+      const uint64_t r1 = A.tile_off[A.chunk_tile0[c + 1]];
+      const uint64_t dst0 = A.keep_pre[r1] + A.tail_pre[c];
+      const uint8_t* d = A.base + A.chunks[c].offset;
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint64_t m = A.tail_pos[c * A.tail_cap + k];
+        uint64_t p = m;
+        if (A.line_mode)
+          while (p > 0 && d[p - 1] != '\n') --p;
+        A.f_pos[dst0 + k] = p;
+        A.f_match[dst0 + k] = m;
+        A.f_chunk[dst0 + k] = (uint32_t)c;
+      }
+    }
+  }
+}
+
+hipError_t launch_keep_all(const ListArgs& a, hipStream_t s) {
+  if (!a.M) return hipSuccess;
+  hipLaunchKernelGGL(k_keep_all, grid_for(a.M), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s) {
+  if (!a.M) return hipSuccess;
+  hipLaunchKernelGGL(k_greedy_keep, grid_for(a.M), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_line_starts(const ListArgs& a, hipStream_t s) {
+  if (!a.M) return hipSuccess;
+  hipLaunchKernelGGL(k_line_starts, grid_for(a.M), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_line_keep(const ListArgs& a, hipStream_t s) {
+  if (!a.M) return hipSuccess;
+  hipLaunchKernelGGL(k_line_keep, grid_for(a.M), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s) {
+  if (!a.nchunks) return hipSuccess;
+  hipLaunchKernelGGL(k_chunk_shift0, grid_for(a.nchunks), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_tail_list(const ListArgs& a, hipStream_t s) {
+  if (!a.nchunks) return hipSuccess;
+  hipLaunchKernelGGL(k_tail_list, grid_for(a.nchunks), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_assemble(const ListArgs& a, hipStream_t s) {
+  const uint64_t n = a.M > a.nchunks ? a.M : a.nchunks;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_assemble, grid_for(n), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// outputs of the list modes
+// ---------------------------------------------------------------------------
+__global__ void k_globalize(const LineOutArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < A.total) A.out_u64[i] = A.chunks[A.f_chunk[i]].global_offset + A.f_pos[i];
+}
+
+// xs::line_indices: number of '\n' before the line start
+__global__ void k_line_indices(const LineOutArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.total) return;
+  const uint32_t c = A.f_chunk[i];
+  const ChunkDev ch = A.chunks[c];
+  const uint8_t* d = A.base + ch.offset;
+  const uint64_t b = A.f_pos[i];
+  const uint64_t t0 = A.chunk_tile0[c];
+  const uint64_t t = t0 + b / kTile;
+  uint64_t n = A.tile_nl_off[t];
+  for (uint64_t p = (b / kTile) * kTile; p < b; ++p) n += d[p] == '\n';
+  if (ch.line_base == XSG_LINE_BASE_AUTO)
+    A.out_u64[i] = A.shard_line_base + n;
+  else
+    A.out_u64[i] = ch.line_base + (n - A.tile_nl_off[t0]);
+}
+
+// xs::lines: [line start, next '\n' after the match); a line without '\n' is
+// dropped (search_wrappers.h:199-202)
+__global__ void k_line_lengths(const LineOutArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.total) return;
+  const ChunkDev ch = A.chunks[A.f_chunk[i]];
+  const uint8_t* d = A.base + ch.offset;
+  const int64_t e = next_newline(d, A.f_match[i] + A.pat.plen, ch.length);
+  A.line_len[i] = e < 0 ? UINT64_MAX : (uint64_t)e - A.f_pos[i];
+  A.out_u64[i] = ch.global_offset + A.f_pos[i];
+}
+
+// one wave per line copies its bytes to the packed output
+__global__ __launch_bounds__(kBlock) void k_line_gather(const LineOutArgs A) {
+  const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  if (i >= A.total) return;
+  const uint64_t len = A.line_len[i];
+  if (len == UINT64_MAX) return;
+  const uint8_t* src = A.base + A.chunks[A.f_chunk[i]].offset + A.f_pos[i];
+  uint8_t* dst = A.line_bytes + A.line_out_off[i];
+  for (uint64_t k = lane; k < len; k += 64) dst[k] = src[k];
+}
+
+hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s) {
+  if (!a.total) return hipSuccess;
+  hipLaunchKernelGGL(k_globalize, grid_for(a.total), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_line_indices(const LineOutArgs& a, hipStream_t s) {
+  if (!a.total) return hipSuccess;
+  hipLaunchKernelGGL(k_line_indices, grid_for(a.total), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_line_lengths(const LineOutArgs& a, hipStream_t s) {
+  if (!a.total) return hipSuccess;
+  hipLaunchKernelGGL(k_line_lengths, grid_for(a.total), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s) {
+  if (!a.total) return hipSuccess;
+  hipLaunchKernelGGL(k_line_gather, grid_for(a.total * 64), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace xsg
