@@ -174,7 +174,11 @@ def main():
     ctx.set_pattern(pattern)
     shard = xsg.Shard(ctx, shard_t.data_ptr(), cap, chunks)
     counters = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream()
+    # a dedicated stream: a NULL handle would mean "the ctx's own stream" to xsg_count_async
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     setup_s = time.perf_counter() - t_setup
 
     if dist is not None:

@@ -1,0 +1,288 @@
+// xsearch/xsearch.h -- the one-call C++ API of lfreist/x-search, served by the
+// MI355X scan engine (libxsg.so).  Header-only on top of the C ABI in xsg.h.
+//
+// Mirrors the surface the reference's users and tests call (the reference
+// snapshot holds only call sites, no definition -- SURVEY 0 / 8b):
+//
+//   auto res = xs::extern_search<xs::count>(pattern, file, meta, threads, readers);   README.md:72
+//   auto s   = xs::extern_search<xs::lines>(pattern, file, ignore_case, threads);     README.md:37, example/grep.cpp:69-76
+//   res->join();  res->getResult()->size();                                           test/src/xsearchTest.cpp:344-346
+//   auto v = res->getResult()->copyResultSafe();                                      test/src/xsearchTest.cpp:450,657
+//   for (auto r : *res->getResult()) { ... }     // live, blocks per element          test/src/xsearchTest.cpp:735-739,888-890
+//
+// Tags: xs::count (== xs::count_matches), xs::count_lines, xs::match_byte_offsets,
+// xs::line_byte_offsets, xs::line_indices, xs::lines (README.md:77-81).
+//
+// Semantics (include/xsearch/string_search/search_wrappers.h, bit-exact):
+//   count tags   getResult()->size() is the count; live iteration yields the
+//                running total after every chunk (last value == total)
+//   vector tags  flat elements: global byte offsets / 0-based line indices /
+//                lines without the trailing '\n'; published in file order
+//   the searcher's threads are joined on destruction (README.md:91; Searcher.h:41)
+//
+// Errors (the reference defines none; a bad path spins there, readers.h:40-47):
+// extern_search throws std::runtime_error when the file or metafile cannot be
+// opened/parsed or no MI355X is usable; a failure inside a worker ends the
+// search and is thrown by join() / by the iterator that runs into it.
+//
+// Not served here: regular expressions (the reference routes them to RE2,
+// utils/utils.h:17-25) -- every pattern is a literal; ignore_case=true throws.
+//
+// Environment: XS_DEVICE (HIP device index, default 0), XS_CHUNK_BYTES (target
+// chunk size without a metafile, default 16 MiB).
+#pragma once
+
+#include <xsg.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <iterator>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace xs {
+
+// ---- tags -------------------------------------------------------------------
+struct count {};
+using count_matches = count;
+struct count_lines {};
+struct match_byte_offsets {};
+struct line_byte_offsets {};
+struct line_indices {};
+struct lines {};
+
+namespace detail {
+
+template <class Tag>
+struct traits;
+template <>
+struct traits<count> {
+  using value_type = uint64_t;
+  static constexpr uint32_t mode = XSG_COUNT_MATCHES;
+  static constexpr bool is_count = true;
+};
+template <>
+struct traits<count_lines> {
+  using value_type = uint64_t;
+  static constexpr uint32_t mode = XSG_COUNT_LINES;
+  static constexpr bool is_count = true;
+};
+template <>
+struct traits<match_byte_offsets> {
+  using value_type = uint64_t;
+  static constexpr uint32_t mode = XSG_MATCH_BYTE_OFFSETS;
+  static constexpr bool is_count = false;
+};
+template <>
+struct traits<line_byte_offsets> {
+  using value_type = uint64_t;
+  static constexpr uint32_t mode = XSG_LINE_BYTE_OFFSETS;
+  static constexpr bool is_count = false;
+};
+template <>
+struct traits<line_indices> {
+  using value_type = uint64_t;
+  static constexpr uint32_t mode = XSG_LINE_INDICES;
+  static constexpr bool is_count = false;
+};
+template <>
+struct traits<lines> {
+  using value_type = std::string;
+  static constexpr uint32_t mode = XSG_LINES;
+  static constexpr bool is_count = false;
+};
+
+[[noreturn]] inline void throw_last(const char* what, int code) {
+  throw std::runtime_error(std::string(what) + ": " + xsg_strerror(code) + " (" + xsg_last_error() + ")");
+}
+
+inline uint64_t env_u64(const char* name, uint64_t dflt) {
+  const char* v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  return std::strtoull(v, nullptr, 10);
+}
+
+template <class T>
+struct fetch;
+template <>
+struct fetch<uint64_t> {
+  static uint64_t get(xsg_job* j, uint64_t i) {
+    uint64_t v = 0;
+    const int r = xsg_job_get_u64(j, i, 1, &v);
+    if (r != XSG_OK) throw_last("xs::Result", r);
+    return v;
+  }
+};
+template <>
+struct fetch<std::string> {
+  static std::string get(xsg_job* j, uint64_t i) {
+    const char* p = nullptr;
+    uint64_t n = 0;
+    const int r = xsg_job_get_line(j, i, &p, &n);
+    if (r != XSG_OK) throw_last("xs::Result", r);
+    return std::string(p, n);
+  }
+};
+
+}  // namespace detail
+
+// ---- result container (semantics of include/xsearch/ResultTypes.h:31-130) -----
+template <class Tag>
+class Result {
+ public:
+  using value_type = typename detail::traits<Tag>::value_type;
+
+  // Blocking input iterator: `it != end()` waits until the element exists or
+  // the search is closed (ResultTypes.h:48-60).
+  class iterator {
+   public:
+    using iterator_category = std::input_iterator_tag;
+    using value_type = typename Result::value_type;
+    using difference_type = std::ptrdiff_t;
+    using pointer = const value_type*;
+    using reference = value_type;
+
+    iterator(xsg_job* job, uint64_t index, bool is_end) : _job(job), _index(index), _end(is_end) {}
+    value_type operator*() const { return detail::fetch<value_type>::get(_job, _index); }
+    iterator& operator++() {
+      ++_index;
+      return *this;
+    }
+    bool operator!=(const iterator& other) const { return !(*this == other); }
+    bool operator==(const iterator& other) const {
+      if (_end && other._end) return true;
+      if (!_end && !other._end) return _index == other._index;
+      const iterator& it = _end ? other : *this;
+      return !it.exists();
+    }
+
+   private:
+    bool exists() const {
+      uint64_t avail = 0;
+      int fin = 0;
+      const int r = xsg_job_wait(_job, _index, &avail, &fin);
+      if (r != XSG_OK) detail::throw_last("xs::Result", r);
+      return avail > _index;
+    }
+    xsg_job* _job;
+    uint64_t _index;
+    bool _end;
+  };
+
+  explicit Result(xsg_job* job) : _job(job) {}
+  Result(const Result&) = delete;
+  Result& operator=(const Result&) = delete;
+
+  iterator begin() { return iterator(_job, 0, false); }
+  iterator end() { return iterator(_job, 0, true); }
+
+  // count tags: the count (so far; final after join()).  Vector tags: number of
+  // elements available so far.  (test/src/xsearchTest.cpp:346)
+  size_t size() const {
+    uint64_t t = 0;
+    const int r = xsg_job_total(_job, &t);
+    if (r != XSG_OK) detail::throw_last("xs::Result::size", r);
+    return static_cast<size_t>(t);
+  }
+  bool empty() const { return size() == 0; }
+
+  // Thread-safe copy of everything available now (test/src/xsearchTest.cpp:450).
+  // Count tags: the running totals published so far (one per chunk).
+  std::vector<value_type> copyResultSafe() const {
+    uint64_t n = 0;
+    int fin = 0;
+    const int r = xsg_job_poll(_job, &n, &fin);
+    if (r != XSG_OK) detail::throw_last("xs::Result::copyResultSafe", r);
+    std::vector<value_type> out;
+    out.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) out.push_back(detail::fetch<value_type>::get(_job, i));
+    return out;
+  }
+
+ private:
+  xsg_job* _job;
+};
+
+// ---- the handle xs::extern_search returns --------------------------------------
+template <class Tag>
+class ExternSearcher {
+ public:
+  using ResultT = Result<Tag>;
+
+  ExternSearcher(const std::string& pattern, const std::string& file_path, const std::string& meta_file_path,
+                 bool ignore_case, int num_threads, int num_max_readers) {
+    if (ignore_case)
+      throw std::invalid_argument("xs::extern_search: ignore_case is not supported by the MI355X engine yet");
+    xsg_job_opts o;
+    xsg_job_opts_init(&o);
+    o.mode = detail::traits<Tag>::mode;
+    o.device = static_cast<int32_t>(detail::env_u64("XS_DEVICE", 0));
+    o.num_threads = num_threads < 1 ? 1 : num_threads;
+    o.num_max_readers = num_max_readers < 1 ? 1 : num_max_readers;
+    o.chunk_bytes = detail::env_u64("XS_CHUNK_BYTES", 16u << 20);
+    const int r = xsg_job_start(pattern.data(), pattern.size(), file_path.c_str(),
+                                meta_file_path.empty() ? nullptr : meta_file_path.c_str(), &o, &_job);
+    if (r != XSG_OK) detail::throw_last("xs::extern_search", r);
+    _result.reset(new ResultT(_job));
+  }
+  ~ExternSearcher() {
+    if (_job) xsg_job_destroy(_job);  // joins the workers (README.md:91)
+  }
+  ExternSearcher(const ExternSearcher&) = delete;
+  ExternSearcher& operator=(const ExternSearcher&) = delete;
+  ExternSearcher(ExternSearcher&&) = delete;
+  ExternSearcher& operator=(ExternSearcher&&) = delete;
+
+  // Blocks until all workers are done (README.md:84); throws the first worker error.
+  void join() {
+    const int r = xsg_job_join(_job);
+    if (r != XSG_OK) detail::throw_last("xs::ExternSearcher::join", r);
+  }
+  ResultT* getResult() { return _result.get(); }
+  bool running() const {
+    uint64_t n = 0;
+    int fin = 0;
+    return xsg_job_poll(_job, &n, &fin) == XSG_OK && !fin;
+  }
+  xsg_job_stats stats() const {
+    xsg_job_stats st{};
+    xsg_job_stats_get(_job, &st);
+    return st;
+  }
+
+ private:
+  xsg_job* _job = nullptr;
+  std::unique_ptr<ResultT> _result;
+};
+
+// ---- one-call API (overloads are told apart by arity) -----------------
+template <class Tag>
+std::shared_ptr<ExternSearcher<Tag>> extern_search(const std::string& pattern, const std::string& file_path,
+                                                   bool ignore_case = false, int num_threads = 1) {
+  return std::make_shared<ExternSearcher<Tag>>(pattern, file_path, std::string(), ignore_case, num_threads, 1);
+}
+// a C string in third place is a metafile path, never a bool
+template <class Tag>
+std::shared_ptr<ExternSearcher<Tag>> extern_search(const std::string& pattern, const std::string& file_path,
+                                                   const char* meta_file_path) {
+  return std::make_shared<ExternSearcher<Tag>>(pattern, file_path, std::string(meta_file_path ? meta_file_path : ""),
+                                               false, 1, 1);
+}
+template <class Tag>
+std::shared_ptr<ExternSearcher<Tag>> extern_search(const std::string& pattern, const std::string& file_path,
+                                                   const std::string& meta_file_path, bool ignore_case,
+                                                   int num_threads, int num_max_readers) {
+  return std::make_shared<ExternSearcher<Tag>>(pattern, file_path, meta_file_path, ignore_case, num_threads,
+                                               num_max_readers);
+}
+template <class Tag>
+std::shared_ptr<ExternSearcher<Tag>> extern_search(const std::string& pattern, const std::string& file_path,
+                                                   const std::string& meta_file_path, int num_threads,
+                                                   int num_max_readers) {
+  return std::make_shared<ExternSearcher<Tag>>(pattern, file_path, meta_file_path, false, num_threads,
+                                               num_max_readers);
+}
+
+}  // namespace xs

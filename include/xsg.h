@@ -150,6 +150,102 @@ int xsg_result_lines_size(xsg_shard* shard, uint64_t* n_lines, uint64_t* total_b
  * `offsets` (optional) receives the global byte offset of each line start. */
 int xsg_result_lines(xsg_shard* shard, uint64_t* lengths, char* bytes, uint64_t bytes_cap, uint64_t* offsets);
 
+/* newline count of the shard, available after an XSG_LINE_INDICES search (lets a
+ * caller chain line-index bases from chunk to chunk without a second pass). */
+int xsg_result_newlines(xsg_shard* shard, uint64_t* newlines);
+
+/* ======================================================================== */
+/* File searches: the host pipeline behind xs::extern_search                 */
+/* ======================================================================== */
+/* Replaces, for the literal path, what the reference runs inside
+ * include/xsearch/Searcher.h:100-120 (worker loop: read -> search -> result.add)
+ * with include/xsearch/tasks/readers.h:29-54 as the reader and
+ * include/xsearch/ResultTypes.h:31-130 as the result container:
+ *   - chunks are cut at '\n' (>= chunk_bytes, extended to the next newline; the
+ *     layout the reference's .meta fixtures show) or taken from a metafile;
+ *   - num_threads workers each own a pinned host buffer, a device buffer and a
+ *     HIP stream: pread -> (decompress) -> hipMemcpyAsync -> scan -> results;
+ *   - at most num_max_readers workers read at the same time;
+ *   - partial results are published in chunk order; a consumer may read them
+ *     while the search is still running (blocking cursor below).
+ * Errors: start fails for an unreadable file / bad metafile / no device; a
+ * failure inside a worker stops the job and is returned by xsg_job_join. */
+typedef struct xsg_job xsg_job;
+
+typedef struct xsg_job_opts {
+  uint32_t struct_size;     /* sizeof(xsg_job_opts), for ABI growth */
+  uint32_t mode;            /* enum xsg_mode */
+  uint32_t pattern_flags;   /* XSG_FLAG_* */
+  int32_t device;           /* HIP device index */
+  int32_t num_threads;      /* worker threads, >= 1 */
+  int32_t num_max_readers;  /* concurrent reads, >= 1 */
+  uint64_t chunk_bytes;     /* target chunk size without a metafile (default 16 MiB) */
+} xsg_job_opts;
+
+typedef struct xsg_job_stats {
+  uint64_t bytes_scanned;  /* uncompressed bytes handed to the GPU */
+  uint64_t bytes_read;     /* bytes read from disk/page cache */
+  uint64_t chunks;
+  double seconds_total;    /* start -> last worker done */
+  double seconds_read;     /* summed over workers */
+  double seconds_decompress;
+  double seconds_device;   /* H2D + kernels + D2H, summed over workers */
+} xsg_job_stats;
+
+void xsg_job_opts_init(xsg_job_opts* opts);
+/* meta_file_path may be NULL.  Returns immediately; the search runs in the
+ * job's own threads. */
+int xsg_job_start(const void* pattern, size_t plen, const char* file_path, const char* meta_file_path,
+                  const xsg_job_opts* opts, xsg_job** out);
+/* Blocks until every worker has finished; returns the first worker error. */
+int xsg_job_join(xsg_job* job);
+/* Joins, then frees the job and everything it returned pointers into. */
+void xsg_job_destroy(xsg_job* job);
+/* Count tags: the count so far (final after join).  List tags: elements so far. */
+int xsg_job_total(xsg_job* job, uint64_t* total);
+/* Blocks until element `index` of the result sequence exists or the job has
+ * finished.  *available = number of elements that exist now; *finished = 1 once
+ * no more will come.  Count tags: element k = running total after k+1 chunks. */
+int xsg_job_wait(xsg_job* job, uint64_t index, uint64_t* available, int* finished);
+/* Non-blocking form of xsg_job_wait. */
+int xsg_job_poll(xsg_job* job, uint64_t* available, int* finished);
+int xsg_job_get_u64(xsg_job* job, uint64_t first, uint64_t n, uint64_t* out);
+/* XSG_LINES: line `index`; *data stays valid until xsg_job_destroy. */
+int xsg_job_get_line(xsg_job* job, uint64_t index, const char** data, uint64_t* len);
+int xsg_job_stats_get(xsg_job* job, xsg_job_stats* stats);
+
+/* ---- chunk plans and metafiles (host only: usable without a GPU) ------------- */
+/* One record of the reference's metafile (decoded from test/files/ *.meta,
+ * field names from metafile_cat.cpp:39-49). */
+typedef struct xsg_file_chunk {
+  uint64_t original_offset; /* offset in the uncompressed stream */
+  uint64_t actual_offset;   /* offset in the file on disk */
+  uint64_t original_size;
+  uint64_t actual_size;     /* == original_size when not compressed */
+  uint64_t first_line;      /* global index of the first line of the chunk, or XSG_LINE_BASE_AUTO */
+  uint64_t n_mappings;      /* metafile only: number of (byte offset, line index) pairs */
+} xsg_file_chunk;
+
+#define XSG_COMPRESSION_NONE 1
+#define XSG_COMPRESSION_ZSTD 2
+#define XSG_COMPRESSION_LZ4 3
+
+/* Newline-aligned plan of a plain file: every chunk is >= target_bytes long and
+ * ends just after a '\n' (the last one ends at EOF).  *chunks is malloc'ed:
+ * release with xsg_free. */
+int xsg_plan_chunks(const char* file_path, uint64_t target_bytes, xsg_file_chunk** chunks, uint64_t* n);
+/* Parse a metafile.  mappings (optional) receives all (globalByteOffset,
+ * globalLineIndex) pairs back to back, 2 uint64 each, n_mappings per chunk. */
+int xsg_meta_read(const char* meta_path, int32_t* compression, xsg_file_chunk** chunks, uint64_t* n,
+                  uint64_t** mappings, uint64_t* n_mapping_pairs);
+/* Preprocess `file_path` into the reference's on-disk layout: writes the
+ * metafile and, for ZSTD/LZ4, the chunk-wise compressed data file
+ * (data_out_path; ignored for XSG_COMPRESSION_NONE).  mapping_gap = minimum
+ * distance in bytes between two mapping entries (fixtures: 500). */
+int xsg_meta_write(const char* file_path, const char* meta_out_path, const char* data_out_path, int32_t compression,
+                   uint64_t chunk_bytes, uint64_t mapping_gap, int hc);
+void xsg_free(void* p);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 /* Name of the device the ctx is bound to (e.g. "gfx950..."), CU count. */
 int xsg_ctx_info(xsg_ctx* ctx, char* arch, size_t arch_cap, int* compute_units, uint64_t* hbm_bytes);

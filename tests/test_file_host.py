@@ -1,0 +1,145 @@
+"""Host-side file logic of the pipeline (no GPU): newline-aligned chunk plans,
+metafile reader/writer.  The metafile format is pinned by the reference's four
+.meta fixtures (test/files/): they are parsed in place when the
+reference tree is mounted and compared with tests/golden/ref_metafile_summary.json."""
+import hashlib
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import corpus
+import golden_util as G
+import xsg
+
+REF_FILES = Path("/root/reference/test/files")
+
+
+@pytest.fixture(scope="module")
+def text_file(tmp_path_factory):
+    d = tmp_path_factory.mktemp("xsg")
+    blocks = [corpus.text_block(31, i, 700_000 + 13 * i, needle_rate=1e-3) for i in range(4)]
+    data = np.concatenate(blocks)
+    p = d / "corpus.txt"
+    data.tofile(p)
+    return p, data
+
+
+def test_plan_is_newline_aligned_and_covers_the_file(text_file):
+    p, data = text_file
+    for target in (1 << 16, 1 << 20, 1 << 30):
+        pl = xsg.plan_chunks(str(p), target)
+        assert int(pl["original_size"].sum()) == data.size
+        pos = 0
+        for i, c in enumerate(pl):
+            assert int(c["original_offset"]) == pos == int(c["actual_offset"])
+            n = int(c["original_size"])
+            last = i == len(pl) - 1
+            assert n >= target or last
+            assert data[pos + n - 1] == 10  # ends just after a newline (the corpus is '\n'-terminated)
+            if not last:
+                # minimal: no newline in [pos+target-1, end-1)
+                assert not (data[pos + target - 1:pos + n - 1] == 10).any()
+            pos += n
+
+
+def test_plan_edge_cases(tmp_path):
+    e = tmp_path / "empty"
+    e.write_bytes(b"")
+    assert len(xsg.plan_chunks(str(e), 100)) == 0
+    f = tmp_path / "no_nl"
+    f.write_bytes(b"x" * 1000)
+    pl = xsg.plan_chunks(str(f), 100)
+    assert len(pl) == 1 and int(pl[0]["original_size"]) == 1000
+    g = tmp_path / "unterminated"
+    g.write_bytes(b"ab\n" * 100 + b"tail")
+    pl = xsg.plan_chunks(str(g), 30)
+    assert int(pl["original_size"].sum()) == 304
+    assert all(int(c["original_size"]) % 3 == 0 for c in pl[:-1])
+    with pytest.raises(xsg.XsgError) as ei:
+        xsg.plan_chunks(str(tmp_path / "missing"), 100)
+    assert ei.value.code == xsg.EIO
+
+
+@pytest.mark.parametrize("comp,name", [(xsg.COMPRESSION_NONE, "none"), (xsg.COMPRESSION_LZ4, "lz4"),
+                                       (xsg.COMPRESSION_ZSTD, "zst")])
+def test_meta_write_read_roundtrip(text_file, tmp_path, comp, name):
+    p, data = text_file
+    meta, out = tmp_path / f"c.{name}.meta", tmp_path / f"c.{name}"
+    xsg.meta_write(str(p), str(meta), str(out), comp, 1 << 19, 500)
+    ctype, chunks, maps = xsg.meta_read(str(meta), True)
+    assert ctype == comp
+    plan = xsg.plan_chunks(str(p), 1 << 19)
+    assert chunks["original_offset"].tolist() == plan["original_offset"].tolist()
+    assert chunks["original_size"].tolist() == plan["original_size"].tolist()
+    # mapping entries: (line start offset, 0-based line index); first entry of a chunk = chunk start;
+    # consecutive entries of a chunk >= 500 bytes apart (fixtures: min 500 / max 818)
+    nl = np.flatnonzero(data == 10)
+    line_starts = np.concatenate([[0], nl + 1])
+    at = 0
+    for c in chunks:
+        m = maps[at:at + int(c["n_mappings"])]
+        at += int(c["n_mappings"])
+        assert int(m[0][0]) == int(c["original_offset"]) and int(c["first_line"]) == int(m[0][1])
+        idx = np.searchsorted(line_starts, m[:, 0])
+        assert (line_starts[idx] == m[:, 0]).all()       # every entry is a line start
+        assert (idx == m[:, 1]).all()                     # ... with its 0-based line index
+        gaps = np.diff(m[:, 0].astype(np.int64))
+        assert (gaps[1:] >= 500).all() if len(gaps) > 1 else True
+    if comp == xsg.COMPRESSION_NONE:
+        assert chunks["actual_size"].tolist() == chunks["original_size"].tolist()
+        assert chunks["actual_offset"].tolist() == chunks["original_offset"].tolist()
+    else:
+        assert int(chunks["actual_size"].sum()) == out.stat().st_size < data.size
+        assert chunks["actual_offset"].tolist() == np.concatenate([[0], np.cumsum(chunks["actual_size"])[:-1]]).tolist()
+
+
+def test_meta_read_rejects_garbage(tmp_path):
+    bad = tmp_path / "bad.meta"
+    bad.write_bytes(b"\x07\x00\x00\x00")
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.meta_read(str(bad))
+    assert e.value.code == xsg.EIO
+    bad.write_bytes(b"\x01\x00\x00\x00" + b"\x00" * 17)
+    with pytest.raises(xsg.XsgError):
+        xsg.meta_read(str(bad))
+
+
+def _summary(path):
+    ctype, chunks, maps = xsg.meta_read(str(path), True)
+    return {
+        "compression_type": ctype,
+        "file_bytes": os.path.getsize(path),
+        "original_size": [int(x) for x in chunks["original_size"]],
+        "actual_size_total": int(chunks["actual_size"].sum()),
+        "n_mappings": [int(x) for x in chunks["n_mappings"]],
+        "first_line": [int(x) for x in chunks["first_line"]],
+        "last_mapping": [int(x) for x in maps[-1]],
+        "mapping_gap_min_max": [int(np.diff(maps[:int(chunks["n_mappings"][0]), 0].astype(np.int64))[1:].min()),
+                                int(np.diff(maps[:int(chunks["n_mappings"][0]), 0].astype(np.int64)).max())],
+        "mappings_sha256": hashlib.sha256(maps.tobytes()).hexdigest(),
+    }
+
+
+def test_reference_metafile_fixtures():
+    """The four fixtures the reference's tests use must parse to exactly EOF with
+    the values recorded in tests/golden/ref_metafile_summary.json."""
+    want = G.load("ref_metafile_summary.json")
+    assert want["sample.meta"]["compression_type"] == 1 and want["sample.xszst.meta"]["compression_type"] == 2
+    assert want["sample.xslz4.meta"]["compression_type"] == want["sample.xslz4hc.meta"]["compression_type"] == 3
+    for v in want.values():
+        assert sum(v["original_size"]) == 100_000_000 and v["file_bytes"] == 3_060_484
+        assert v["last_mapping"] == [99_999_691, 3_447_129]
+    if not REF_FILES.exists():
+        pytest.skip("reference tree not mounted: summary checked, fixtures not re-parsed")
+    for name, v in want.items():
+        assert _summary(REF_FILES / name) == v, name
+
+
+if __name__ == "__main__":  # regenerate the summary (build container only)
+    out = {n: _summary(REF_FILES / n) for n in ("sample.meta", "sample.xslz4.meta", "sample.xslz4hc.meta",
+                                                  "sample.xszst.meta")}
+    (G.GOLDEN / "ref_metafile_summary.json").write_text(json.dumps(out, indent=1))
+    print(json.dumps(out, indent=1)[:600])

@@ -1,0 +1,168 @@
+"""The drop-in boundary end to end on the GPU box: xs::extern_search (C++,
+include/xsearch/xsearch.h) and its C ABI (xsg_job_*) on real files, plain and
+through metafiles (none / LZ4 / ZSTD), against the oracle run chunk by chunk
+over the same chunk plan.  Reads like the reference's test/src/xsearchTest.cpp:
+{join, live} x {plain, meta} x {six tags} x {1, 4 threads}."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import corpus
+import xsg
+from gpu_util import oracle_all_modes
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+CLI = ROOT / "tests" / "cpp" / "build" / "extern_search_cli"
+TAGS = {"count": xsg.COUNT_MATCHES, "count_lines": xsg.COUNT_LINES, "match_byte_offsets": xsg.MATCH_BYTE_OFFSETS,
+        "line_byte_offsets": xsg.LINE_BYTE_OFFSETS, "line_indices": xsg.LINE_INDICES, "lines": xsg.LINES}
+KEY = {"count": "count_matches", "count_lines": "count_lines", "match_byte_offsets": "match_byte_offsets",
+       "line_byte_offsets": "line_byte_offsets", "line_indices": "line_indices", "lines": "lines"}
+CHUNK = 2 << 20
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory, oracle):
+    d = tmp_path_factory.mktemp("xsjobs")
+    blocks = [corpus.text_block(77, i, 3_000_000 + 17 * i, needle_rate=4e-4) for i in range(6)]
+    data = np.concatenate(blocks)
+    data = np.concatenate([data[:-1], np.frombuffer(b" SheSherlock", dtype=np.uint8)])  # decoy + no final newline
+    txt = d / "sample.txt"
+    data.tofile(txt)
+    plan = xsg.plan_chunks(str(txt), CHUNK)
+    chunks = [data[int(c["original_offset"]):int(c["original_offset"] + c["original_size"])] for c in plan]
+    want = {p: oracle_all_modes(oracle, chunks, p) for p in (b"Sherlock", b"She", b"detective street")}
+    metas = {}
+    for comp, name in ((xsg.COMPRESSION_NONE, "none"), (xsg.COMPRESSION_LZ4, "xslz4"), (xsg.COMPRESSION_ZSTD, "xszst")):
+        out = d / f"sample.{name}"
+        meta = d / f"sample.{name}.meta"
+        xsg.meta_write(str(txt), str(meta), str(out), comp, CHUNK, 500)
+        metas[name] = (str(txt) if comp == xsg.COMPRESSION_NONE else str(out), str(meta))
+    return {"txt": str(txt), "want": want, "metas": metas, "nchunks": len(plan), "size": data.size}
+
+
+def as_py(tag, value):
+    if tag in ("count", "count_lines"):
+        return int(value)
+    if tag == "lines":
+        return list(value)
+    return [int(x) for x in value]
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("tag", list(TAGS))
+def test_job_join_plain(files, tag, threads):
+    for pat, want in files["want"].items():
+        j = xsg.Job(pat, files["txt"], TAGS[tag], num_threads=threads, num_max_readers=threads, chunk_bytes=CHUNK)
+        got = as_py(tag, j.result())
+        assert got == want[KEY[tag]], (tag, pat, threads)
+        st = j.stats()
+        assert st["chunks"] == files["nchunks"] and st["bytes_scanned"] == files["size"]
+        j.close()
+
+
+@pytest.mark.parametrize("tag", list(TAGS))
+def test_job_live_iteration(files, tag):
+    pat = b"She"
+    want = files["want"][pat][KEY[tag]]
+    j = xsg.Job(pat, files["txt"], TAGS[tag], num_threads=3, num_max_readers=2, chunk_bytes=CHUNK)
+    seen = list(j)  # blocks per element until the job closes
+    if tag in ("count", "count_lines"):
+        assert len(seen) == files["nchunks"] and seen[-1] == want and seen == sorted(seen)
+    else:
+        assert as_py(tag, seen) == want
+    j.join()
+    j.close()
+
+
+@pytest.mark.parametrize("meta", ["none", "xslz4", "xszst"])
+@pytest.mark.parametrize("tag", list(TAGS))
+def test_job_with_metafile(files, tag, meta):
+    data_path, meta_path = files["metas"][meta]
+    pat = b"Sherlock"
+    j = xsg.Job(pat, data_path, TAGS[tag], meta_path=meta_path, num_threads=2, num_max_readers=2)
+    assert as_py(tag, j.result()) == files["want"][pat][KEY[tag]], (tag, meta)
+    st = j.stats()
+    if meta != "none":
+        assert st["bytes_read"] < st["bytes_scanned"] == files["size"]
+    j.close()
+
+
+def test_job_errors(files, tmp_path):
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.Job(b"x", str(tmp_path / "missing.txt"), xsg.COUNT_MATCHES)
+    assert e.value.code == xsg.EIO
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.Job(b"", files["txt"], xsg.COUNT_MATCHES)
+    assert e.value.code == xsg.EINVAL
+    bad = tmp_path / "bad.meta"
+    bad.write_bytes(b"\x09\x00\x00\x00")
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.Job(b"x", files["txt"], xsg.COUNT_MATCHES, meta_path=str(bad))
+    assert e.value.code == xsg.EIO
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.Job(b"a\nb", files["txt"], xsg.LINES)
+    assert e.value.code == xsg.ENOTSUP
+    empty = tmp_path / "empty.txt"
+    empty.write_bytes(b"")
+    j = xsg.Job(b"x", str(empty), xsg.COUNT_MATCHES)
+    assert j.result() == 0 and list(j) == []
+    j.close()
+
+
+def run_cli(*args, env=None):
+    import os
+    e = dict(os.environ)
+    e["XS_CHUNK_BYTES"] = str(CHUNK)
+    if env:
+        e.update(env)
+    return subprocess.run([str(CLI), *args], capture_output=True, env=e, timeout=300)
+
+
+@pytest.mark.parametrize("how", ["join", "live"])
+@pytest.mark.parametrize("tag", list(TAGS))
+def test_cpp_extern_search(files, tag, how):
+    """xs::extern_search<Tag>(pattern, file, false, threads) as README.md:37 / xsearchTest.cpp:344 call it."""
+    if not CLI.exists():
+        pytest.fail(f"{CLI} not built (make -C tests/cpp)")
+    pat = b"Sherlock"
+    want = files["want"][pat][KEY[tag]]
+    for threads in ("1", "4"):
+        r = run_cli(tag, how, pat.decode(), files["txt"], "-", threads)
+        assert r.returncode == 0, r.stderr.decode()
+        out = r.stdout.split(b"\n")[:-1]
+        if tag in ("count", "count_lines"):
+            assert int(out[0]) == want
+        elif tag == "lines":
+            assert out == want
+        else:
+            assert [int(x) for x in out] == want
+
+
+def test_cpp_extern_search_with_meta_and_errors(files):
+    data_path, meta_path = files["metas"]["xslz4"]
+    r = run_cli("count", "join", "Sherlock", data_path, meta_path, "4", "2")  # README.md:72 / checkit.cpp:4
+    assert r.returncode == 0 and int(r.stdout) == files["want"][b"Sherlock"]["count_matches"]
+    r = run_cli("lines", "live", "Sherlock", data_path, meta_path, "4", "2")
+    assert r.returncode == 0 and r.stdout.split(b"\n")[:-1] == files["want"][b"Sherlock"]["lines"]
+    r = run_cli("count", "join", "Sherlock", "/nonexistent/file.txt")
+    assert r.returncode == 1 and b"cannot open" in r.stderr
+
+
+def test_config1_shape_100mb_six_chunks(oracle, tmp_path):
+    """BASELINE configs[0]: xs::count 'Sherlock' on a 100 000 000-byte file -> 6 chunks of 16 MiB(+) like
+    test/files/sample.meta."""
+    blocks = [corpus.text_block(123, i, 10_000_000) for i in range(10)]
+    data = np.concatenate(blocks)
+    assert data.size == 100_000_000
+    p = tmp_path / "sample.txt"
+    data.tofile(p)
+    plan = xsg.plan_chunks(str(p))
+    assert len(plan) == 6 and all(16777216 <= int(c["original_size"]) < 16777216 + 200 for c in plan[:-1])
+    chunks = [data[int(c["original_offset"]):int(c["original_offset"] + c["original_size"])] for c in plan]
+    want = sum(oracle.count(c, b"Sherlock", False) for c in chunks)
+    j = xsg.Job(b"Sherlock", str(p), xsg.COUNT_MATCHES, num_threads=1)
+    assert j.result() == want > 0
+    j.close()

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "xsg_internal.h"
+#include "xsg_objects.h"
 #include "xsg_tail.h"
 
 using namespace xsg;
@@ -22,26 +22,16 @@ using namespace xsg;
 // ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char* fmt, ...) {
+namespace xsg {
+int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
   return code;
 }
-
-#define HIP_TRY(expr)                                                                                   \
-  do {                                                                                                  \
-    hipError_t _e = (expr);                                                                             \
-    if (_e != hipSuccess) return fail(XSG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-                                      __FILE__, __LINE__);                                              \
-  } while (0)
-
-#define XSG_TRY(expr)        \
-  do {                       \
-    int _r = (expr);         \
-    if (_r != XSG_OK) return _r; \
-  } while (0)
+const char* last_error_message() { return g_err; }
+}  // namespace xsg
 
 extern "C" int xsg_abi_version(void) { return XSG_ABI_VERSION; }
 
@@ -71,56 +61,6 @@ extern "C" int xsg_device_count(int* count) {
   *count = n;
   return XSG_OK;
 }
-
-// ---------------------------------------------------------------------------
-// device buffers (grow-only)
-// ---------------------------------------------------------------------------
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t bytes) {
-    if (bytes <= cap && p) return XSG_OK;
-    if (bytes == 0) bytes = 16;
-    // grow geometrically so that repeated searches with slowly growing results do not re-allocate
-    size_t want = std::max(bytes, cap + cap / 2);
-    want = (want + 255) & ~(size_t)255;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {
-      p = nullptr;
-      return fail(XSG_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-    }
-    cap = want;
-    return XSG_OK;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  template <typename T>
-  T* as() const {
-    return static_cast<T*>(p);
-  }
-};
-
-// ---------------------------------------------------------------------------
-// context
-// ---------------------------------------------------------------------------
-struct xsg_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::vector<uint8_t> pattern;
-  uint32_t flags = 0;
-  bool bordered = false;  // the pattern can overlap itself
-  PatternDev pat{};
-  DevBuf d_pat;
-  char arch[128] = "";
-  int cus = 0;
-  uint64_t hbm = 0;
-};
 
 extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
   if (!out) return fail(XSG_EINVAL, "out is null");
@@ -224,37 +164,6 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
 // ---------------------------------------------------------------------------
 // shards
 // ---------------------------------------------------------------------------
-struct xsg_shard {
-  xsg_ctx* ctx = nullptr;
-  const uint8_t* base = nullptr;
-  uint64_t capacity = 0;
-  std::vector<xsg_chunk> chunks;
-  std::vector<uint64_t> chunk_tile0;
-  uint64_t ntiles = 0;
-  uint64_t total_bytes = 0;
-  uint64_t shard_line_base = 0;
-
-  DevBuf d_chunks, d_tile_chunk, d_chunk_tile0;
-  DevBuf d_tile_cnt, d_tile_nl, d_tile_sum, d_chunk_last, d_counters;
-  DevBuf d_tile_off, d_tile_nl_off, d_scan_tmp;
-  DevBuf d_m_pos, d_m_chunk, d_m_ls, d_keep, d_keep_pre;
-  DevBuf d_chunk_shift0, d_tail_cnt, d_tail_pos, d_tail_pre;
-  DevBuf d_f_pos, d_f_match, d_f_chunk, d_out_u64, d_line_len, d_line_off, d_line_bytes;
-
-  int last_mode = -1;
-  uint64_t total = 0;       // elements of the last list search
-  uint64_t line_bytes = 0;  // XSG_LINES: packed bytes
-  std::vector<uint64_t> h_line_len, h_line_off;
-
-  void release_all() {
-    DevBuf* all[] = {&d_chunks, &d_tile_chunk, &d_chunk_tile0, &d_tile_cnt, &d_tile_nl, &d_tile_sum, &d_chunk_last,
-                     &d_counters, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls, &d_keep,
-                     &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
-                     &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes};
-    for (DevBuf* b : all) b->release();
-  }
-};
-
 static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const xsg_chunk* chunks, uint64_t nchunks) {
   xsg_ctx* c = s->ctx;
   if (nchunks && !chunks) return fail(XSG_EINVAL, "chunks is null");
@@ -614,6 +523,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
                                       st));
     o.tile_nl_off = s->d_tile_nl_off.as<uint64_t>();
     HIP_TRY(launch_line_indices(o, st));
+    HIP_TRY(hipMemcpyAsync(&s->last_newlines, s->d_tile_nl_off.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, st));
   } else {  // XSG_LINES
     XSG_TRY(s->d_line_len.ensure(8 * std::max<uint64_t>(total, 1)));
     XSG_TRY(s->d_line_off.ensure(8 * (total + 1)));
@@ -668,6 +578,13 @@ extern "C" int xsg_result_u64(xsg_shard* s, uint64_t* out, uint64_t cap) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(out, s->d_out_u64.p, 8 * s->total, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return XSG_OK;
+}
+
+extern "C" int xsg_result_newlines(xsg_shard* s, uint64_t* newlines) {
+  if (!s || !newlines) return fail(XSG_EINVAL, "null argument");
+  if (s->last_mode != XSG_LINE_INDICES) return fail(XSG_ESTATE, "no XSG_LINE_INDICES result is pending on this shard");
+  *newlines = s->last_newlines;
   return XSG_OK;
 }
 

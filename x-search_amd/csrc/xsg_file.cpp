@@ -1,0 +1,737 @@
+// xsg_file.cpp -- the host pipeline behind xs::extern_search: chunk plans,
+// metafiles, reader/feeder threads, ordered result store.  C++ on the host (the
+// reference's pipeline is C++: include/xsearch/Searcher.h, tasks/readers.h,
+// ResultTypes.h); the scan itself always runs on the GPU through the shard API
+// of xsg_api.cpp -- there is no CPU search path in here.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include "xsg_objects.h"
+
+using namespace xsg;
+using Clock = std::chrono::steady_clock;
+
+static double seconds_since(Clock::time_point t0) {
+  return std::chrono::duration<double>(Clock::now() - t0).count();
+}
+
+extern "C" void xsg_free(void* p) { free(p); }
+
+// ---------------------------------------------------------------------------
+// file helpers
+// ---------------------------------------------------------------------------
+static int pread_full(int fd, void* buf, uint64_t n, uint64_t off) {
+  uint8_t* p = static_cast<uint8_t*>(buf);
+  while (n) {
+    const ssize_t r = pread(fd, p, n > (1u << 30) ? (1u << 30) : n, (off_t)off);
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      return fail(XSG_EIO, "pread failed: %s", strerror(errno));
+    }
+    if (r == 0) return fail(XSG_EIO, "unexpected end of file at offset %llu", (unsigned long long)off);
+    p += r;
+    off += (uint64_t)r;
+    n -= (uint64_t)r;
+  }
+  return XSG_OK;
+}
+
+static int open_ro(const char* path, int* fd, uint64_t* size) {
+  if (!path || !*path) return fail(XSG_EINVAL, "empty file path");
+  const int f = open(path, O_RDONLY | O_CLOEXEC);
+  if (f < 0) return fail(XSG_EIO, "cannot open '%s': %s", path, strerror(errno));
+  struct stat st;
+  if (fstat(f, &st) != 0) {
+    close(f);
+    return fail(XSG_EIO, "cannot stat '%s': %s", path, strerror(errno));
+  }
+  if (!S_ISREG(st.st_mode)) {
+    close(f);
+    return fail(XSG_EIO, "'%s' is not a regular file", path);
+  }
+  *fd = f;
+  *size = (uint64_t)st.st_size;
+  return XSG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// chunk plan of a plain file: >= target bytes, extended to just past the next '\n'
+// (the layout of the reference's fixtures: SURVEY 5.1)
+// ---------------------------------------------------------------------------
+static int plan_plain(int fd, uint64_t size, uint64_t target, std::vector<xsg_file_chunk>& out) {
+  if (target < 1) target = 1;
+  uint64_t pos = 0;
+  std::vector<uint8_t> probe(1 << 16);
+  while (pos < size) {
+    uint64_t end = pos + target;
+    if (end >= size) {
+      end = size;
+    } else {
+      // first '\n' at or after end-1
+      uint64_t q = end - 1;
+      bool found = false;
+      while (q < size) {
+        const uint64_t n = std::min<uint64_t>(probe.size(), size - q);
+        XSG_TRY(pread_full(fd, probe.data(), n, q));
+        const void* hit = memchr(probe.data(), '\n', n);
+        if (hit) {
+          end = q + (uint64_t)((const uint8_t*)hit - probe.data()) + 1;
+          found = true;
+          break;
+        }
+        q += n;
+      }
+      if (!found) end = size;
+    }
+    xsg_file_chunk c{};
+    c.original_offset = pos;
+    c.actual_offset = pos;
+    c.original_size = end - pos;
+    c.actual_size = end - pos;
+    c.first_line = XSG_LINE_BASE_AUTO;
+    c.n_mappings = 0;
+    out.push_back(c);
+    pos = end;
+  }
+  return XSG_OK;
+}
+
+static int to_malloc(const std::vector<xsg_file_chunk>& v, xsg_file_chunk** chunks, uint64_t* n) {
+  *n = v.size();
+  *chunks = static_cast<xsg_file_chunk*>(malloc(sizeof(xsg_file_chunk) * std::max<size_t>(v.size(), 1)));
+  if (!*chunks) return fail(XSG_ENOMEM, "host allocation failed");
+  if (!v.empty()) memcpy(*chunks, v.data(), sizeof(xsg_file_chunk) * v.size());
+  return XSG_OK;
+}
+
+extern "C" int xsg_plan_chunks(const char* file_path, uint64_t target_bytes, xsg_file_chunk** chunks, uint64_t* n) {
+  if (!chunks || !n) return fail(XSG_EINVAL, "null output");
+  int fd;
+  uint64_t size;
+  XSG_TRY(open_ro(file_path, &fd, &size));
+  std::vector<xsg_file_chunk> v;
+  const int r = plan_plain(fd, size, target_bytes ? target_bytes : (16u << 20), v);
+  close(fd);
+  if (r != XSG_OK) return r;
+  return to_malloc(v, chunks, n);
+}
+
+// ---------------------------------------------------------------------------
+// metafile (little-endian, packed):
+//   int32 compression_type, then per chunk
+//   u64 original_offset, actual_offset, original_size, actual_size, n, n x {u64 byte offset, u64 line index}
+// ---------------------------------------------------------------------------
+static int read_meta(const char* path, int32_t* compression, std::vector<xsg_file_chunk>& chunks,
+                     std::vector<uint64_t>* mappings) {
+  int fd;
+  uint64_t size;
+  XSG_TRY(open_ro(path, &fd, &size));
+  std::vector<uint8_t> buf(size);
+  int r = size ? pread_full(fd, buf.data(), size, 0) : XSG_OK;
+  close(fd);
+  if (r != XSG_OK) return r;
+  if (size < 4) return fail(XSG_EIO, "metafile '%s' is too short", path);
+  int32_t ct;
+  memcpy(&ct, buf.data(), 4);
+  if (ct != XSG_COMPRESSION_NONE && ct != XSG_COMPRESSION_ZSTD && ct != XSG_COMPRESSION_LZ4)
+    return fail(XSG_EIO, "metafile '%s': unknown compression type %d", path, ct);
+  *compression = ct;
+  uint64_t pos = 4;
+  uint64_t expect_orig = 0;
+  while (pos < size) {
+    if (size - pos < 40) return fail(XSG_EIO, "metafile '%s': truncated chunk record at byte %llu", path,
+                                     (unsigned long long)pos);
+    uint64_t f[5];
+    memcpy(f, buf.data() + pos, 40);
+    pos += 40;
+    const uint64_t n = f[4];
+    if (n > (size - pos) / 16) return fail(XSG_EIO, "metafile '%s': mapping table of chunk %zu overruns the file", path,
+                                           chunks.size());
+    xsg_file_chunk c{};
+    c.original_offset = f[0];
+    c.actual_offset = f[1];
+    c.original_size = f[2];
+    c.actual_size = f[3];
+    c.n_mappings = n;
+    c.first_line = XSG_LINE_BASE_AUTO;
+    if (c.original_offset != expect_orig)
+      return fail(XSG_EIO, "metafile '%s': chunk %zu does not start where its predecessor ends", path, chunks.size());
+    expect_orig += c.original_size;
+    if (n) {
+      uint64_t first[2];
+      memcpy(first, buf.data() + pos, 16);
+      // the first mapping entry of a chunk is the chunk start
+      if (first[0] == c.original_offset) c.first_line = first[1];
+      if (mappings) {
+        const size_t at = mappings->size();
+        mappings->resize(at + 2 * n);
+        memcpy(mappings->data() + at, buf.data() + pos, 16 * n);
+      }
+    }
+    pos += 16 * n;
+    chunks.push_back(c);
+  }
+  return XSG_OK;
+}
+
+extern "C" int xsg_meta_read(const char* meta_path, int32_t* compression, xsg_file_chunk** chunks, uint64_t* n,
+                             uint64_t** mappings, uint64_t* n_mapping_pairs) {
+  if (!compression || !chunks || !n) return fail(XSG_EINVAL, "null output");
+  std::vector<xsg_file_chunk> v;
+  std::vector<uint64_t> maps;
+  XSG_TRY(read_meta(meta_path, compression, v, mappings ? &maps : nullptr));
+  XSG_TRY(to_malloc(v, chunks, n));
+  if (mappings) {
+    *mappings = static_cast<uint64_t*>(malloc(8 * std::max<size_t>(maps.size(), 1)));
+    if (!*mappings) return fail(XSG_ENOMEM, "host allocation failed");
+    if (!maps.empty()) memcpy(*mappings, maps.data(), 8 * maps.size());
+    if (n_mapping_pairs) *n_mapping_pairs = maps.size() / 2;
+  }
+  return XSG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// LZ4 / ZSTD through the system libraries (the reference links liblz4 / libzstd,
+// Dockerfile:8).  Loaded on demand so that plain-text searches need neither.
+// ---------------------------------------------------------------------------
+struct Codecs {
+  void* lz4 = nullptr;
+  void* zstd = nullptr;
+  int (*LZ4_decompress_safe)(const char*, char*, int, int) = nullptr;
+  int (*LZ4_compress_default)(const char*, char*, int, int) = nullptr;
+  int (*LZ4_compress_HC)(const char*, char*, int, int, int) = nullptr;
+  int (*LZ4_compressBound)(int) = nullptr;
+  size_t (*ZSTD_decompress)(void*, size_t, const void*, size_t) = nullptr;
+  size_t (*ZSTD_compress)(void*, size_t, const void*, size_t, int) = nullptr;
+  size_t (*ZSTD_compressBound)(size_t) = nullptr;
+  unsigned (*ZSTD_isError)(size_t) = nullptr;
+};
+
+static Codecs& codecs() {
+  static Codecs c;
+  return c;
+}
+static std::mutex g_codec_mu;
+
+static void* open_any(const char* const* names) {
+  for (; *names; ++names) {
+    void* h = dlopen(*names, RTLD_NOW | RTLD_LOCAL);
+    if (h) return h;
+  }
+  return nullptr;
+}
+
+static int need_lz4() {
+  std::lock_guard<std::mutex> g(g_codec_mu);
+  Codecs& c = codecs();
+  if (c.lz4) return XSG_OK;
+  static const char* names[] = {"liblz4.so.1", "liblz4.so", "/opt/conda/lib/liblz4.so.1", nullptr};
+  void* h = open_any(names);
+  if (!h) return fail(XSG_ENOTSUP, "liblz4 not found on this host (needed for LZ4 metafiles)");
+  c.LZ4_decompress_safe = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_decompress_safe");
+  c.LZ4_compress_default = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_compress_default");
+  c.LZ4_compress_HC = (int (*)(const char*, char*, int, int, int))dlsym(h, "LZ4_compress_HC");
+  c.LZ4_compressBound = (int (*)(int))dlsym(h, "LZ4_compressBound");
+  if (!c.LZ4_decompress_safe || !c.LZ4_compress_default || !c.LZ4_compressBound)
+    return fail(XSG_ENOTSUP, "liblz4 lacks the expected symbols");
+  c.lz4 = h;
+  return XSG_OK;
+}
+
+static int need_zstd() {
+  std::lock_guard<std::mutex> g(g_codec_mu);
+  Codecs& c = codecs();
+  if (c.zstd) return XSG_OK;
+  static const char* names[] = {"libzstd.so.1", "libzstd.so", "/opt/conda/lib/libzstd.so.1", nullptr};
+  void* h = open_any(names);
+  if (!h) return fail(XSG_ENOTSUP, "libzstd not found on this host (needed for ZSTD metafiles)");
+  c.ZSTD_decompress = (size_t(*)(void*, size_t, const void*, size_t))dlsym(h, "ZSTD_decompress");
+  c.ZSTD_compress = (size_t(*)(void*, size_t, const void*, size_t, int))dlsym(h, "ZSTD_compress");
+  c.ZSTD_compressBound = (size_t(*)(size_t))dlsym(h, "ZSTD_compressBound");
+  c.ZSTD_isError = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+  if (!c.ZSTD_decompress || !c.ZSTD_compress || !c.ZSTD_compressBound || !c.ZSTD_isError)
+    return fail(XSG_ENOTSUP, "libzstd lacks the expected symbols");
+  c.zstd = h;
+  return XSG_OK;
+}
+
+static int decompress_chunk(int32_t type, const uint8_t* src, uint64_t src_n, uint8_t* dst, uint64_t dst_n) {
+  if (type == XSG_COMPRESSION_LZ4) {
+    // raw LZ4 block per chunk, decoded to exactly original_size bytes
+    if (src_n > INT32_MAX || dst_n > INT32_MAX) return fail(XSG_EIO, "LZ4 chunk too large");
+    const int r = codecs().LZ4_decompress_safe((const char*)src, (char*)dst, (int)src_n, (int)dst_n);
+    if (r < 0 || (uint64_t)r != dst_n) return fail(XSG_EIO, "LZ4 chunk does not decode to its recorded size");
+    return XSG_OK;
+  }
+  if (type == XSG_COMPRESSION_ZSTD) {
+    const size_t r = codecs().ZSTD_decompress(dst, dst_n, src, src_n);
+    if (codecs().ZSTD_isError(r) || r != dst_n) return fail(XSG_EIO, "ZSTD chunk does not decode to its recorded size");
+    return XSG_OK;
+  }
+  return fail(XSG_EINVAL, "bad compression type %d", type);
+}
+
+// ---------------------------------------------------------------------------
+// metafile writer / preprocessor
+// ---------------------------------------------------------------------------
+extern "C" int xsg_meta_write(const char* file_path, const char* meta_out_path, const char* data_out_path,
+                              int32_t compression, uint64_t chunk_bytes, uint64_t mapping_gap, int hc) {
+  if (!meta_out_path) return fail(XSG_EINVAL, "meta_out_path is null");
+  if (compression != XSG_COMPRESSION_NONE && compression != XSG_COMPRESSION_ZSTD && compression != XSG_COMPRESSION_LZ4)
+    return fail(XSG_EINVAL, "bad compression type %d", compression);
+  if (compression != XSG_COMPRESSION_NONE && !data_out_path) return fail(XSG_EINVAL, "data_out_path is null");
+  if (compression == XSG_COMPRESSION_LZ4) XSG_TRY(need_lz4());
+  if (compression == XSG_COMPRESSION_ZSTD) XSG_TRY(need_zstd());
+  if (!chunk_bytes) chunk_bytes = 16u << 20;
+  if (!mapping_gap) mapping_gap = 500;
+  int fd;
+  uint64_t size;
+  XSG_TRY(open_ro(file_path, &fd, &size));
+  std::vector<xsg_file_chunk> plan;
+  int r = plan_plain(fd, size, chunk_bytes, plan);
+  if (r != XSG_OK) {
+    close(fd);
+    return r;
+  }
+  FILE* mf = fopen(meta_out_path, "wb");
+  FILE* df = compression != XSG_COMPRESSION_NONE ? fopen(data_out_path, "wb") : nullptr;
+  if (!mf || (compression != XSG_COMPRESSION_NONE && !df)) {
+    if (mf) fclose(mf);
+    if (df) fclose(df);
+    close(fd);
+    return fail(XSG_EIO, "cannot create output files: %s", strerror(errno));
+  }
+  fwrite(&compression, 4, 1, mf);
+  std::vector<uint8_t> raw, packed;
+  std::vector<uint64_t> maps;
+  uint64_t line = 0, actual_off = 0;
+  for (const xsg_file_chunk& pc : plan) {
+    raw.resize(pc.original_size);
+    r = pread_full(fd, raw.data(), pc.original_size, pc.original_offset);
+    if (r != XSG_OK) break;
+    // mapping: the chunk start, then the first line start >= previous entry + gap
+    maps.clear();
+    maps.push_back(pc.original_offset);
+    maps.push_back(line);
+    uint64_t last_entry = 0;
+    for (uint64_t i = 0; i < pc.original_size; ++i) {
+      if (raw[i] == '\n') {
+        ++line;
+        const uint64_t ls = i + 1;
+        if (ls < pc.original_size && ls >= last_entry + mapping_gap) {
+          maps.push_back(pc.original_offset + ls);
+          maps.push_back(line);
+          last_entry = ls;
+        }
+      }
+    }
+    uint64_t actual_size = pc.original_size;
+    if (compression == XSG_COMPRESSION_LZ4) {
+      if (pc.original_size > INT32_MAX) {
+        r = fail(XSG_EINVAL, "chunk too large for an LZ4 block");
+        break;
+      }
+      packed.resize((size_t)codecs().LZ4_compressBound((int)pc.original_size));
+      const int n = hc && codecs().LZ4_compress_HC
+                        ? codecs().LZ4_compress_HC((const char*)raw.data(), (char*)packed.data(), (int)raw.size(),
+                                                   (int)packed.size(), 9)
+                        : codecs().LZ4_compress_default((const char*)raw.data(), (char*)packed.data(), (int)raw.size(),
+                                                        (int)packed.size());
+      if (n <= 0 && pc.original_size) {
+        r = fail(XSG_EIO, "LZ4 compression failed");
+        break;
+      }
+      actual_size = (uint64_t)n;
+    } else if (compression == XSG_COMPRESSION_ZSTD) {
+      packed.resize(codecs().ZSTD_compressBound(raw.size()));
+      const size_t n = codecs().ZSTD_compress(packed.data(), packed.size(), raw.data(), raw.size(), 3);
+      if (codecs().ZSTD_isError(n)) {
+        r = fail(XSG_EIO, "ZSTD compression failed");
+        break;
+      }
+      actual_size = n;
+    }
+    if (df && actual_size && fwrite(packed.data(), 1, actual_size, df) != actual_size) {
+      r = fail(XSG_EIO, "short write to '%s'", data_out_path);
+      break;
+    }
+    const uint64_t rec[5] = {pc.original_offset, compression == XSG_COMPRESSION_NONE ? pc.original_offset : actual_off,
+                             pc.original_size, actual_size, maps.size() / 2};
+    fwrite(rec, 8, 5, mf);
+    fwrite(maps.data(), 8, maps.size(), mf);
+    actual_off += actual_size;
+  }
+  if (fclose(mf) != 0 && r == XSG_OK) r = fail(XSG_EIO, "cannot write '%s'", meta_out_path);
+  if (df && fclose(df) != 0 && r == XSG_OK) r = fail(XSG_EIO, "cannot write '%s'", data_out_path);
+  close(fd);
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// the job
+// ---------------------------------------------------------------------------
+struct Partial {
+  uint64_t count = 0;     // count tags
+  uint64_t newlines = 0;  // line indices without metafile bases
+  bool indices_local = false;
+  std::vector<uint64_t> u64;
+  std::vector<std::string> lines;
+};
+
+struct xsg_job {
+  xsg_job_opts opts{};
+  std::vector<uint8_t> pattern;
+  int fd = -1;
+  int32_t compression = XSG_COMPRESSION_NONE;
+  std::vector<xsg_file_chunk> plan;
+  uint64_t max_orig = 0, max_actual = 0;
+
+  std::vector<std::thread> threads;
+  std::atomic<uint64_t> next_chunk{0};
+  std::atomic<bool> stop{false};
+  std::atomic<int> active{0};
+
+  // bounded read concurrency (Searcher.h:39,106 num_concurrent_reads)
+  std::mutex rd_mu;
+  std::condition_variable rd_cv;
+  int rd_free = 1;
+
+  // ordered result store
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<uint64_t, Partial> pending;
+  uint64_t next_publish = 0;
+  std::vector<uint64_t> values;   // count tags: running totals; u64 tags: elements
+  std::deque<std::string> lines;  // XSG_LINES
+  uint64_t total = 0;             // count so far / elements so far
+  uint64_t nl_running = 0;        // '\n' in all published chunks
+  bool finished = false;
+  int error = XSG_OK;
+  std::string errmsg;
+
+  Clock::time_point t_start;
+  xsg_job_stats stats{};
+  bool joined = false;
+};
+
+static void job_fail(xsg_job* j, int code) {
+  std::lock_guard<std::mutex> g(j->mu);
+  if (j->error == XSG_OK) {
+    j->error = code;
+    j->errmsg = last_error_message();
+  }
+  j->stop.store(true);
+}
+
+static void publish(xsg_job* j, uint64_t index, Partial&& p) {
+  std::lock_guard<std::mutex> g(j->mu);
+  j->pending.emplace(index, std::move(p));
+  const uint32_t mode = j->opts.mode;
+  for (auto it = j->pending.find(j->next_publish); it != j->pending.end(); it = j->pending.find(j->next_publish)) {
+    Partial& q = it->second;
+    if (mode == XSG_COUNT_MATCHES || mode == XSG_COUNT_LINES) {
+      j->total += q.count;
+      j->values.push_back(j->total);
+    } else if (mode == XSG_LINES) {
+      for (std::string& s : q.lines) j->lines.push_back(std::move(s));
+      j->total = j->lines.size();
+    } else {
+      if (q.indices_local)
+        for (uint64_t& v : q.u64) v += j->nl_running;
+      j->values.insert(j->values.end(), q.u64.begin(), q.u64.end());
+      j->total = j->values.size();
+    }
+    j->nl_running += q.newlines;
+    j->pending.erase(it);
+    ++j->next_publish;
+  }
+  j->cv.notify_all();
+}
+
+struct Slot {
+  xsg_ctx* ctx = nullptr;
+  xsg_shard* shard = nullptr;
+  void* host = nullptr;  // pinned
+  void* dev = nullptr;
+  uint64_t cap = 0;
+  std::vector<uint8_t> staging;  // compressed bytes
+  ~Slot() {
+    if (shard) xsg_shard_destroy(shard);
+    if (host) (void)hipHostFree(host);
+    if (dev) (void)hipFree(dev);
+    if (ctx) xsg_ctx_destroy(ctx);
+  }
+};
+
+static int slot_init(xsg_job* j, Slot& s) {
+  XSG_TRY(xsg_ctx_create(j->opts.device, &s.ctx));
+  XSG_TRY(xsg_set_pattern(s.ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
+  s.cap = ((j->max_orig + 15u) & ~(uint64_t)15u) + 256u;
+  HIP_TRY(hipHostMalloc(&s.host, s.cap, hipHostMallocDefault));
+  HIP_TRY(hipMalloc(&s.dev, s.cap));
+  XSG_TRY(xsg_shard_create(s.ctx, s.dev, s.cap, nullptr, 0, &s.shard));
+  if (j->compression != XSG_COMPRESSION_NONE) s.staging.resize(j->max_actual);
+  return XSG_OK;
+}
+
+static int process_chunk(xsg_job* j, Slot& s, uint64_t index, double* t_read, double* t_dec, double* t_dev) {
+  const xsg_file_chunk& fc = j->plan[index];
+  const uint32_t mode = j->opts.mode;
+  // ---- read (bounded concurrency)
+  {
+    std::unique_lock<std::mutex> lk(j->rd_mu);
+    j->rd_cv.wait(lk, [&] { return j->rd_free > 0; });
+    --j->rd_free;
+  }
+  auto t0 = Clock::now();
+  int r = XSG_OK;
+  if (fc.actual_size) {
+    void* dst = j->compression == XSG_COMPRESSION_NONE ? s.host : (void*)s.staging.data();
+    r = pread_full(j->fd, dst, fc.actual_size, fc.actual_offset);
+  }
+  *t_read += seconds_since(t0);
+  {
+    std::lock_guard<std::mutex> lk(j->rd_mu);
+    ++j->rd_free;
+  }
+  j->rd_cv.notify_one();
+  XSG_TRY(r);
+  if (j->compression != XSG_COMPRESSION_NONE && fc.original_size) {
+    t0 = Clock::now();
+    XSG_TRY(decompress_chunk(j->compression, s.staging.data(), fc.actual_size, static_cast<uint8_t*>(s.host),
+                             fc.original_size));
+    *t_dec += seconds_since(t0);
+  }
+  // ---- device
+  t0 = Clock::now();
+  if (fc.original_size)
+    HIP_TRY(hipMemcpyAsync(s.dev, s.host, fc.original_size, hipMemcpyHostToDevice, s.ctx->stream));
+  xsg_chunk ch{};
+  ch.offset = 0;
+  ch.length = fc.original_size;
+  ch.global_offset = fc.original_offset;
+  ch.line_base = fc.first_line;  // from the metafile, or AUTO (then local indices + running base at publish)
+  XSG_TRY(xsg_shard_rebind(s.shard, s.dev, s.cap, &ch, 1));
+  Partial p;
+  if (mode == XSG_COUNT_MATCHES || mode == XSG_COUNT_LINES) {
+    uint64_t ctr[XSG_NUM_COUNTERS];
+    XSG_TRY(xsg_count(s.shard, mode, ctr));
+    p.count = ctr[mode == XSG_COUNT_MATCHES ? XSG_CTR_MATCHES : XSG_CTR_LINES];
+  } else if (mode == XSG_LINES) {
+    uint64_t n = 0, nl = 0, nb = 0;
+    XSG_TRY(xsg_search(s.shard, mode, &n));
+    XSG_TRY(xsg_result_lines_size(s.shard, &nl, &nb));
+    std::vector<uint64_t> lens(nl);
+    std::vector<char> bytes(nb ? nb : 1);
+    XSG_TRY(xsg_result_lines(s.shard, lens.data(), bytes.data(), nb, nullptr));
+    p.lines.reserve(nl);
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < nl; ++i) {
+      p.lines.emplace_back(bytes.data() + at, lens[i]);
+      at += lens[i];
+    }
+  } else {
+    uint64_t n = 0;
+    XSG_TRY(xsg_search(s.shard, mode, &n));
+    p.u64.resize(n);
+    XSG_TRY(xsg_result_u64(s.shard, p.u64.data(), n));
+    if (mode == XSG_LINE_INDICES && fc.first_line == XSG_LINE_BASE_AUTO) {
+      p.indices_local = true;
+      XSG_TRY(xsg_result_newlines(s.shard, &p.newlines));
+    }
+  }
+  *t_dev += seconds_since(t0);
+  publish(j, index, std::move(p));
+  return XSG_OK;
+}
+
+static void worker_main(xsg_job* j) {
+  double t_read = 0, t_dec = 0, t_dev = 0;
+  uint64_t bytes = 0, rbytes = 0, chunks = 0;
+  {
+    Slot s;
+    int r = slot_init(j, s);
+    if (r != XSG_OK) {
+      job_fail(j, r);
+    } else {
+      while (!j->stop.load()) {
+        const uint64_t i = j->next_chunk.fetch_add(1);
+        if (i >= j->plan.size()) break;
+        r = process_chunk(j, s, i, &t_read, &t_dec, &t_dev);
+        if (r != XSG_OK) {
+          job_fail(j, r);
+          break;
+        }
+        bytes += j->plan[i].original_size;
+        rbytes += j->plan[i].actual_size;
+        ++chunks;
+      }
+    }
+  }
+  std::lock_guard<std::mutex> g(j->mu);
+  j->stats.bytes_scanned += bytes;
+  j->stats.bytes_read += rbytes;
+  j->stats.chunks += chunks;
+  j->stats.seconds_read += t_read;
+  j->stats.seconds_decompress += t_dec;
+  j->stats.seconds_device += t_dev;
+  if (--j->active == 0) {  // the last worker closes the result (Searcher.h:116-119)
+    j->finished = true;
+    j->stats.seconds_total = seconds_since(j->t_start);
+    j->cv.notify_all();
+  }
+}
+
+extern "C" void xsg_job_opts_init(xsg_job_opts* o) {
+  if (!o) return;
+  memset(o, 0, sizeof *o);
+  o->struct_size = sizeof *o;
+  o->mode = XSG_COUNT_MATCHES;
+  o->device = 0;
+  o->num_threads = 1;
+  o->num_max_readers = 1;
+  o->chunk_bytes = 16u << 20;
+}
+
+extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_path, const char* meta_file_path,
+                             const xsg_job_opts* opts, xsg_job** out) {
+  if (!out) return fail(XSG_EINVAL, "out is null");
+  *out = nullptr;
+  if (!opts || opts->struct_size != sizeof(xsg_job_opts)) return fail(XSG_EINVAL, "bad xsg_job_opts (struct_size)");
+  if (!pattern || plen == 0 || plen > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "pattern must be 1..%u bytes",
+                                                                  XSG_MAX_PATTERN);
+  if (opts->mode > XSG_LINES) return fail(XSG_EINVAL, "bad mode %u", opts->mode);
+  if (opts->num_threads < 1 || opts->num_max_readers < 1) return fail(XSG_EINVAL, "num_threads/num_max_readers < 1");
+  if (opts->mode != XSG_COUNT_MATCHES && opts->mode != XSG_MATCH_BYTE_OFFSETS &&
+      memchr(pattern, '\n', plen) != nullptr)
+    return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+  // fail early and loudly without a device: there is no CPU search path
+  int ndev = 0;
+  XSG_TRY(xsg_device_count(&ndev));
+  if (opts->device < 0 || opts->device >= ndev) return fail(XSG_ENODEV, "device %d out of range", opts->device);
+
+  std::unique_ptr<xsg_job> j(new (std::nothrow) xsg_job());
+  if (!j) return fail(XSG_ENOMEM, "host allocation failed");
+  j->opts = *opts;
+  if (!j->opts.chunk_bytes) j->opts.chunk_bytes = 16u << 20;
+  j->pattern.assign((const uint8_t*)pattern, (const uint8_t*)pattern + plen);
+  uint64_t fsize = 0;
+  XSG_TRY(open_ro(file_path, &j->fd, &fsize));
+  int r = XSG_OK;
+  if (meta_file_path && *meta_file_path) {
+    r = read_meta(meta_file_path, &j->compression, j->plan, nullptr);
+    if (r == XSG_OK) {
+      for (const xsg_file_chunk& c : j->plan)
+        if (c.actual_offset + c.actual_size > fsize) {
+          r = fail(XSG_EIO, "metafile '%s' describes bytes beyond the end of '%s'", meta_file_path, file_path);
+          break;
+        }
+    }
+    if (r == XSG_OK && j->compression == XSG_COMPRESSION_LZ4) r = need_lz4();
+    if (r == XSG_OK && j->compression == XSG_COMPRESSION_ZSTD) r = need_zstd();
+  } else {
+    r = plan_plain(j->fd, fsize, j->opts.chunk_bytes, j->plan);
+  }
+  if (r != XSG_OK) {
+    close(j->fd);
+    return r;
+  }
+  for (const xsg_file_chunk& c : j->plan) {
+    j->max_orig = std::max(j->max_orig, c.original_size);
+    j->max_actual = std::max(j->max_actual, c.actual_size);
+  }
+  j->rd_free = opts->num_max_readers;
+  j->t_start = Clock::now();
+  const int nthreads = (int)std::min<uint64_t>((uint64_t)opts->num_threads, std::max<uint64_t>(j->plan.size(), 1));
+  j->active = nthreads;
+  xsg_job* raw = j.release();
+  for (int t = 0; t < nthreads; ++t) raw->threads.emplace_back(worker_main, raw);
+  *out = raw;
+  return XSG_OK;
+}
+
+extern "C" int xsg_job_join(xsg_job* j) {
+  if (!j) return fail(XSG_EINVAL, "job is null");
+  for (std::thread& t : j->threads)
+    if (t.joinable()) t.join();
+  j->joined = true;
+  std::lock_guard<std::mutex> g(j->mu);
+  if (j->error != XSG_OK) return fail(j->error, "%s", j->errmsg.c_str());
+  return XSG_OK;
+}
+
+extern "C" void xsg_job_destroy(xsg_job* j) {
+  if (!j) return;
+  j->stop.store(true);
+  for (std::thread& t : j->threads)
+    if (t.joinable()) t.join();
+  if (j->fd >= 0) close(j->fd);
+  delete j;
+}
+
+extern "C" int xsg_job_total(xsg_job* j, uint64_t* total) {
+  if (!j || !total) return fail(XSG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(j->mu);
+  *total = j->total;
+  return XSG_OK;
+}
+
+extern "C" int xsg_job_wait(xsg_job* j, uint64_t index, uint64_t* available, int* finished) {
+  if (!j) return fail(XSG_EINVAL, "job is null");
+  std::unique_lock<std::mutex> lk(j->mu);
+  const bool is_lines = j->opts.mode == XSG_LINES;
+  auto avail = [&] { return is_lines ? (uint64_t)j->lines.size() : (uint64_t)j->values.size(); };
+  j->cv.wait(lk, [&] { return avail() > index || j->finished; });
+  if (available) *available = avail();
+  if (finished) *finished = j->finished ? 1 : 0;
+  if (j->finished && j->error != XSG_OK && avail() <= index) return fail(j->error, "%s", j->errmsg.c_str());
+  return XSG_OK;
+}
+
+extern "C" int xsg_job_poll(xsg_job* j, uint64_t* available, int* finished) {
+  if (!j) return fail(XSG_EINVAL, "job is null");
+  std::lock_guard<std::mutex> g(j->mu);
+  if (available) *available = j->opts.mode == XSG_LINES ? (uint64_t)j->lines.size() : (uint64_t)j->values.size();
+  if (finished) *finished = j->finished ? 1 : 0;
+  return XSG_OK;
+}
+
+extern "C" int xsg_job_get_u64(xsg_job* j, uint64_t first, uint64_t n, uint64_t* out) {
+  if (!j || (!out && n)) return fail(XSG_EINVAL, "null argument");
+  if (j->opts.mode == XSG_LINES) return fail(XSG_ESTATE, "XSG_LINES results are strings: use xsg_job_get_line");
+  std::lock_guard<std::mutex> g(j->mu);
+  if (first + n > j->values.size()) return fail(XSG_EINVAL, "range beyond the available results");
+  if (n) memcpy(out, j->values.data() + first, 8 * n);
+  return XSG_OK;
+}
+
+extern "C" int xsg_job_get_line(xsg_job* j, uint64_t index, const char** data, uint64_t* len) {
+  if (!j || !data || !len) return fail(XSG_EINVAL, "null argument");
+  if (j->opts.mode != XSG_LINES) return fail(XSG_ESTATE, "not an XSG_LINES job");
+  std::lock_guard<std::mutex> g(j->mu);
+  if (index >= j->lines.size()) return fail(XSG_EINVAL, "index beyond the available results");
+  const std::string& s = j->lines[index];  // deque: references stay valid while the job lives
+  *data = s.data();
+  *len = s.size();
+  return XSG_OK;
+}
+
+extern "C" int xsg_job_stats_get(xsg_job* j, xsg_job_stats* stats) {
+  if (!j || !stats) return fail(XSG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(j->mu);
+  *stats = j->stats;
+  if (!j->finished) stats->seconds_total = seconds_since(j->t_start);
+  return XSG_OK;
+}

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -31,6 +32,22 @@ CHUNK_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u8"), ("global_offset", 
 
 _u64p = C.POINTER(C.c_uint64)
 
+FILE_CHUNK_DTYPE = np.dtype([("original_offset", "<u8"), ("actual_offset", "<u8"), ("original_size", "<u8"),
+                             ("actual_size", "<u8"), ("first_line", "<u8"), ("n_mappings", "<u8")])
+COMPRESSION_NONE, COMPRESSION_ZSTD, COMPRESSION_LZ4 = 1, 2, 3
+
+
+class JobOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_uint32), ("pattern_flags", C.c_uint32),
+                ("device", C.c_int32), ("num_threads", C.c_int32), ("num_max_readers", C.c_int32),
+                ("chunk_bytes", C.c_uint64)]
+
+
+class JobStats(C.Structure):
+    _fields_ = [("bytes_scanned", C.c_uint64), ("bytes_read", C.c_uint64), ("chunks", C.c_uint64),
+                ("seconds_total", C.c_double), ("seconds_read", C.c_double), ("seconds_decompress", C.c_double),
+                ("seconds_device", C.c_double)]
+
 
 class XsgError(RuntimeError):
     def __init__(self, code, msg):
@@ -51,6 +68,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 /
+    # libhsa-runtime64 and a second HSA runtime in the same process sees no GPU.
+    # libxsg.so only NEEDs the SONAME libamdhip64.so.7, so when torch is loaded
+    # first the dynamic loader binds libxsg to torch's copy and both share it.
+    # (A process without torch simply gets /opt/rocm's runtime.)
+    if "torch" not in sys.modules and not os.environ.get("XSG_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     p = lib_path()
     if not p.exists():
         raise FileNotFoundError(f"{p} not found: build it with `make -C x-search_amd` (or __graft_entry__.build())")
@@ -74,6 +101,21 @@ def load():
         "xsg_result_u64": (ci, [vp, _u64p, u64]),
         "xsg_result_lines_size": (ci, [vp, _u64p, _u64p]),
         "xsg_result_lines": (ci, [vp, _u64p, vp, u64, _u64p]),
+        "xsg_result_newlines": (ci, [vp, _u64p]),
+        "xsg_job_opts_init": (None, [C.POINTER(JobOpts)]),
+        "xsg_job_start": (ci, [C.c_char_p, sz, C.c_char_p, C.c_char_p, C.POINTER(JobOpts), C.POINTER(vp)]),
+        "xsg_job_join": (ci, [vp]),
+        "xsg_job_destroy": (None, [vp]),
+        "xsg_job_total": (ci, [vp, _u64p]),
+        "xsg_job_wait": (ci, [vp, u64, _u64p, C.POINTER(ci)]),
+        "xsg_job_poll": (ci, [vp, _u64p, C.POINTER(ci)]),
+        "xsg_job_get_u64": (ci, [vp, u64, u64, _u64p]),
+        "xsg_job_get_line": (ci, [vp, u64, C.POINTER(C.c_char_p), _u64p]),
+        "xsg_job_stats_get": (ci, [vp, C.POINTER(JobStats)]),
+        "xsg_plan_chunks": (ci, [C.c_char_p, u64, C.POINTER(vp), _u64p]),
+        "xsg_meta_read": (ci, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(vp), _u64p, C.POINTER(vp), _u64p]),
+        "xsg_meta_write": (ci, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, u64, u64, ci]),
+        "xsg_free": (None, [vp]),
         "xsg_ctx_info": (ci, [vp, C.c_char_p, sz, C.POINTER(ci), _u64p]),
         "xsg_time_scan_kernel": (ci, [vp, u32, ci, C.POINTER(C.c_float)]),
     }
@@ -88,7 +130,10 @@ def load():
 EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_count", "xsg_ctx_create",
            "xsg_ctx_destroy", "xsg_set_pattern", "xsg_shard_create", "xsg_shard_rebind", "xsg_shard_destroy",
            "xsg_shard_set_line_base", "xsg_count_async", "xsg_count", "xsg_search", "xsg_result_u64",
-           "xsg_result_lines_size", "xsg_result_lines", "xsg_ctx_info", "xsg_time_scan_kernel"]
+           "xsg_result_lines_size", "xsg_result_lines", "xsg_ctx_info", "xsg_time_scan_kernel", "xsg_result_newlines",
+           "xsg_job_opts_init", "xsg_job_start", "xsg_job_join", "xsg_job_destroy", "xsg_job_total", "xsg_job_wait", "xsg_job_poll",
+           "xsg_job_get_u64", "xsg_job_get_line", "xsg_job_stats_get", "xsg_plan_chunks", "xsg_meta_read",
+           "xsg_meta_write", "xsg_free"]
 
 
 def _check(rc):
@@ -215,3 +260,113 @@ class Shard:
         ms = C.c_float(0)
         _check(self._lib.xsg_time_scan_kernel(self.h, mode, iters, C.byref(ms)))
         return ms.value
+
+
+# ---------------------------------------------------------------------------
+# host-only helpers (no GPU needed): chunk plans and metafiles
+# ---------------------------------------------------------------------------
+def _take_chunks(ptr, n):
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(max(n, 1) * 6,))[:n * 6].copy()
+    load().xsg_free(ptr)
+    return arr.view(FILE_CHUNK_DTYPE)
+
+
+def plan_chunks(path: str, target_bytes: int = 16 << 20) -> np.ndarray:
+    ptr, n = C.c_void_p(), C.c_uint64(0)
+    _check(load().xsg_plan_chunks(os.fsencode(path), target_bytes, C.byref(ptr), C.byref(n)))
+    return _take_chunks(ptr, n.value)
+
+
+def meta_read(path: str, with_mappings: bool = False):
+    lib = load()
+    comp, ptr, n = C.c_int32(0), C.c_void_p(), C.c_uint64(0)
+    mp, nm = C.c_void_p(), C.c_uint64(0)
+    _check(lib.xsg_meta_read(os.fsencode(path), C.byref(comp), C.byref(ptr), C.byref(n),
+                             C.byref(mp) if with_mappings else None, C.byref(nm) if with_mappings else None))
+    chunks = _take_chunks(ptr, n.value)
+    if not with_mappings:
+        return comp.value, chunks
+    maps = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint64)), shape=(max(nm.value, 1) * 2,))[:nm.value * 2].copy()
+    lib.xsg_free(mp)
+    return comp.value, chunks, maps.reshape(-1, 2)
+
+
+def meta_write(path: str, meta_out: str, data_out: str | None = None, compression: int = COMPRESSION_NONE,
+               chunk_bytes: int = 16 << 20, mapping_gap: int = 500, hc: bool = False):
+    _check(load().xsg_meta_write(os.fsencode(path), os.fsencode(meta_out), os.fsencode(data_out) if data_out else None,
+                                 compression, chunk_bytes, mapping_gap, 1 if hc else 0))
+
+
+class Job:
+    """A file search (what xs::extern_search returns a handle to)."""
+
+    def __init__(self, pattern: bytes, path: str, mode: int, meta_path: str | None = None, device: int = 0,
+                 num_threads: int = 1, num_max_readers: int = 1, chunk_bytes: int = 16 << 20, flags: int = 0):
+        self._lib = load()
+        o = JobOpts()
+        self._lib.xsg_job_opts_init(C.byref(o))
+        o.mode, o.pattern_flags, o.device = mode, flags, device
+        o.num_threads, o.num_max_readers, o.chunk_bytes = num_threads, num_max_readers, chunk_bytes
+        h = C.c_void_p()
+        _check(self._lib.xsg_job_start(pattern, len(pattern), os.fsencode(path),
+                                       os.fsencode(meta_path) if meta_path else None, C.byref(o), C.byref(h)))
+        self.h = h
+        self.mode = mode
+
+    def join(self):
+        _check(self._lib.xsg_job_join(self.h))
+
+    def close(self):
+        if self.h:
+            self._lib.xsg_job_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def total(self) -> int:
+        t = C.c_uint64(0)
+        _check(self._lib.xsg_job_total(self.h, C.byref(t)))
+        return t.value
+
+    def __iter__(self):
+        """Live iteration: blocks until the next element exists or the job is done."""
+        i = 0
+        while True:
+            avail, fin = C.c_uint64(0), C.c_int(0)
+            _check(self._lib.xsg_job_wait(self.h, i, C.byref(avail), C.byref(fin)))
+            if avail.value <= i:
+                return
+            while i < avail.value:
+                yield self._get(i)
+                i += 1
+
+    def _get(self, i):
+        if self.mode == LINES:
+            p, n = C.c_char_p(), C.c_uint64(0)
+            _check(self._lib.xsg_job_get_line(self.h, i, C.byref(p), C.byref(n)))
+            return C.string_at(p, n.value)
+        v = C.c_uint64(0)
+        _check(self._lib.xsg_job_get_u64(self.h, i, 1, C.byref(v)))
+        return v.value
+
+    def result(self):
+        """join + copy everything (copyResultSafe)."""
+        self.join()
+        if self.mode in (COUNT_MATCHES, COUNT_LINES):
+            return self.total()
+        n = self.total()
+        if self.mode == LINES:
+            return [self._get(i) for i in range(n)]
+        out = np.empty(n, dtype=np.uint64)
+        if n:
+            _check(self._lib.xsg_job_get_u64(self.h, 0, n, out.ctypes.data_as(_u64p)))
+        return out
+
+    def stats(self) -> dict:
+        st = JobStats()
+        _check(self._lib.xsg_job_stats_get(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in JobStats._fields_}
