@@ -253,6 +253,9 @@ int xsg_ctx_info(xsg_ctx* ctx, char* arch, size_t arch_cap, int* compute_units, 
  * mode `iters` times back to back on the ctx stream between two HIP events and
  * returns the average milliseconds per launch (bench.py's roofline figure). */
 int xsg_time_scan_kernel(xsg_shard* shard, uint32_t mode, int iters, float* avg_ms);
+/* Diagnostic: a kernel with k_scan's load shape and no work on the bytes, over the
+ * shard's span -- the empirical HBM read ceiling for this access pattern. */
+int xsg_time_read_ceiling(xsg_shard* shard, int iters, float* avg_ms, uint64_t* bytes_per_launch);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,10 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
     delete c;
     return fail(XSG_ENODEV, "device %d is %s; this library carries gfx950 (MI355X) code only", device, a.c_str());
   }
+  if (const char* tk = getenv("XSG_TILE_KIB")) {
+    const int v = atoi(tk);
+    if (v == 16 || v == 32) c->tile_bytes = (uint32_t)v * 1024u;
+  }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -154,6 +158,10 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   P.m0 = mask32(plen);
   P.p1 = plen > 4 ? le32(p + 4, plen - 4) : 0u;
   P.m1 = plen > 4 ? mask32(plen - 4) : 0u;
+  P.p2 = plen > 8 ? le32(p + 8, plen - 8) : 0u;
+  P.m2 = plen > 8 ? mask32(plen - 8) : 0u;
+  P.p3 = plen > 12 ? le32(p + 12, plen - 12) : 0u;
+  P.m3 = plen > 12 ? mask32(plen - 12) : 0u;
   P.kind = plen < 4 ? kMask1 : plen == 4 ? kOne : plen < 8 ? kMask2 : plen == 8 ? kTwo : kLong;
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;
@@ -171,6 +179,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   if (((uintptr_t)d_base & 15u) != 0) return fail(XSG_EINVAL, "d_base is not 16-byte aligned");
   if (nchunks >= (1ull << 32)) return fail(XSG_EINVAL, "too many chunks");
   uint64_t prev_end = 0, ntiles = 0, total = 0;
+  const uint32_t tile_bytes = c->tile_bytes;
   std::vector<uint64_t> tile0(nchunks + 1, 0);
   for (uint64_t i = 0; i < nchunks; ++i) {
     const xsg_chunk& k = chunks[i];
@@ -185,7 +194,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
                   (unsigned long long)i);
     prev_end = k.offset + k.length;
     tile0[i] = ntiles;
-    ntiles += (k.length + kTile - 1) / kTile;
+    ntiles += (k.length + tile_bytes - 1) / tile_bytes;
     total += k.length;
   }
   tile0[nchunks] = ntiles;
@@ -196,6 +205,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   s->chunks.assign(chunks, chunks + nchunks);
   s->chunk_tile0 = std::move(tile0);
   s->ntiles = ntiles;
+  s->tile_bytes = tile_bytes;
   s->total_bytes = total;
   s->last_mode = -1;
   s->total = 0;
@@ -272,6 +282,7 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.tile_chunk = s->chunks.size() > 1 ? s->d_tile_chunk.as<uint32_t>() : nullptr;
   a.chunk_tile0 = s->d_chunk_tile0.as<uint64_t>();
   a.ntiles = s->ntiles;
+  a.tile_bytes = s->tile_bytes;
   a.pat = s->ctx->pat;
   a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
   a.tile_nl = s->d_tile_nl.as<uint32_t>();
@@ -394,6 +405,45 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   return XSG_OK;
 }
 
+static int time_read(xsg_shard* s, uint32_t tile_bytes, int variant, int iters, float* avg_ms,
+                     uint64_t* bytes_per_launch) {
+  if (!s || !avg_ms || iters <= 0) return fail(XSG_EINVAL, "bad argument");
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  // the span from the first to the last chunk, whole tiles only (padding between chunks is read too)
+  if (s->chunks.empty()) return fail(XSG_ESTATE, "empty shard");
+  const uint64_t lo = s->chunks.front().offset;
+  const uint64_t hi = s->chunks.back().offset + s->chunks.back().length;
+  const uint64_t bytes = ((hi - lo) / tile_bytes) * tile_bytes;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  uint32_t* sink = s->d_counters.as<uint32_t>();
+  HIP_TRY(launch_read_ceiling(s->base + lo, bytes, tile_bytes, variant, sink, c->stream));
+  HIP_TRY(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch_read_ceiling(s->base + lo, bytes, tile_bytes, variant, sink, c->stream));
+  HIP_TRY(hipEventRecord(e1, c->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / (float)iters;
+  if (bytes_per_launch) *bytes_per_launch = bytes;
+  return XSG_OK;
+}
+
+extern "C" int xsg_time_read_ceiling(xsg_shard* s, int iters, float* avg_ms, uint64_t* bytes_per_launch) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  return time_read(s, s->tile_bytes, 0, iters, avg_ms, bytes_per_launch);
+}
+
+// not in xsg.h: access-pattern experiments for scripts/perf_sweep.py
+extern "C" int xsg_diag_read_variant(xsg_shard* s, uint32_t tile_bytes, int variant, int iters, float* avg_ms,
+                                     uint64_t* bytes_per_launch) {
+  return time_read(s, tile_bytes, variant, iters, avg_ms, bytes_per_launch);
+}
+
 // ---------------------------------------------------------------------------
 // list searches
 // ---------------------------------------------------------------------------
@@ -514,6 +564,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   o.f_chunk = l.f_chunk;
   o.out_u64 = s->d_out_u64.as<uint64_t>();
   o.shard_line_base = s->shard_line_base;
+  o.tile_bytes = s->tile_bytes;
 
   if (mode == XSG_MATCH_BYTE_OFFSETS || mode == XSG_LINE_BYTE_OFFSETS) {
     HIP_TRY(launch_globalize(o, st));

@@ -15,11 +15,11 @@ namespace xsg {
 // kLoads KiB and the tile is the 4 spans back to back.
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kLoads = 4;
 constexpr uint32_t kUnit = 16;
 constexpr uint32_t kWaveLoad = 64 * kUnit;
-constexpr uint32_t kWaveSpan = kWaveLoad * kLoads;
-constexpr uint32_t kTile = kWaveSpan * kWaves;
+// kLoads (units per lane) is a template parameter of k_scan: the tile is
+// kLoads KiB per wave x 4 waves = 16 KiB (kLoads 4) or 32 KiB (kLoads 8).
+constexpr uint32_t kDefaultTileBytes = 16384;
 
 // Same layout as xsg_chunk (include/xsg.h).
 struct ChunkDev {
@@ -36,13 +36,14 @@ enum FilterKind : int {
   kOne = 1,    // plen 4    : one dword compare
   kMask2 = 2,  // plen 5..7 : one dword + one masked dword
   kTwo = 3,    // plen 8    : two dword compares (exact)
-  kLong = 4    // plen > 8  : two dword compares + byte verify of the rest
+  kLong = 4    // plen > 8  : two dword compares, then bytes 8..15 in registers, then memory for the rest
 };
 
 struct PatternDev {
   uint32_t plen;
   uint32_t kind;
   uint32_t p0, m0, p1, m1;  // first 8 pattern bytes as little-endian dwords and their byte masks
+  uint32_t p2, m2, p3, m3;  // bytes 8..15 (kLong: checked in registers before any memory compare)
   const uint8_t* d_pat;     // device copy of the pattern
   uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL
   uint32_t has_newline;     // pattern contains '\n'
@@ -56,6 +57,7 @@ struct ScanArgs {
   const uint32_t* tile_chunk;   // tile -> chunk (null when the shard has one chunk)
   const uint64_t* chunk_tile0;  // first tile of every chunk (nchunks + 1 entries)
   uint64_t ntiles;
+  uint32_t tile_bytes;          // 16384 or 32768 (selects the k_scan instantiation)
   PatternDev pat;
   // outputs of the counting pass
   uint32_t* tile_cnt;                  // matches starting in the tile (o < limit)
@@ -89,6 +91,8 @@ struct FinishArgs {
 hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s);
 hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s);
 hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s);
+hipError_t launch_read_ceiling(const uint8_t* base, uint64_t bytes, uint32_t tile_bytes, int variant, uint32_t* sink,
+                               hipStream_t s);
 
 // exclusive scan: out[i] = sum_{k<i} in[k] for i in [0, n]; out has n+1 entries.
 // tmp must hold scan_tmp_elems(n) uint64 values.
@@ -143,6 +147,7 @@ struct LineOutArgs {
   uint64_t* out_u64;  // global offsets or line indices
   // line indices
   const uint64_t* tile_nl_off;  // exclusive prefix of tile_nl over all tiles of the shard
+  uint32_t tile_bytes;
   uint64_t shard_line_base;
   // lines
   uint64_t* line_len;  // length without '\n'; UINT64_MAX marks "no terminating newline" (dropped)

@@ -24,6 +24,8 @@
 
 namespace xsg {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------
 // cross-lane helpers (wave64)
 // ---------------------------------------------------------------------------
@@ -82,12 +84,12 @@ __device__ __forceinline__ uint32_t nl_flags(uint32_t d) {
   const uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
   return ~t;  // 0x80 in every byte that was '\n'
 }
-__device__ __forceinline__ uint32_t nl_count16(const uint32_t (&d)[6]) {
+__device__ __forceinline__ uint32_t nl_count16(const uint32_t (&d)[8]) {
   return (uint32_t)__popc(nl_flags(d[0])) + (uint32_t)__popc(nl_flags(d[1])) + (uint32_t)__popc(nl_flags(d[2])) +
          (uint32_t)__popc(nl_flags(d[3]));
 }
 // bit b set <=> byte b of the unit is '\n'
-__device__ __forceinline__ uint32_t nl_mask16(const uint32_t (&d)[6]) {
+__device__ __forceinline__ uint32_t nl_mask16(const uint32_t (&d)[8]) {
   uint32_t m = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -97,7 +99,7 @@ __device__ __forceinline__ uint32_t nl_mask16(const uint32_t (&d)[6]) {
   }
   return m;
 }
-__device__ __forceinline__ bool nl_any16(const uint32_t (&d)[6]) {
+__device__ __forceinline__ bool nl_any16(const uint32_t (&d)[8]) {
   uint32_t acc = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -107,10 +109,11 @@ __device__ __forceinline__ bool nl_any16(const uint32_t (&d)[6]) {
   return (acc & 0x80808080u) != 0;
 }
 
-template <int KIND>
-__device__ __forceinline__ void windows(const uint32_t (&d)[6], uint32_t (&w)[20]) {
+// w[b] = the 4 bytes starting at byte b of the lane's 32-byte view (own unit + neighbour's)
+template <int N>
+__device__ __forceinline__ void windows(const uint32_t (&d)[8], uint32_t (&w)[N]) {
 #pragma unroll
-  for (int b = 0; b < 20; ++b) {
+  for (int b = 0; b < N; ++b) {
     const int q = b >> 2, r = b & 3;
     w[b] = r ? __builtin_amdgcn_alignbyte(d[q + 1], d[q], (uint32_t)r) : d[q];
   }
@@ -126,9 +129,9 @@ __device__ __forceinline__ bool cand_at(const uint32_t (&w)[20], int b, const Pa
 
 // true if any of the 16 positions of the unit passes the prefix filter
 template <int KIND>
-__device__ __forceinline__ bool cand_any(const uint32_t (&d)[6], const PatternDev& P) {
+__device__ __forceinline__ bool cand_any(const uint32_t (&d)[8], const PatternDev& P) {
   uint32_t w[20];
-  windows<KIND>(d, w);
+  windows<20>(d, w);
   bool any = false;
 #pragma unroll
   for (int b = 0; b < 16; ++b) any |= cand_at<KIND>(w, b, P);
@@ -136,9 +139,9 @@ __device__ __forceinline__ bool cand_any(const uint32_t (&d)[6], const PatternDe
 }
 
 template <int KIND>
-__device__ __forceinline__ uint32_t cand_mask16(const uint32_t (&d)[6], const PatternDev& P) {
+__device__ __forceinline__ uint32_t cand_mask16(const uint32_t (&d)[8], const PatternDev& P) {
   uint32_t w[20];
-  windows<KIND>(d, w);
+  windows<20>(d, w);
   uint32_t m = 0;
 #pragma unroll
   for (int b = 0; b < 16; ++b) m |= (uint32_t)cand_at<KIND>(w, b, P) << b;
@@ -147,25 +150,38 @@ __device__ __forceinline__ uint32_t cand_mask16(const uint32_t (&d)[6], const Pa
 
 // exact match-start bits of one unit: filter, position limit, long-pattern verify
 template <int KIND>
-__device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[6], const PatternDev& P, const uint8_t* cbase,
+__device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const PatternDev& P, const uint8_t* cbase,
                                                  uint64_t unit_off, uint64_t limit, const uint8_t* lds_pat) {
   uint32_t m = cand_mask16<KIND>(d, P);
   if (unit_off >= limit) return 0;
   if (unit_off + kUnit > limit) m &= (1u << (uint32_t)(limit - unit_off)) - 1u;
   if (KIND == kLong) {
-    uint32_t c = m;
-    while (c) {
-      const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
-      c &= c - 1u;
-      const uint8_t* s = cbase + unit_off + b;
-      bool ok = true;
-      for (uint32_t k = 8; k < P.plen; ++k) {
-        if (s[k] != lds_pat[k]) {
-          ok = false;
-          break;
+    // bytes 8..15 of the pattern, still in registers (d[6], d[7] hold the neighbour's upper half)
+    if (__any(m != 0)) {
+      uint32_t w[28];
+      windows<28>(d, w);
+      uint32_t m2 = 0;
+#pragma unroll
+      for (int b = 0; b < 16; ++b)
+        m2 |= (uint32_t)(((w[b + 8] & P.m2) == P.p2) & ((w[b + 12] & P.m3) == P.p3)) << b;
+      m &= m2;
+    }
+    // beyond 16 bytes: compare the rest from memory (rare: a 16-byte prefix already matched)
+    if (P.plen > 16) {
+      uint32_t c = m;
+      while (c) {
+        const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
+        c &= c - 1u;
+        const uint8_t* s = cbase + unit_off + b;
+        bool ok = true;
+        for (uint32_t k = 16; k < P.plen; ++k) {
+          if (s[k] != lds_pat[k]) {
+            ok = false;
+            break;
+          }
         }
+        if (!ok) m &= ~(1u << b);
       }
-      if (!ok) m &= ~(1u << b);
     }
   }
   return m;
@@ -176,8 +192,11 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[6], const P
 // summaries.  EMIT=true: the same decisions, writing every match offset at its
 // rank (tile_off[tile] + rank inside the tile).
 // ---------------------------------------------------------------------------
-template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT>
+template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, int LOADS>
 __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
+  constexpr int kLoads = LOADS;                          // 16-byte units per lane
+  constexpr uint32_t kWaveSpan = kWaveLoad * kLoads;     // contiguous bytes per wave
+  constexpr uint32_t kTile = kWaveSpan * kWaves;         // bytes per workgroup
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
   __shared__ uint32_t s_sum[kWaves];
@@ -218,12 +237,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   for (int j = 0; j < kLoads; ++j) {
     uint64_t off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
     off = off < last_unit ? off : last_unit;
-    v[j] = *reinterpret_cast<const uint4*>(cbase + off);
+    // non-temporal: every byte is read once, so keeping it out of L2/MALL allocation
+    // is worth +8 % on this stream (7.1 vs 6.55 TB/s, scripts/read_variants.py)
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(cbase + off));
+    v[j] = make_uint4(t.x, t.y, t.z, t.w);
   }
-  // the 8 bytes that follow the span (wave-uniform address)
+  // the 16 bytes that follow the span (wave-uniform address)
   uint64_t eoff = wbase + kWaveSpan;
   eoff = eoff < last_unit ? eoff : last_unit;
-  const uint2 edge = *reinterpret_cast<const uint2*>(cbase + eoff);
+  const uint4 edge = *reinterpret_cast<const uint4*>(cbase + eoff);
   // keep every load ahead of the first use of any of them (otherwise the
   // scheduler sinks a copy of load 0 between the loads and stalls the issue)
   __builtin_amdgcn_sched_barrier(0);
@@ -236,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
 #pragma unroll
   for (int j = 0; j < kLoads; ++j) {
     const uint64_t unit_off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
-    uint32_t d[6] = {v[j].x, v[j].y, v[j].z, v[j].w, 0u, 0u};
+    uint32_t d[8] = {v[j].x, v[j].y, v[j].z, v[j].w, 0u, 0u, 0u, 0u};
     // bytes at or beyond L are not part of the chunk: clear them once
     if (unit_off + kUnit > L) {
 #pragma unroll
@@ -256,7 +278,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
 
     const bool any_c = cand_any<KIND>(d, P);
     uint32_t m = 0;
-    if (__any(any_c)) m = match_mask16<KIND>(d, P, cbase, unit_off, limit, s_pat);
+    if (__any(any_c)) {
+      if (KIND == kLong) {  // the neighbour's upper 8 bytes, for the in-register check of pattern bytes 8..15
+        const uint32_t e2 = j + 1 < kLoads ? __builtin_amdgcn_readfirstlane(v[j + 1 < kLoads ? j + 1 : j].z) : edge.z;
+        const uint32_t e3 = j + 1 < kLoads ? __builtin_amdgcn_readfirstlane(v[j + 1 < kLoads ? j + 1 : j].w) : edge.w;
+        d[6] = from_next_lane(v[j].z, e2, lane);
+        d[7] = from_next_lane(v[j].w, e3, lane);
+      }
+      m = match_mask16<KIND>(d, P, cbase, unit_off, limit, s_pat);
+    }
     if (EMIT) {
       masks[j] = m;
       cnt += (uint32_t)__popc(m);
@@ -266,13 +296,14 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
         last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen;
       }
       if (WANT_LINES) {
+        // A wave-load without any match start (the common case) summarises to
+        // "has a newline or not": no cross-lane reduction needed.
         uint32_t us;
         if (__any(m != 0)) {
-          us = sum_of_unit(m, nl_mask16(d));
+          us = wave_sum_combine(sum_of_unit(m, nl_mask16(d)), lane);
         } else {
-          us = nl_any16(d) ? kSumNl : 0u;
+          us = __any(nl_any16(d)) ? kSumNl : 0u;
         }
-        us = wave_sum_combine(us, lane);
         wsum = j == 0 ? us : sum_combine(wsum, us);
       }
     }
@@ -336,23 +367,33 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   }
 }
 
-template <int KIND>
+template <int KIND, int LOADS>
 static hipError_t launch_scan_kind(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, dim3 grid,
                                    hipStream_t s) {
   if (emit) {
-    hipLaunchKernelGGL((k_scan<KIND, false, false, true>), grid, dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((k_scan<KIND, false, false, true, LOADS>), grid, dim3(kBlock), 0, s, a);
   } else if (want_lines) {
     if (want_nl)
-      hipLaunchKernelGGL((k_scan<KIND, true, true, false>), grid, dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_scan<KIND, true, true, false, LOADS>), grid, dim3(kBlock), 0, s, a);
     else
-      hipLaunchKernelGGL((k_scan<KIND, false, true, false>), grid, dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_scan<KIND, false, true, false, LOADS>), grid, dim3(kBlock), 0, s, a);
   } else {
     if (want_nl)
-      hipLaunchKernelGGL((k_scan<KIND, true, false, false>), grid, dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_scan<KIND, true, false, false, LOADS>), grid, dim3(kBlock), 0, s, a);
     else
-      hipLaunchKernelGGL((k_scan<KIND, false, false, false>), grid, dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_scan<KIND, false, false, false, LOADS>), grid, dim3(kBlock), 0, s, a);
   }
   return hipGetLastError();
+}
+
+template <int KIND>
+static hipError_t launch_scan_loads(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, dim3 grid,
+                                    hipStream_t s) {
+  switch (a.tile_bytes) {
+    case 4096u * 4: return launch_scan_kind<KIND, 4>(a, want_nl, want_lines, emit, grid, s);
+    case 4096u * 8: return launch_scan_kind<KIND, 8>(a, want_nl, want_lines, emit, grid, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 static dim3 tile_grid(uint64_t ntiles) {
@@ -366,11 +407,11 @@ static hipError_t launch_scan(const ScanArgs& a, bool want_nl, bool want_lines, 
   if (a.ntiles == 0) return hipSuccess;
   const dim3 grid = tile_grid(a.ntiles);
   switch (a.pat.kind) {
-    case kMask1: return launch_scan_kind<kMask1>(a, want_nl, want_lines, emit, grid, s);
-    case kOne: return launch_scan_kind<kOne>(a, want_nl, want_lines, emit, grid, s);
-    case kMask2: return launch_scan_kind<kMask2>(a, want_nl, want_lines, emit, grid, s);
-    case kTwo: return launch_scan_kind<kTwo>(a, want_nl, want_lines, emit, grid, s);
-    default: return launch_scan_kind<kLong>(a, want_nl, want_lines, emit, grid, s);
+    case kMask1: return launch_scan_loads<kMask1>(a, want_nl, want_lines, emit, grid, s);
+    case kOne: return launch_scan_loads<kOne>(a, want_nl, want_lines, emit, grid, s);
+    case kMask2: return launch_scan_loads<kMask2>(a, want_nl, want_lines, emit, grid, s);
+    case kTwo: return launch_scan_loads<kTwo>(a, want_nl, want_lines, emit, grid, s);
+    default: return launch_scan_loads<kLong>(a, want_nl, want_lines, emit, grid, s);
   }
 }
 
@@ -378,6 +419,68 @@ hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, h
   return launch_scan(a, want_nl, want_lines, false, s);
 }
 hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s) { return launch_scan(a, false, false, true, s); }
+
+// ---------------------------------------------------------------------------
+// k_read_ceiling: diagnostic only.  The same load shape as k_scan (LOADS x
+// global_load_dwordx4 per lane, 1 KiB per wave-instruction) with no work on the
+// bytes: the empirical HBM read ceiling of this device for this access pattern.
+// ---------------------------------------------------------------------------
+// VARIANT 0: tile = block index (k_scan's mapping)      1: + non-temporal loads
+//         2: XCD-contiguous (blocks b, b+8, ... walk one eighth of the span)
+//         3: waves of a block interleave their KiBs instead of owning contiguous spans
+template <int LOADS, int VARIANT>
+__global__ __launch_bounds__(kBlock) void k_read_ceiling(const uint8_t* base, uint64_t ntiles, uint32_t* sink) {
+  uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+  if (tile >= ntiles) return;
+  if (VARIANT == 2) {
+    const uint64_t per = ntiles / 8;
+    if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint8_t* tbase = base + tile * (uint64_t)(kWaveLoad * LOADS * kWaves);
+  uint4 v[LOADS];
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) {
+    const uint64_t off = VARIANT == 3 ? ((uint64_t)(j * kWaves + wave) * kWaveLoad + (uint64_t)lane * kUnit)
+                                      : ((uint64_t)wave * (kWaveLoad * LOADS) + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit);
+    if (VARIANT == 1) {
+      const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tbase + off));
+      v[j] = make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+      v[j] = *reinterpret_cast<const uint4*>(tbase + off);
+    }
+  }
+  uint32_t x = 0;
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) x ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+  if (x == 0xdeadbeefu) sink[0] = x;  // keeps the loads alive; practically never true
+}
+
+template <int LOADS>
+static void launch_rc(int variant, dim3 grid, hipStream_t s, const uint8_t* base, uint64_t ntiles, uint32_t* sink) {
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((k_read_ceiling<LOADS, 1>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+    case 2: hipLaunchKernelGGL((k_read_ceiling<LOADS, 2>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+    case 3: hipLaunchKernelGGL((k_read_ceiling<LOADS, 3>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+    default: hipLaunchKernelGGL((k_read_ceiling<LOADS, 0>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+  }
+}
+
+hipError_t launch_read_ceiling(const uint8_t* base, uint64_t bytes, uint32_t tile_bytes, int variant, uint32_t* sink,
+                               hipStream_t s) {
+  const uint64_t ntiles = bytes / tile_bytes;
+  if (!ntiles) return hipSuccess;
+  const uint64_t maxx = 1u << 30;
+  const dim3 grid = ntiles <= maxx ? dim3((unsigned)ntiles) : dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx));
+  switch (tile_bytes) {
+    case 4096u: launch_rc<1>(variant, grid, s, base, ntiles, sink); break;
+    case 8192u: launch_rc<2>(variant, grid, s, base, ntiles, sink); break;
+    case 16384u: launch_rc<4>(variant, grid, s, base, ntiles, sink); break;
+    case 32768u: launch_rc<8>(variant, grid, s, base, ntiles, sink); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------
 // k_count_finish: sums the per-tile outputs and replays the reference walk
@@ -743,9 +846,9 @@ __global__ void k_line_indices(const LineOutArgs A) {
   const uint8_t* d = A.base + ch.offset;
   const uint64_t b = A.f_pos[i];
   const uint64_t t0 = A.chunk_tile0[c];
-  const uint64_t t = t0 + b / kTile;
+  const uint64_t t = t0 + b / A.tile_bytes;
   uint64_t n = A.tile_nl_off[t];
-  for (uint64_t p = (b / kTile) * kTile; p < b; ++p) n += d[p] == '\n';
+  for (uint64_t p = (b / A.tile_bytes) * A.tile_bytes; p < b; ++p) n += d[p] == '\n';
   if (ch.line_base == XSG_LINE_BASE_AUTO)
     A.out_u64[i] = A.shard_line_base + n;
   else

@@ -73,6 +73,7 @@ struct xsg_ctx {
   bool bordered = false;  // the pattern can overlap itself
   xsg::PatternDev pat{};
   DevBuf d_pat;
+  uint32_t tile_bytes = xsg::kDefaultTileBytes;  // geometry new shards get (XSG_TILE_KIB)
   char arch[128] = "";
   int cus = 0;
   uint64_t hbm = 0;
@@ -86,6 +87,7 @@ struct xsg_shard {
   std::vector<xsg_chunk> chunks;
   std::vector<uint64_t> chunk_tile0;
   uint64_t ntiles = 0;
+  uint32_t tile_bytes = xsg::kDefaultTileBytes;
   uint64_t total_bytes = 0;
   uint64_t shard_line_base = 0;
 
