@@ -180,6 +180,8 @@ typedef struct xsg_job_opts {
   int32_t num_threads;      /* worker threads, >= 1 */
   int32_t num_max_readers;  /* concurrent reads, >= 1 */
   uint64_t chunk_bytes;     /* target chunk size without a metafile (default 16 MiB) */
+  uint64_t chunk_begin;     /* search only chunks [chunk_begin, chunk_end) of the plan; 0,0 = all. */
+  uint64_t chunk_end;       /* (how one rank of a multi-GPU job takes its contiguous range) */
 } xsg_job_opts;
 
 typedef struct xsg_job_stats {
@@ -190,6 +192,8 @@ typedef struct xsg_job_stats {
   double seconds_read;     /* summed over workers */
   double seconds_decompress;
   double seconds_device;   /* H2D + kernels + D2H, summed over workers */
+  uint64_t newlines;       /* XSG_LINE_INDICES without metafile bases: '\n' in the searched chunks */
+  uint64_t plan_chunks;    /* chunks in the whole plan of the file (before the range was applied) */
 } xsg_job_stats;
 
 void xsg_job_opts_init(xsg_job_opts* opts);

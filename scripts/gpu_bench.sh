@@ -21,7 +21,7 @@ step bench_4g 600 python bench.py --gib-per-gpu 4 --steps 10 --warmup 2 --cpu-se
 step bench_50g 900 python bench.py || exit 1
 grep '^{' $OUT/bench_50g.log > $OUT/BENCH_${TAG}_local.json
 cd /tmp && export TMPDIR=/tmp
-step prof_stats 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --kernel-iters 3
+step prof_stats 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -- python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --kernel-iters 10
 step prof_fetch 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --kernel-iters 1
 step prof_write 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --kernel-iters 1
 cd $REPO

@@ -648,6 +648,16 @@ extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_
     close(j->fd);
     return r;
   }
+  j->stats.plan_chunks = j->plan.size();
+  if (opts->chunk_begin || opts->chunk_end) {
+    if (opts->chunk_begin > opts->chunk_end || opts->chunk_end > j->plan.size()) {
+      close(j->fd);
+      return fail(XSG_EINVAL, "chunk range [%llu, %llu) outside the plan of %zu chunks",
+                  (unsigned long long)opts->chunk_begin, (unsigned long long)opts->chunk_end, j->plan.size());
+    }
+    j->plan = std::vector<xsg_file_chunk>(j->plan.begin() + (ptrdiff_t)opts->chunk_begin,
+                                          j->plan.begin() + (ptrdiff_t)opts->chunk_end);
+  }
   for (const xsg_file_chunk& c : j->plan) {
     j->max_orig = std::max(j->max_orig, c.original_size);
     j->max_actual = std::max(j->max_actual, c.actual_size);
@@ -732,6 +742,7 @@ extern "C" int xsg_job_stats_get(xsg_job* j, xsg_job_stats* stats) {
   if (!j || !stats) return fail(XSG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(j->mu);
   *stats = j->stats;
+  stats->newlines = j->nl_running;
   if (!j->finished) stats->seconds_total = seconds_since(j->t_start);
   return XSG_OK;
 }

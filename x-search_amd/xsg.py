@@ -40,13 +40,13 @@ COMPRESSION_NONE, COMPRESSION_ZSTD, COMPRESSION_LZ4 = 1, 2, 3
 class JobOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_uint32), ("pattern_flags", C.c_uint32),
                 ("device", C.c_int32), ("num_threads", C.c_int32), ("num_max_readers", C.c_int32),
-                ("chunk_bytes", C.c_uint64)]
+                ("chunk_bytes", C.c_uint64), ("chunk_begin", C.c_uint64), ("chunk_end", C.c_uint64)]
 
 
 class JobStats(C.Structure):
     _fields_ = [("bytes_scanned", C.c_uint64), ("bytes_read", C.c_uint64), ("chunks", C.c_uint64),
                 ("seconds_total", C.c_double), ("seconds_read", C.c_double), ("seconds_decompress", C.c_double),
-                ("seconds_device", C.c_double)]
+                ("seconds_device", C.c_double), ("newlines", C.c_uint64), ("plan_chunks", C.c_uint64)]
 
 
 class XsgError(RuntimeError):
@@ -307,12 +307,15 @@ class Job:
     """A file search (what xs::extern_search returns a handle to)."""
 
     def __init__(self, pattern: bytes, path: str, mode: int, meta_path: str | None = None, device: int = 0,
-                 num_threads: int = 1, num_max_readers: int = 1, chunk_bytes: int = 16 << 20, flags: int = 0):
+                 num_threads: int = 1, num_max_readers: int = 1, chunk_bytes: int = 16 << 20, flags: int = 0,
+                 chunk_range: tuple[int, int] | None = None):
         self._lib = load()
         o = JobOpts()
         self._lib.xsg_job_opts_init(C.byref(o))
         o.mode, o.pattern_flags, o.device = mode, flags, device
         o.num_threads, o.num_max_readers, o.chunk_bytes = num_threads, num_max_readers, chunk_bytes
+        if chunk_range is not None:
+            o.chunk_begin, o.chunk_end = chunk_range
         h = C.c_void_p()
         _check(self._lib.xsg_job_start(pattern, len(pattern), os.fsencode(path),
                                        os.fsencode(meta_path) if meta_path else None, C.byref(o), C.byref(h)))
