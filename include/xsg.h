@@ -218,6 +218,31 @@ int xsg_job_get_u64(xsg_job* job, uint64_t first, uint64_t n, uint64_t* out);
 int xsg_job_get_line(xsg_job* job, uint64_t index, const char** data, uint64_t* len);
 int xsg_job_stats_get(xsg_job* job, xsg_job_stats* stats);
 
+/* ======================================================================== */
+/* The lower seam: one chunk held in HOST memory                             */
+/* ======================================================================== */
+/* What a reference-style searcher functor calls for the chunk its reader just
+ * produced (include/xsearch/tasks/searchers.h:38-93: IndexSearcher ->
+ * byte_offsets_match, LineIndexSearcher -> byte_offsets_line, LineSearcher ->
+ * line; concepts.h:36-39 SearcherC).  Results are CHUNK-LOCAL, exactly what the
+ * search_wrappers.h functions return.  Thread-safe like the reference's shared
+ * const functor (Searcher.h:110): concurrent callers use separate internal
+ * slots (pinned staging buffer + device buffer + stream); callers beyond
+ * max_slots wait for a free one.  include/xsearch/tasks/gpu_searchers.h wraps
+ * these in functors with the reference's call signature. */
+typedef struct xsg_host_searcher xsg_host_searcher;
+int xsg_host_searcher_create(int device, const void* pattern, size_t plen, uint32_t flags, int max_slots,
+                             xsg_host_searcher** out);
+void xsg_host_searcher_destroy(xsg_host_searcher* hs);
+/* search::count(data, pattern, skip_to_nl)  (search_wrappers.h:163-185) */
+int xsg_host_count(xsg_host_searcher* hs, const void* data, uint64_t len, int skip_to_nl, uint64_t* count);
+/* mode = XSG_MATCH_BYTE_OFFSETS / XSG_LINE_BYTE_OFFSETS / XSG_LINE_INDICES; *out is malloc'ed (xsg_free) */
+int xsg_host_offsets(xsg_host_searcher* hs, uint32_t mode, const void* data, uint64_t len, uint64_t** out,
+                     uint64_t* n);
+/* search::line (:187-207): n lines, lengths[i] bytes each, packed in *bytes; both malloc'ed (xsg_free) */
+int xsg_host_lines(xsg_host_searcher* hs, const void* data, uint64_t len, uint64_t** lengths, char** bytes,
+                   uint64_t* n, uint64_t* nbytes);
+
 /* ---- chunk plans and metafiles (host only: usable without a GPU) ------------- */
 /* One record of the reference's metafile (decoded from test/files/ *.meta,
  * field names from metafile_cat.cpp:39-49). */

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe-inclusive) rate of the file pipeline: a page-cache/tmpfs
+resident text file -> pread into pinned buffers -> hipMemcpyAsync -> scan -> result.
+Bounded by PCIe Gen5 x16 (~63 GB/s) and the host read path, never by HBM; reported
+next to -- never instead of -- bench.py's device-resident number."""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "x-search_amd"))
+sys.path.insert(0, str(ROOT / "oracle"))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gib", type=float, default=8.0)
+    ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--threads", default="1,2,4,8,16")
+    ap.add_argument("--modes", default="count,count_lines,match_byte_offsets,lines")
+    a = ap.parse_args()
+    import xsg
+    from xs_oracle import Oracle
+    args = argparse.Namespace(chunk_mib=16, templates=16, seed=0x5EED)
+    blocks = bench.template_blocks(args, b"Sherlock")
+    n = int(a.gib * 2**30 / (16 << 20))
+    plan = bench.chunk_plan(args, 0, n)
+    path = os.path.join(a.dir, f"xsg_e2e_{os.getpid()}.txt")
+    with open(path, "wb") as f:
+        for c in plan:
+            f.write(blocks[int(c)].tobytes())
+    size = os.path.getsize(path)
+    orc = Oracle()
+    tc = [orc.count(b, b"Sherlock", False) for b in blocks]
+    want = sum(tc[int(c)] for c in plan)
+    modes = {"count": xsg.COUNT_MATCHES, "count_lines": xsg.COUNT_LINES, "match_byte_offsets": xsg.MATCH_BYTE_OFFSETS,
+             "lines": xsg.LINES, "line_indices": xsg.LINE_INDICES, "line_byte_offsets": xsg.LINE_BYTE_OFFSETS}
+    try:
+        for name in a.modes.split(","):
+            for th in [int(x) for x in a.threads.split(",")]:
+                t0 = time.perf_counter()
+                j = xsg.Job(b"Sherlock", path, modes[name], num_threads=th, num_max_readers=th)
+                r = j.result()
+                dt = time.perf_counter() - t0
+                st = j.stats()
+                j.close()
+                got = r if isinstance(r, int) else len(r)
+                ok = (got == want) if name in ("count", "match_byte_offsets") else None
+                print(json.dumps({"mode": name, "threads": th, "gib": round(size / 2**30, 2), "seconds": round(dt, 3),
+                                  "gib_per_s": round(size / dt / 2**30, 2), "result": got, "parity": ok,
+                                  "read_s": round(st["seconds_read"], 2), "device_s": round(st["seconds_device"], 2)}),
+                      flush=True)
+    finally:
+        os.unlink(path)
+
+
+if __name__ == "__main__":
+    main()

@@ -166,3 +166,46 @@ def test_config1_shape_100mb_six_chunks(oracle, tmp_path):
     j = xsg.Job(b"Sherlock", str(p), xsg.COUNT_MATCHES, num_threads=1)
     assert j.result() == want > 0
     j.close()
+
+
+SEAM = ROOT / "tests" / "cpp" / "build" / "seam_cli"
+
+
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_reference_style_searcher_functors(files, oracle, threads):
+    """GpuIndexSearcher / GpuLineIndexSearcher / GpuLineSearcher called like
+    Searcher::run_thread calls the reference's functors (Searcher.h:100-120,
+    tasks/searchers.h:38-93): chunk-local results, nullopt for hit-less chunks,
+    one shared const functor used by N threads."""
+    if not SEAM.exists():
+        pytest.fail(f"{SEAM} not built (make -C tests/cpp)")
+    data = np.fromfile(files["txt"], dtype=np.uint8)
+    plan = xsg.plan_chunks(files["txt"], CHUNK)
+    chunks = [data[int(c["original_offset"]):int(c["original_offset"] + c["original_size"])] for c in plan]
+    pat = b"She"
+
+    def parse(out):
+        res, cur = {}, None
+        for line in out.split(b"\n")[:-1]:
+            if line.startswith(b"C "):
+                _, i, n = line.split()
+                cur = res.setdefault(int(i), [])
+            else:
+                cur.append(line)
+        return res
+
+    for what, fn in (("index", lambda b: [str(int(x)).encode() for x in oracle.byte_offsets_match(b, pat)]),
+                     ("line_index", lambda b: [str(int(x)).encode() for x in oracle.byte_offsets_line(b, pat)]),
+                     ("line", lambda b: oracle.lines(b, pat))):
+        r = subprocess.run([str(SEAM), what, pat.decode(), files["txt"], str(CHUNK), threads], capture_output=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr.decode()
+        got = parse(r.stdout)
+        assert sorted(got) == list(range(len(chunks)))
+        for i, b in enumerate(chunks):
+            assert got[i] == fn(b), (what, i)
+    r = subprocess.run([str(SEAM), "count", pat.decode(), files["txt"], str(CHUNK), threads], capture_output=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    counts = {int(l.split()[1]): int(l.split()[2]) for l in r.stdout.split(b"\n")[:-1]}
+    assert [counts[i] for i in range(len(chunks))] == [oracle.count(b, pat, True) for b in chunks]

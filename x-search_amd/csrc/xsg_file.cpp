@@ -746,3 +746,186 @@ extern "C" int xsg_job_stats_get(xsg_job* j, xsg_job_stats* stats) {
   if (!j->finished) stats->seconds_total = seconds_since(j->t_start);
   return XSG_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// the lower seam: chunks in host memory (reference-style searcher functors)
+// ---------------------------------------------------------------------------
+struct HostSlot {
+  xsg_ctx* ctx = nullptr;
+  xsg_shard* shard = nullptr;
+  void* pinned = nullptr;
+  void* dev = nullptr;
+  uint64_t cap = 0;
+  ~HostSlot() {
+    if (shard) xsg_shard_destroy(shard);
+    if (pinned) (void)hipHostFree(pinned);
+    if (dev) (void)hipFree(dev);
+    if (ctx) xsg_ctx_destroy(ctx);
+  }
+};
+
+struct xsg_host_searcher {
+  int device = 0;
+  std::vector<uint8_t> pattern;
+  uint32_t flags = 0;
+  int max_slots = 1;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::unique_ptr<HostSlot>> all;
+  std::vector<HostSlot*> free_slots;
+};
+
+static int host_slot_acquire(xsg_host_searcher* hs, HostSlot** out) {
+  std::unique_lock<std::mutex> lk(hs->mu);
+  for (;;) {
+    if (!hs->free_slots.empty()) {
+      *out = hs->free_slots.back();
+      hs->free_slots.pop_back();
+      return XSG_OK;
+    }
+    if ((int)hs->all.size() < hs->max_slots) {
+      hs->all.emplace_back(new HostSlot());
+      HostSlot* s = hs->all.back().get();
+      lk.unlock();
+      int r = xsg_ctx_create(hs->device, &s->ctx);
+      if (r == XSG_OK) r = xsg_set_pattern(s->ctx, hs->pattern.data(), hs->pattern.size(), hs->flags);
+      if (r == XSG_OK) r = xsg_shard_create(s->ctx, nullptr, 0, nullptr, 0, &s->shard);
+      if (r != XSG_OK) return r;  // the half-built slot stays owned by `all` and is never handed out
+      *out = s;
+      return XSG_OK;
+    }
+    hs->cv.wait(lk);
+  }
+}
+
+static void host_slot_release(xsg_host_searcher* hs, HostSlot* s) {
+  {
+    std::lock_guard<std::mutex> g(hs->mu);
+    hs->free_slots.push_back(s);
+  }
+  hs->cv.notify_one();
+}
+
+// stage the chunk: host -> pinned -> device, bind it as a 1-chunk shard (local offsets, line base 0)
+static int host_stage(HostSlot* s, const void* data, uint64_t len) {
+  const uint64_t need = ((len + 15u) & ~(uint64_t)15u) + 256u;
+  if (need > s->cap) {
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    if (s->dev) (void)hipFree(s->dev);
+    s->pinned = s->dev = nullptr;
+    s->cap = 0;
+    const uint64_t cap = std::max<uint64_t>(need, 1u << 20);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipHostMalloc(&s->pinned, cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&s->dev, cap));
+    s->cap = cap;
+  }
+  if (len) {
+    memcpy(s->pinned, data, len);
+    HIP_TRY(hipMemcpyAsync(s->dev, s->pinned, len, hipMemcpyHostToDevice, s->ctx->stream));
+  }
+  xsg_chunk ch{};
+  ch.offset = 0;
+  ch.length = len;
+  ch.global_offset = 0;
+  ch.line_base = 0;
+  return xsg_shard_rebind(s->shard, s->dev, s->cap, &ch, 1);
+}
+
+extern "C" int xsg_host_searcher_create(int device, const void* pattern, size_t plen, uint32_t flags, int max_slots,
+                                        xsg_host_searcher** out) {
+  if (!out) return fail(XSG_EINVAL, "out is null");
+  *out = nullptr;
+  if (!pattern || plen == 0 || plen > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "pattern must be 1..%u bytes",
+                                                                  XSG_MAX_PATTERN);
+  int ndev = 0;
+  XSG_TRY(xsg_device_count(&ndev));
+  if (device < 0 || device >= ndev) return fail(XSG_ENODEV, "device %d out of range", device);
+  std::unique_ptr<xsg_host_searcher> hs(new (std::nothrow) xsg_host_searcher());
+  if (!hs) return fail(XSG_ENOMEM, "host allocation failed");
+  hs->device = device;
+  hs->pattern.assign((const uint8_t*)pattern, (const uint8_t*)pattern + plen);
+  hs->flags = flags;
+  hs->max_slots = max_slots < 1 ? 1 : max_slots;
+  // build the first slot now so that a bad pattern / missing GPU fails here, not in the first search
+  HostSlot* s = nullptr;
+  XSG_TRY(host_slot_acquire(hs.get(), &s));
+  host_slot_release(hs.get(), s);
+  *out = hs.release();
+  return XSG_OK;
+}
+
+extern "C" void xsg_host_searcher_destroy(xsg_host_searcher* hs) { delete hs; }
+
+struct SlotLease {
+  xsg_host_searcher* hs;
+  HostSlot* s = nullptr;
+  explicit SlotLease(xsg_host_searcher* h) : hs(h) {}
+  ~SlotLease() {
+    if (s) host_slot_release(hs, s);
+  }
+};
+
+extern "C" int xsg_host_count(xsg_host_searcher* hs, const void* data, uint64_t len, int skip_to_nl,
+                              uint64_t* count) {
+  if (!hs || !count || (!data && len)) return fail(XSG_EINVAL, "null argument");
+  SlotLease l(hs);
+  XSG_TRY(host_slot_acquire(hs, &l.s));
+  XSG_TRY(host_stage(l.s, data, len));
+  uint64_t ctr[XSG_NUM_COUNTERS];
+  XSG_TRY(xsg_count(l.s->shard, skip_to_nl ? XSG_COUNT_LINES : XSG_COUNT_MATCHES, ctr));
+  *count = ctr[skip_to_nl ? XSG_CTR_LINES : XSG_CTR_MATCHES];
+  return XSG_OK;
+}
+
+extern "C" int xsg_host_offsets(xsg_host_searcher* hs, uint32_t mode, const void* data, uint64_t len, uint64_t** out,
+                                uint64_t* n) {
+  if (!hs || !out || !n || (!data && len)) return fail(XSG_EINVAL, "null argument");
+  if (mode != XSG_MATCH_BYTE_OFFSETS && mode != XSG_LINE_BYTE_OFFSETS && mode != XSG_LINE_INDICES)
+    return fail(XSG_EINVAL, "mode %u has no uint64 list result", mode);
+  SlotLease l(hs);
+  XSG_TRY(host_slot_acquire(hs, &l.s));
+  XSG_TRY(host_stage(l.s, data, len));
+  uint64_t cnt = 0;
+  XSG_TRY(xsg_search(l.s->shard, mode, &cnt));
+  uint64_t* buf = static_cast<uint64_t*>(malloc(8 * std::max<uint64_t>(cnt, 1)));
+  if (!buf) return fail(XSG_ENOMEM, "host allocation failed");
+  const int r = xsg_result_u64(l.s->shard, buf, cnt);
+  if (r != XSG_OK) {
+    free(buf);
+    return r;
+  }
+  *out = buf;
+  *n = cnt;
+  return XSG_OK;
+}
+
+extern "C" int xsg_host_lines(xsg_host_searcher* hs, const void* data, uint64_t len, uint64_t** lengths, char** bytes,
+                              uint64_t* n, uint64_t* nbytes) {
+  if (!hs || !lengths || !bytes || !n || !nbytes || (!data && len)) return fail(XSG_EINVAL, "null argument");
+  SlotLease l(hs);
+  XSG_TRY(host_slot_acquire(hs, &l.s));
+  XSG_TRY(host_stage(l.s, data, len));
+  uint64_t cnt = 0, nl = 0, nb = 0;
+  XSG_TRY(xsg_search(l.s->shard, XSG_LINES, &cnt));
+  XSG_TRY(xsg_result_lines_size(l.s->shard, &nl, &nb));
+  uint64_t* lens = static_cast<uint64_t*>(malloc(8 * std::max<uint64_t>(nl, 1)));
+  char* buf = static_cast<char*>(malloc(std::max<uint64_t>(nb, 1)));
+  if (!lens || !buf) {
+    free(lens);
+    free(buf);
+    return fail(XSG_ENOMEM, "host allocation failed");
+  }
+  const int r = xsg_result_lines(l.s->shard, lens, buf, nb, nullptr);
+  if (r != XSG_OK) {
+    free(lens);
+    free(buf);
+    return r;
+  }
+  *lengths = lens;
+  *bytes = buf;
+  *n = nl;
+  *nbytes = nb;
+  return XSG_OK;
+}

@@ -112,6 +112,11 @@ def load():
         "xsg_job_get_u64": (ci, [vp, u64, u64, _u64p]),
         "xsg_job_get_line": (ci, [vp, u64, C.POINTER(C.c_char_p), _u64p]),
         "xsg_job_stats_get": (ci, [vp, C.POINTER(JobStats)]),
+        "xsg_host_searcher_create": (ci, [ci, C.c_char_p, sz, u32, ci, C.POINTER(vp)]),
+        "xsg_host_searcher_destroy": (None, [vp]),
+        "xsg_host_count": (ci, [vp, vp, u64, ci, _u64p]),
+        "xsg_host_offsets": (ci, [vp, u32, vp, u64, C.POINTER(vp), _u64p]),
+        "xsg_host_lines": (ci, [vp, vp, u64, C.POINTER(vp), C.POINTER(vp), _u64p, _u64p]),
         "xsg_plan_chunks": (ci, [C.c_char_p, u64, C.POINTER(vp), _u64p]),
         "xsg_meta_read": (ci, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(vp), _u64p, C.POINTER(vp), _u64p]),
         "xsg_meta_write": (ci, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, u64, u64, ci]),
@@ -134,7 +139,8 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_result_lines_size", "xsg_result_lines", "xsg_ctx_info", "xsg_time_scan_kernel", "xsg_time_read_ceiling", "xsg_result_newlines",
            "xsg_job_opts_init", "xsg_job_start", "xsg_job_join", "xsg_job_destroy", "xsg_job_total", "xsg_job_wait", "xsg_job_poll",
            "xsg_job_get_u64", "xsg_job_get_line", "xsg_job_stats_get", "xsg_plan_chunks", "xsg_meta_read",
-           "xsg_meta_write", "xsg_free"]
+           "xsg_meta_write", "xsg_free", "xsg_host_searcher_create", "xsg_host_searcher_destroy", "xsg_host_count",
+           "xsg_host_offsets", "xsg_host_lines"]
 
 
 def _check(rc):
