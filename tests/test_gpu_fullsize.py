@@ -1,0 +1,115 @@
+"""BASELINE.json's full sizes on one MI355X, checked exactly.
+
+The shard is built like bench.py's: T distinct template chunks replicated in a
+seeded order (every byte at its own HBM address).  Because chunks are independent
+units, the exact expected result of the WHOLE shard follows from the oracle's
+results on the T templates: offsets = template-local offsets + the chunk's global
+offset, line indices = template-local indices + newlines before the chunk, lines
+= the template's lines.  So configs 2 and 4 (10 GiB, list tags) are compared
+element by element, and config 3's shape (50 GiB count) through the sum."""
+import argparse
+
+import numpy as np
+import pytest
+
+import corpus
+import xsg
+
+pytestmark = pytest.mark.gpu
+
+
+def build_shard(gib, templates=16, seed=0xBEEF):
+    import torch
+    import bench
+    args = argparse.Namespace(chunk_mib=16, templates=templates, seed=seed)
+    blocks = bench.template_blocks(args, b"Sherlock")
+    n = int(gib * 2**30 / (16 << 20))
+    plan = bench.chunk_plan(args, 0, n)
+    tbytes = np.array([b.size for b in blocks], dtype=np.int64)
+    off, ln, cap = corpus.chunk_table(tbytes[plan])
+    dev = torch.device("cuda", 0)
+    t = torch.empty(cap, dtype=torch.uint8, device=dev)
+    dts = [torch.from_numpy(b).to(dev) for b in blocks]
+    for c in range(n):
+        o = int(off[c])
+        t[o:o + dts[int(plan[c])].numel()].copy_(dts[int(plan[c])])
+    torch.cuda.synchronize()
+    goffs = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.uint64)
+    return t, blocks, plan, xsg.make_chunks(off, ln, goffs), goffs, cap
+
+
+@pytest.fixture(scope="module")
+def shard10():
+    t, blocks, plan, chunks, goffs, cap = build_shard(10.0)
+    ctx = xsg.Context(0)
+    sh = xsg.Shard(ctx, t.data_ptr(), cap, chunks)
+    yield {"t": t, "blocks": blocks, "plan": plan, "goffs": goffs, "ctx": ctx, "shard": sh}
+    sh.close()
+    ctx.close()
+
+
+def test_config2_match_byte_offsets_10gib(shard10, oracle):
+    s = shard10
+    pat = b"Sherlock"
+    s["ctx"].set_pattern(pat)
+    got = s["shard"].search_u64(xsg.MATCH_BYTE_OFFSETS)
+    tl = [oracle.byte_offsets_match(b, pat) for b in s["blocks"]]
+    want = np.concatenate([tl[int(c)] + s["goffs"][i] for i, c in enumerate(s["plan"])])
+    assert got.size == want.size > 5000
+    assert np.array_equal(got, want)
+    assert np.all(np.diff(got.astype(np.int64)) > 0)  # sorted, unique
+    # count through both entry points agrees
+    assert int(s["shard"].count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == want.size
+
+
+def test_config4_line_indices_and_lines_10gib(shard10, oracle):
+    s = shard10
+    pat = b"Sherlock"
+    s["ctx"].set_pattern(pat)
+    nl_t = np.array([oracle.count_newlines(b) for b in s["blocks"]], dtype=np.uint64)
+    nl_before = np.concatenate([[0], np.cumsum(nl_t[s["plan"]])[:-1]]).astype(np.uint64)
+    li_t = [oracle.line_indices(b, pat, 0) for b in s["blocks"]]
+    want_idx = np.concatenate([li_t[int(c)] + nl_before[i] for i, c in enumerate(s["plan"])])
+    got_idx = s["shard"].search_u64(xsg.LINE_INDICES)
+    assert np.array_equal(got_idx, want_idx)
+
+    lo_t = [oracle.byte_offsets_line(b, pat) for b in s["blocks"]]
+    want_lo = np.concatenate([lo_t[int(c)] + s["goffs"][i] for i, c in enumerate(s["plan"])])
+    assert np.array_equal(s["shard"].search_u64(xsg.LINE_BYTE_OFFSETS), want_lo)
+
+    lines_t = [oracle.lines(b, pat) for b in s["blocks"]]
+    want_lines = [l for c in s["plan"] for l in lines_t[int(c)]]
+    got_lines, got_off = s["shard"].search_lines()
+    assert got_lines == want_lines
+    assert np.array_equal(got_off, want_lo)  # all chunks are newline-terminated: every matching line is reported
+    assert int(s["shard"].count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == len(want_lines)
+
+
+def test_dense_pattern_10gib_count_properties(shard10, oracle):
+    """A dense needle ('e': ~8 % of all bytes) at full size: linearity over chunks."""
+    s = shard10
+    for pat in (b"e", b"the", b"She"):
+        s["ctx"].set_pattern(pat)
+        tm = np.array([oracle.count(b, pat, False) for b in s["blocks"]], dtype=np.int64)
+        tlc = np.array([oracle.count(b, pat, True) for b in s["blocks"]], dtype=np.int64)
+        c = s["shard"].count(xsg.COUNT_MATCHES | xsg.WITH_NEWLINES)
+        assert int(c[xsg.CTR_MATCHES]) == int(tm[s["plan"]].sum())
+        assert int(s["shard"].count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == int(tlc[s["plan"]].sum())
+        nl_t = np.array([oracle.count_newlines(b) for b in s["blocks"]], dtype=np.int64)
+        assert int(c[xsg.CTR_NEWLINES]) == int(nl_t[s["plan"]].sum())
+
+
+def test_config3_shape_50gib_count(oracle):
+    """One rank's share of config 3 is covered by bench.py (it checks every timed
+    step); here the 50 GiB shard is checked once more through count_lines."""
+    t, blocks, plan, chunks, goffs, cap = build_shard(50.0, templates=8, seed=0xABCD)
+    ctx = xsg.Context(0)
+    sh = xsg.Shard(ctx, t.data_ptr(), cap, chunks)
+    ctx.set_pattern(b"Sherlock")
+    tm = np.array([oracle.count(b, b"Sherlock", False) for b in blocks], dtype=np.int64)
+    tl = np.array([oracle.count(b, b"Sherlock", True) for b in blocks], dtype=np.int64)
+    assert int(sh.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == int(tm[plan].sum())
+    assert int(sh.count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == int(tl[plan].sum())
+    assert int(sh.count(xsg.COUNT_MATCHES)[xsg.CTR_BYTES]) == int(chunks["length"].sum())
+    sh.close()
+    ctx.close()
