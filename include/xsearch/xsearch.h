@@ -26,7 +26,8 @@
 // search and is thrown by join() / by the iterator that runs into it.
 //
 // Not served here: regular expressions (the reference routes them to RE2,
-// utils/utils.h:17-25) -- every pattern is a literal; ignore_case=true throws.
+// utils/utils.h:17-25) -- every pattern is a literal.  ignore_case folds ASCII
+// letters only (what the reference's simd::toLower does).
 //
 // Environment: XS_DEVICE (HIP device index, default 0), XS_CHUNK_BYTES (target
 // chunk size without a metafile, default 16 MiB).
@@ -213,11 +214,10 @@ class ExternSearcher {
 
   ExternSearcher(const std::string& pattern, const std::string& file_path, const std::string& meta_file_path,
                  bool ignore_case, int num_threads, int num_max_readers) {
-    if (ignore_case)
-      throw std::invalid_argument("xs::extern_search: ignore_case is not supported by the MI355X engine yet");
     xsg_job_opts o;
     xsg_job_opts_init(&o);
     o.mode = detail::traits<Tag>::mode;
+    if (ignore_case) o.pattern_flags |= XSG_FLAG_IGNORE_CASE;  // ASCII, as simd::toLower (string_utils.cpp:11-33)
     o.device = static_cast<int32_t>(detail::env_u64("XS_DEVICE", 0));
     o.num_threads = num_threads < 1 ? 1 : num_threads;
     o.num_max_readers = num_max_readers < 1 ? 1 : num_max_readers;

@@ -64,6 +64,15 @@ enum xsg_mode {
  * (simd_search.cpp:58-78,203).  With XSG_FLAG_EXACT_TAIL every occurrence in
  * the chunk is reported (what the reference intends). */
 #define XSG_FLAG_EXACT_TAIL 0x1u
+/* ASCII case-insensitive search (the `ignore_case` argument of xs::extern_search,
+ * example/grep.cpp:69, test/src/xsearchTest.cpp:350).  The snapshot holds no
+ * implementation of the case-insensitive wrappers; the semantics here are the
+ * reference's building block applied to both sides: simd::toLower
+ * (src/utils/string_utils.cpp:11-33: 'A'..'Z' += 32, other bytes unchanged) on
+ * the chunk and on the pattern, then the normal search.  Offsets are unchanged
+ * and xs::lines returns the ORIGINAL bytes (goldens keep their case,
+ * test/src/xsearchTest.cpp:227-240). */
+#define XSG_FLAG_IGNORE_CASE 0x2u
 
 #define XSG_MAX_PATTERN 1024u
 

@@ -343,6 +343,12 @@ uint64_t xso_line_indices(const char* data, size_t len, const char* pat, size_t 
   return n;
 }
 
+/* string_utils.cpp:11-33 */
+void xso_to_lower(char* buf, size_t len) {
+  for (size_t i = 0; i < len; ++i)
+    if (buf[i] >= 'A' && buf[i] <= 'Z') buf[i] = (char)(buf[i] + ('a' - 'A'));
+}
+
 /* ------------------------------------------------------------------------ */
 typedef struct {
   const char* base;

@@ -75,6 +75,13 @@ uint64_t xso_line_indices(const char* data, size_t len, const char* pat, size_t 
                           uint64_t* out, uint64_t cap);
 uint64_t xso_count_newlines(const char* data, size_t len);
 
+/* ---- ignore_case building block (src/utils/string_utils.cpp:11-33) ------- */
+/* simd::toLower: bytes 'A'..'Z' += 32 in place (signed compares in the AVX2 body,
+ * std::tolower in the C locale for the remainder: ASCII only, bytes >= 0x80 untouched).
+ * The snapshot has no case-insensitive wrapper; ignore_case is modelled as
+ * search(toLower(chunk), toLower(pattern)) -- offsets unchanged. */
+void xso_to_lower(char* buf, size_t len);
+
 /* ---- chunk driver (include/xsearch/Searcher.h:100-120 worker loop) ------- */
 /* N worker threads pull chunk indices from a shared counter (work stealing,
  * like run_thread), each runs count() on its chunk; returns the sum.

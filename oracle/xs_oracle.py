@@ -102,6 +102,7 @@ class Oracle:
         lib.xso_line_indices.restype = u64
         lib.xso_count_newlines.argtypes = [vp, sz]
         lib.xso_count_newlines.restype = u64
+        lib.xso_to_lower.argtypes = [vp, sz]
         lib.xso_count_chunks_mt.argtypes = [vp, _u64p, _u64p, u64, cp, sz, ci, ci, _u64p]
         lib.xso_count_chunks_mt.restype = u64
 
@@ -115,6 +116,13 @@ class Oracle:
             self.lib.xso_use_primitives(None, None)
         else:
             self.lib.xso_use_primitives(C.cast(ref.fn_findnext, C.c_void_p), C.cast(ref.fn_findnl, C.c_void_p))
+
+    def lower(self, data) -> np.ndarray:
+        """simd::toLower on a copy (string_utils.cpp:11-33)."""
+        a = np.frombuffer(_as_bytes(data), dtype=np.uint8).copy() if not isinstance(data, np.ndarray) else data.copy()
+        if a.size:
+            self.lib.xso_to_lower(a.ctypes.data, a.size)
+        return a
 
     # -- primitives ---------------------------------------------------------
     def strstr(self, data, pat) -> int:

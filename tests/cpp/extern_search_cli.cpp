@@ -6,14 +6,16 @@
 #include <xsearch/xsearch.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
 template <class Tag>
 static int run(const std::string& how, const std::string& pattern, const std::string& file, const std::string& meta,
                int threads, int readers) {
-  auto res = meta.empty() ? xs::extern_search<Tag>(pattern, file, false, threads)
-                          : xs::extern_search<Tag>(pattern, file, meta, false, threads, readers);
+  const bool icase = std::getenv("XS_IGNORE_CASE") != nullptr;  // test hook for the ignore_case argument
+  auto res = meta.empty() ? xs::extern_search<Tag>(pattern, file, icase, threads)
+                          : xs::extern_search<Tag>(pattern, file, meta, icase, threads, readers);
   using V = typename xs::Result<Tag>::value_type;
   constexpr bool is_count = std::is_same<Tag, xs::count>::value || std::is_same<Tag, xs::count_lines>::value;
   if (how == "join") {

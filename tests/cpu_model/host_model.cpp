@@ -24,11 +24,13 @@ static uint64_t bulk_limit(uint64_t L, uint32_t plen, int exact) {
   return tail_zone_begin(L, plen);
 }
 
+// bit 1 of `exact` = ignore_case (the pattern passed in is already lowered, like the device copy)
+static bool g_icase = false;
 static std::vector<uint64_t> bulk_occ(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t plen, int exact) {
   std::vector<uint64_t> v;
   const uint64_t lim = bulk_limit(L, plen, exact);
   for (uint64_t o = 0; o < lim; ++o)
-    if (memcmp(d + o, p, plen) == 0) v.push_back(o);
+    if (occurs_at(d, o, p, plen, g_icase)) v.push_back(o);
   return v;
 }
 
@@ -76,7 +78,7 @@ static void model_list(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t 
   if (!exact && plen > 1) {
     std::vector<uint64_t> t(tail_max_matches(plen) + 1);
     const uint32_t n = tail_walk(d, L, p, plen, walk_entry(d, L, last_end, line_mode != 0), line_mode != 0, t.data(),
-                                 (uint32_t)t.size());
+                                 (uint32_t)t.size(), g_icase);
     for (uint32_t k = 0; k < n; ++k) {
       pos.push_back(line_mode ? line_start(d, t[k]) : t[k]);
       first_match.push_back(t[k]);
@@ -85,6 +87,8 @@ static void model_list(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t 
 }
 
 extern "C" {
+
+void hm_set_icase(int on) { g_icase = on != 0; }
 
 uint64_t hm_list(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t plen, int exact, int line_mode, uint64_t* out,
                  uint64_t cap) {
@@ -117,7 +121,7 @@ uint64_t hm_count_matches_borderfree(const uint8_t* d, uint64_t L, const uint8_t
   std::vector<uint64_t> occ = bulk_occ(d, L, p, plen, exact);
   uint64_t n = occ.size();
   const uint64_t last_end = occ.empty() ? 0 : occ.back() + plen;
-  if (!exact && plen > 1) n += tail_walk(d, L, p, plen, walk_entry(d, L, last_end, false), false, nullptr, 0);
+  if (!exact && plen > 1) n += tail_walk(d, L, p, plen, walk_entry(d, L, last_end, false), false, nullptr, 0, g_icase);
   return n;
 }
 
@@ -144,7 +148,7 @@ uint64_t hm_count_lines(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t
   }
   uint64_t lines = have ? sum_total_lines(total) : 0;
   const uint64_t last_end = occ.empty() ? 0 : occ.back() + plen;
-  if (!exact && plen > 1) lines += tail_walk(d, L, p, plen, walk_entry(d, L, last_end, true), true, nullptr, 0);
+  if (!exact && plen > 1) lines += tail_walk(d, L, p, plen, walk_entry(d, L, last_end, true), true, nullptr, 0, g_icase);
   return lines;
 }
 

@@ -56,9 +56,14 @@ class GpuSearch:
         return out
 
 
-def oracle_all_modes(oracle, blocks, pattern: bytes, exact=False, global_offsets=None, line_bases=None):
+def oracle_all_modes(oracle, blocks, pattern: bytes, exact=False, global_offsets=None, line_bases=None,
+                     ignore_case=False):
     """The same dict from the CPU oracle, chunk by chunk (chunks are independent
     units: include/xsearch/Searcher.h:100-120 hands each to the searcher alone)."""
+    orig_blocks = blocks
+    if ignore_case:  # search(toLower(chunk), toLower(pattern)); reported lines keep their original bytes
+        blocks = [oracle.lower(b) for b in blocks]
+        pattern = oracle.lower(pattern).tobytes()
     oracle.set_exact(bool(exact))
     try:
         out = {"count_matches": 0, "newlines": 0, "bytes": 0, "match_byte_offsets": [], "count_lines": 0,
@@ -74,7 +79,7 @@ def oracle_all_modes(oracle, blocks, pattern: bytes, exact=False, global_offsets
                 out["line_byte_offsets"] += [int(x) + g for x in oracle.byte_offsets_line(b, pattern)]
                 out["line_indices"] += [int(x) for x in oracle.line_indices(b, pattern, lb)]
                 beg, ln = oracle.lines_spans(b, pattern)
-                out["lines"] += [b[int(s):int(s + l)].tobytes() for s, l in zip(beg, ln)]
+                out["lines"] += [orig_blocks[i][int(s):int(s + l)].tobytes() for s, l in zip(beg, ln)]
                 out["lines_offsets"] += [int(s) + g for s in beg]
             nl = oracle.count_newlines(b)
             out["newlines"] += nl

@@ -193,3 +193,34 @@ def test_async_count_on_a_caller_stream(gs, oracle):
     with pytest.raises(xsg.XsgError) as e:
         gs.shard.count_async(xsg.COUNT_MATCHES, 0, ctr.data_ptr())
     assert e.value.code == xsg.ENOTSUP
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_ignore_case(gs, oracle, exact):
+    """XSG_FLAG_IGNORE_CASE == search(toLower(chunk), toLower(pattern))
+    (simd::toLower, src/utils/string_utils.cpp:11-33); lines keep original bytes."""
+    rng = np.random.default_rng(2718 + int(exact))
+    flags = xsg.FLAG_IGNORE_CASE | (xsg.FLAG_EXACT_TAIL if exact else 0)
+    alph = np.frombuffer(b"aAbB \ncC", dtype=np.uint8)
+    blocks = [alph[rng.integers(0, len(alph), size=int(n))].copy() for n in (5000, 16385, 40000, 33)]
+    gs.bind(blocks)
+    for p in (b"a", b"Ab", b"aBa", b"abAB", b"b A", b"ABCabc", b"aAbBcCaA", b"cab cab ab", b"a" * 20):
+        got = gs.all_modes(p, flags)
+        want = oracle_all_modes(oracle, blocks, p, exact, ignore_case=True)
+        assert_same(got, want, f"icase exact={exact} pat={p!r}")
+    # realistic text with upper-cased needles and non-ASCII bytes (must not fold)
+    tb = [corpus.text_block(91, i, 500_000, needle_rate=5e-4) for i in range(3)]
+    for b in tb:
+        pos = rng.integers(0, b.size - 64, size=200)
+        for q in pos:
+            seg = b[q:q + 40]
+            up = (seg >= 97) & (seg <= 122)
+            seg[up] -= 32
+        b[rng.integers(0, b.size, size=500)] = rng.integers(128, 256, size=500).astype(np.uint8)
+        b[-1] = 10
+    gs.bind(tb)
+    for p in (b"sherlock", b"SHERLOCK", b"Sherlock Holmes", b"tHe", b"E", b"\xc0\xe0"):
+        got = gs.all_modes(p, flags)
+        want = oracle_all_modes(oracle, tb, p, exact, ignore_case=True)
+        assert_same(got, want, f"icase text exact={exact} pat={p!r}")
+        assert want["count_matches"] >= oracle_all_modes(oracle, tb, p, exact)["count_matches"]

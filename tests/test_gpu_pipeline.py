@@ -209,3 +209,18 @@ def test_reference_style_searcher_functors(files, oracle, threads):
     assert r.returncode == 0, r.stderr.decode()
     counts = {int(l.split()[1]): int(l.split()[2]) for l in r.stdout.split(b"\n")[:-1]}
     assert [counts[i] for i in range(len(chunks))] == [oracle.count(b, pat, True) for b in chunks]
+
+
+def test_cpp_extern_search_ignore_case(files, oracle):
+    """xs::extern_search<Tag>(pattern, file, /*ignore_case=*/true, threads) -- test/src/xsearchTest.cpp:350"""
+    data = np.fromfile(files["txt"], dtype=np.uint8)
+    plan = xsg.plan_chunks(files["txt"], CHUNK)
+    chunks = [data[int(c["original_offset"]):int(c["original_offset"] + c["original_size"])] for c in plan]
+    want = oracle_all_modes(oracle, chunks, b"sHERLOCK", ignore_case=True)
+    assert want["count_matches"] >= files["want"][b"Sherlock"]["count_matches"] > 0
+    r = run_cli("count", "join", "sHERLOCK", files["txt"], "-", "2", env={"XS_IGNORE_CASE": "1"})
+    assert r.returncode == 0 and int(r.stdout) == want["count_matches"]
+    r = run_cli("lines", "live", "sHERLOCK", files["txt"], "-", "2", env={"XS_IGNORE_CASE": "1"})
+    assert r.returncode == 0 and r.stdout.split(b"\n")[:-1] == want["lines"]
+    r = run_cli("count", "join", "sHERLOCK", files["txt"], "-", "2")
+    assert r.returncode == 0 and int(r.stdout) == 0

@@ -32,6 +32,7 @@ def hm():
     lib.hm_count_matches_borderfree.restype = u64
     lib.hm_count_lines.argtypes = [vp, u64, C.c_char_p, u32, ci, u32]
     lib.hm_count_lines.restype = u64
+    lib.hm_set_icase.argtypes = [ci]
     return lib
 
 
@@ -117,3 +118,31 @@ def test_model_tail_decoys(hm, oracle):
         data = np.concatenate([body, tail])
         check_case(hm, oracle, data, p, 0)
         check_case(hm, oracle, data, p, 1)
+
+
+def test_model_ignore_case(hm, oracle):
+    """ignore_case = search(toLower(chunk), toLower(pattern)): the device folds bytes
+    on the fly (xsg::fold / fold4) and uses a lowered pattern."""
+    rng = np.random.default_rng(31337)
+    alph = np.frombuffer(b"aAbB \nxX", dtype=np.uint8)
+    pats = [b"a", b"Ab", b"aBa", b"ABAB", b"b A", b"Xx", b"aab", b"abABabAB"]
+    hm.hm_set_icase(1)
+    try:
+        for it in range(3000):
+            n = int(rng.integers(0, 300))
+            data = alph[rng.integers(0, len(alph), size=n)].copy()
+            p = pats[int(rng.integers(0, len(pats)))]
+            lowered = oracle.lower(data)
+            pl = p.lower()
+            for exact in (0, 1):
+                oracle.set_exact(bool(exact))
+                want_m = oracle.byte_offsets_match(lowered, pl).tolist()
+                want_l = oracle.byte_offsets_line(lowered, pl).tolist()
+                want_c = oracle.count(lowered, pl, True)
+                oracle.set_exact(False)
+                assert _list(hm, data, pl, exact, 0) == want_m
+                assert _list(hm, data, pl, exact, 1) == want_l
+                assert hm.hm_count_lines(data.ctypes.data, data.size, pl, len(pl), exact, 64) == want_c
+    finally:
+        hm.hm_set_icase(0)
+        oracle.set_exact(False)

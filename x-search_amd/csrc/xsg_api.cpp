@@ -90,7 +90,7 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
   }
   if (const char* tk = getenv("XSG_TILE_KIB")) {
     const int v = atoi(tk);
-    if (v == 16 || v == 32) c->tile_bytes = (uint32_t)v * 1024u;
+    if (v == 16) c->tile_bytes = (uint32_t)v * 1024u;
   }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -131,10 +131,13 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   if (!c) return fail(XSG_EINVAL, "ctx is null");
   if (!pattern || plen == 0) return fail(XSG_EINVAL, "empty pattern");
   if (plen > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "pattern longer than %u bytes", XSG_MAX_PATTERN);
-  if (flags & ~XSG_FLAG_EXACT_TAIL) return fail(XSG_EINVAL, "unknown pattern flags 0x%x", flags);
+  if (flags & ~(XSG_FLAG_EXACT_TAIL | XSG_FLAG_IGNORE_CASE)) return fail(XSG_EINVAL, "unknown pattern flags 0x%x", flags);
   HIP_TRY(hipSetDevice(c->device));
-  const uint8_t* p = static_cast<const uint8_t*>(pattern);
-  c->pattern.assign(p, p + plen);
+  c->pattern.assign(static_cast<const uint8_t*>(pattern), static_cast<const uint8_t*>(pattern) + plen);
+  if (flags & XSG_FLAG_IGNORE_CASE)  // simd::toLower on the pattern (string_utils.cpp:11-33)
+    for (uint8_t& b : c->pattern)
+      if (b >= 'A' && b <= 'Z') b = (uint8_t)(b + 32);
+  const uint8_t* p = c->pattern.data();
   c->flags = flags;
   // border <=> the pattern can overlap itself (KMP failure function of the last position > 0)
   std::vector<uint32_t> pi(plen, 0);
@@ -166,6 +169,7 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;
   P.has_newline = memchr(p, '\n', plen) != nullptr;
+  P.icase = (flags & XSG_FLAG_IGNORE_CASE) ? 1u : 0u;
   return XSG_OK;
 }
 

@@ -47,6 +47,7 @@ struct PatternDev {
   const uint8_t* d_pat;     // device copy of the pattern
   uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL
   uint32_t has_newline;     // pattern contains '\n'
+  uint32_t icase;           // XSG_FLAG_IGNORE_CASE: data bytes are ASCII-lowered before every compare (pattern is lowered on the host)
 };
 
 // Per-tile line summaries (XSG_COUNT_LINES): see xsg_linesum.h.

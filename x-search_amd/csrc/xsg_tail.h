@@ -33,36 +33,41 @@ XSG_HD uint64_t tail_zone_begin(uint64_t L, uint32_t plen) {
   return L > z ? L - z : 0;
 }
 
+// simd::toLower on one byte (src/utils/string_utils.cpp:11-33): 'A'..'Z' -> 'a'..'z'.
+// With icase the pattern has already been lowered by the host.
+XSG_HD uint8_t fold(uint8_t b, bool icase) { return (icase && b >= 'A' && b <= 'Z') ? (uint8_t)(b + 32) : b; }
+
 // scalar_strstr (simd_search.cpp:58-78) on d[from, L): absolute offset or -1.
-XSG_HD int64_t lossy_scalar_find(const uint8_t* d, uint64_t from, uint64_t L, const uint8_t* pat, uint32_t plen) {
+XSG_HD int64_t lossy_scalar_find(const uint8_t* d, uint64_t from, uint64_t L, const uint8_t* pat, uint32_t plen,
+                                 bool icase) {
   uint64_t shift = from;
   while (shift < L) {
     if (L - shift < plen) return -1;
     uint32_t k = 0;
-    while (k < plen && d[shift + k] == pat[k]) ++k;
+    while (k < plen && fold(d[shift + k], icase) == pat[k]) ++k;
     if (k == plen) return (int64_t)shift;
     shift += (uint64_t)k + 1u;
   }
   return -1;
 }
 
-XSG_HD bool occurs_at(const uint8_t* d, uint64_t o, const uint8_t* pat, uint32_t plen) {
+XSG_HD bool occurs_at(const uint8_t* d, uint64_t o, const uint8_t* pat, uint32_t plen, bool icase) {
   for (uint32_t k = 0; k < plen; ++k)
-    if (d[o + k] != pat[k]) return false;
+    if (fold(d[o + k], icase) != pat[k]) return false;
   return true;
 }
 
 // findNext(pattern, d, L, shift) (simd_search.cpp:289-295) for plen >= 2,
 // GIVEN that no occurrence starts in [shift, Z) (the bulk scan found none).
 XSG_HD int64_t tail_find_next(const uint8_t* d, uint64_t L, const uint8_t* pat, uint32_t plen, uint64_t shift,
-                              uint64_t Z) {
+                              uint64_t Z, bool icase) {
   if (shift > L) return -1;
   const uint64_t R = L - shift;
-  if (R < 32u + (uint64_t)plen) return lossy_scalar_find(d, shift, L, pat, plen);
+  if (R < 32u + (uint64_t)plen) return lossy_scalar_find(d, shift, L, pat, plen, icase);
   const uint64_t T = shift + 32u * ((R - plen) / 32u);  // end of the exact 32-byte-block part; Z <= T <= L-plen
   for (uint64_t o = shift > Z ? shift : Z; o < T; ++o)
-    if (occurs_at(d, o, pat, plen)) return (int64_t)o;
-  return lossy_scalar_find(d, T, L, pat, plen);
+    if (occurs_at(d, o, pat, plen, icase)) return (int64_t)o;
+  return lossy_scalar_find(d, T, L, pat, plen, icase);
 }
 
 XSG_HD int64_t next_newline(const uint8_t* d, uint64_t from, uint64_t L) {
@@ -81,13 +86,13 @@ XSG_HD int64_t next_newline(const uint8_t* d, uint64_t from, uint64_t L) {
 //   out        : receives up to cap match offsets (chunk-local); may be null
 // Returns the number of matches the walk finds in the zone.
 XSG_HD uint32_t tail_walk(const uint8_t* d, uint64_t L, const uint8_t* pat, uint32_t plen, uint64_t shift0,
-                          bool skip_to_nl, uint64_t* out, uint32_t cap) {
+                          bool skip_to_nl, uint64_t* out, uint32_t cap, bool icase = false) {
   if (plen <= 1 || shift0 == UINT64_MAX) return 0;
   const uint64_t Z = tail_zone_begin(L, plen);
   uint32_t n = 0;
   uint64_t shift = shift0;
   while (shift < L) {
-    const int64_t m = tail_find_next(d, L, pat, plen, shift, Z);
+    const int64_t m = tail_find_next(d, L, pat, plen, shift, Z, icase);
     if (m < 0) break;
     if (out && n < cap) out[n] = (uint64_t)m;
     ++n;

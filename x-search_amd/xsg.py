@@ -21,6 +21,7 @@ EINVAL, ENODEV, EHIP, ENOMEM, ENOTSUP, EIO, ESTATE = -1, -2, -3, -4, -5, -6, -7
 
 COUNT_MATCHES, COUNT_LINES, MATCH_BYTE_OFFSETS, LINE_BYTE_OFFSETS, LINE_INDICES, LINES = range(6)
 FLAG_EXACT_TAIL = 0x1
+FLAG_IGNORE_CASE = 0x2
 WITH_NEWLINES = 0x100
 CTR_MATCHES, CTR_LINES, CTR_NEWLINES, CTR_BYTES = range(4)
 NUM_COUNTERS = 4
