@@ -136,13 +136,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal hook (not used by the driver): XSG_BENCH_BACKEND=gloo runs the N>1 code path on a box with
+    # fewer GPUs than ranks (all ranks scan on the visible GPUs, the collective goes through host memory).
+    backend = os.environ.get("XSG_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     pattern = args.pattern.encode("latin-1")
     t_setup = time.perf_counter()
@@ -170,7 +178,7 @@ def main():
 
     goffs = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.uint64) + np.uint64(rank) * np.uint64(shard_bytes)
     chunks = xsg.make_chunks(off, ln, goffs)
-    ctx = xsg.Context(local_rank)
+    ctx = xsg.Context(dev_index)
     ctx.set_pattern(pattern)
     shard = xsg.Shard(ctx, shard_t.data_ptr(), cap, chunks)
     counters = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device=dev)
@@ -181,9 +189,20 @@ def main():
     assert stream.cuda_stream != 0
     setup_s = time.perf_counter() - t_setup
 
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+
+    def all_reduce_(t, op=None):
+        """in-place all-reduce of a device tensor (through host memory only in the gloo rehearsal)"""
+        if backend == "nccl":
+            dist.all_reduce(t) if op is None else dist.all_reduce(t, op=op)
+        else:
+            h = t.to(coll_dev)
+            dist.all_reduce(h) if op is None else dist.all_reduce(h, op=op)
+            t.copy_(h)
+
     if dist is not None:
         exp = torch.tensor([expected_local], dtype=torch.int64, device=dev)
-        dist.all_reduce(exp)
+        all_reduce_(exp)
         expected_total = int(exp.item())
     else:
         expected_total = expected_local
@@ -191,7 +210,7 @@ def main():
     def step():
         shard.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, counters.data_ptr())
         if dist is not None:
-            dist.all_reduce(counters)  # RCCL sum of the 4 uint64 counters, same stream order
+            all_reduce_(counters)  # RCCL sum of the 4 uint64 counters, same stream order
 
     def sync_all():
         torch.cuda.synchronize()
@@ -216,7 +235,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        all_reduce_(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     bad = [int(x) for x in results.cpu().tolist() if int(x) != expected_total]
     if bad:

@@ -224,3 +224,29 @@ def test_cpp_extern_search_ignore_case(files, oracle):
     assert r.returncode == 0 and r.stdout.split(b"\n")[:-1] == want["lines"]
     r = run_cli("count", "join", "sHERLOCK", files["txt"], "-", "2")
     assert r.returncode == 0 and int(r.stdout) == 0
+
+
+def test_xsgrep_equals_gnu_grep(tmp_path):
+    """tools/xsgrep (the reference's example/grep.cpp on this engine) against GNU grep
+    on a clean, newline-terminated file: same lines, same -c count, same -i behaviour."""
+    import shutil
+    exe = ROOT / "tools" / "build" / "xsgrep"
+    if not exe.exists():
+        pytest.fail(f"{exe} not built (make -C tools)")
+    if not shutil.which("grep"):
+        pytest.skip("no GNU grep on this host")
+    data = np.concatenate([corpus.text_block(404, i, 2_500_000, needle_rate=3e-4) for i in range(4)])
+    # pad the end so that no needle sits in the reference's lossy end-of-chunk zone of the LAST chunk
+    data = np.concatenate([data, np.frombuffer(b"the end of the file is plain text without the needle\n" * 2, dtype=np.uint8)])
+    p = tmp_path / "g.txt"
+    data.tofile(p)
+    import os
+    env = dict(os.environ, XS_CHUNK_BYTES=str(1 << 30), LC_ALL="C")  # one chunk: grep has no chunk-end quirk
+    for args in (["Sherlock"], ["-i", "sherlock"], ["-i", "HOLMES"], ["locked"]):
+        want = subprocess.run(["grep", "-F", *args, str(p)], capture_output=True, env=env).stdout
+        got = subprocess.run([str(exe), "-j", "2", *args, str(p)], capture_output=True, env=env, timeout=120)
+        assert got.returncode == 0, got.stderr.decode()
+        assert got.stdout == want, args
+        wc = subprocess.run(["grep", "-F", "-c", *args, str(p)], capture_output=True, env=env).stdout
+        gc = subprocess.run([str(exe), "-c", *args, str(p)], capture_output=True, env=env, timeout=120).stdout
+        assert gc == wc, args

@@ -1,0 +1,68 @@
+// xsgrep -- the reference's example/grep.cpp (PATTERN FILE, -c, -i; lines 23-82)
+// on the MI355X engine, without boost::program_options.
+//
+//   xsgrep [-c] [-i] [-j THREADS] [-m METAFILE] PATTERN FILE
+//
+// -c  print only a count of matching lines   (grep.cpp:45-46 -> xs::count_lines)
+// -i  ignore ASCII case                      (grep.cpp:47-48)
+// otherwise print the matching lines, live, as they are found (grep.cpp:74-79).
+#include <xsearch/xsearch.h>
+
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+int main(int argc, char** argv) {
+  bool count = false, icase = false;
+  int threads = 2;  // grep.cpp:21
+  std::string meta, pattern, file;
+  int pos = 0;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "-c" || a == "--count") {
+      count = true;
+    } else if (a == "-i" || a == "--ignore-case") {
+      icase = true;
+    } else if ((a == "-j" || a == "--threads") && i + 1 < argc) {
+      threads = std::atoi(argv[++i]);
+    } else if ((a == "-m" || a == "--meta") && i + 1 < argc) {
+      meta = argv[++i];
+    } else if (a == "-h" || a == "--help") {
+      std::printf("usage: %s [-c] [-i] [-j THREADS] [-m METAFILE] PATTERN FILE\n", argv[0]);
+      return 0;
+    } else if (pos == 0) {
+      pattern = a;
+      ++pos;
+    } else if (pos == 1) {
+      file = a;
+      ++pos;
+    } else {
+      std::fprintf(stderr, "unexpected argument '%s'\n", a.c_str());
+      return 2;
+    }
+  }
+  if (pos != 2) {
+    std::fprintf(stderr, "usage: %s [-c] [-i] [-j THREADS] [-m METAFILE] PATTERN FILE\n", argv[0]);
+    return 2;
+  }
+  try {
+    std::ios::sync_with_stdio(false);
+    if (count) {
+      auto searcher = meta.empty() ? xs::extern_search<xs::count_lines>(pattern, file, icase, threads)
+                                   : xs::extern_search<xs::count_lines>(pattern, file, meta, icase, threads, threads);
+      searcher->join();
+      std::cout << searcher->getResult()->size() << std::endl;
+    } else {
+      auto searcher = meta.empty() ? xs::extern_search<xs::lines>(pattern, file, icase, threads)
+                                   : xs::extern_search<xs::lines>(pattern, file, meta, icase, threads, threads);
+      for (auto const& line : *searcher->getResult()) {
+        std::cout << line << '\n';
+      }
+    }
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "xsgrep: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
