@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "xsg_objects.h"
+#include "xsg_linesum.h"
 #include "xsg_tail.h"
 
 using namespace xsg;
@@ -216,7 +217,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
 
   XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
   XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
-  XSG_TRY(s->d_chunk_last.ensure(8 * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_chunk_last.ensure(4 * std::max<uint64_t>(ntiles, 1)));  // tile_last
   XSG_TRY(s->d_tile_cnt.ensure(4 * std::max<uint64_t>(ntiles, 1)));
   XSG_TRY(s->d_counters.ensure(8 * XSG_NUM_COUNTERS));
   static_assert(sizeof(ChunkDev) == sizeof(xsg_chunk), "layout");
@@ -291,7 +292,7 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
   a.tile_nl = s->d_tile_nl.as<uint32_t>();
   a.tile_sum = s->d_tile_sum.as<uint32_t>();
-  a.chunk_last_end = s->d_chunk_last.as<unsigned long long>();
+  a.tile_last = s->d_chunk_last.as<uint32_t>();
   return a;
 }
 
@@ -301,12 +302,24 @@ static int check_ready(xsg_shard* s) {
   return XSG_OK;
 }
 
+// k_scan only writes where a wave found something: preset what "nothing found" looks like.
+static int preset_tile_arrays(xsg_shard* s, bool want_lines, hipStream_t st) {
+  const uint64_t nchunks = s->chunks.size();
+  (void)nchunks;
+  HIP_TRY(hipMemsetAsync(s->d_chunk_last.p, 0, 4 * std::max<uint64_t>(s->ntiles, 1), st));  // tile_last
+  HIP_TRY(hipMemsetAsync(s->d_tile_cnt.p, 0, 4 * std::max<uint64_t>(s->ntiles, 1), st));
+  if (want_lines) {
+    XSG_TRY(s->d_tile_sum.ensure(4 * kWaves * std::max<uint64_t>(s->ntiles, 1)));
+    if (s->ntiles) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_tile_sum.p, (int)kSumNl, kWaves * s->ntiles, st));
+  }
+  return XSG_OK;
+}
+
 static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool want_nl, hipStream_t st,
                          uint64_t* d_counters) {
   if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
-  if (want_lines) XSG_TRY(s->d_tile_sum.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
   const uint64_t nchunks = s->chunks.size();
-  HIP_TRY(hipMemsetAsync(s->d_chunk_last.p, 0, 8 * std::max<uint64_t>(nchunks, 1), st));
+  XSG_TRY(preset_tile_arrays(s, want_lines, st));
   HIP_TRY(hipMemsetAsync(d_counters, 0, 8 * XSG_NUM_COUNTERS, st));
   ScanArgs a = scan_args(s);
   HIP_TRY(launch_scan_count(a, want_nl, want_lines, st));
@@ -320,7 +333,8 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   f.tile_cnt = a.tile_cnt;
   f.tile_nl = a.tile_nl;
   f.tile_sum = a.tile_sum;
-  f.chunk_last_end = a.chunk_last_end;
+  f.tile_last = a.tile_last;
+  f.tile_bytes = s->tile_bytes;
   f.counters = d_counters;
   f.want_nl = want_nl;
   f.want_lines = want_lines;
@@ -390,8 +404,7 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
   const bool want_lines = m == XSG_COUNT_LINES;
   if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
-  if (want_lines) XSG_TRY(s->d_tile_sum.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
-  HIP_TRY(hipMemsetAsync(s->d_chunk_last.p, 0, 8 * std::max<size_t>(s->chunks.size(), 1), c->stream));
+  XSG_TRY(preset_tile_arrays(s, want_lines, c->stream));
   ScanArgs a = scan_args(s);
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
@@ -442,6 +455,32 @@ extern "C" int xsg_time_read_ceiling(xsg_shard* s, int iters, float* avg_ms, uin
   return time_read(s, s->tile_bytes, 0, iters, avg_ms, bytes_per_launch);
 }
 
+// not in xsg.h: where does k_scan lose against the pure read? (scripts/perf_sweep.py)
+extern "C" int xsg_diag_read_probe(xsg_shard* s, int parts, int iters, float* avg_ms) {
+  if (!s || !avg_ms || iters <= 0) return fail(XSG_EINVAL, "bad argument");
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  if (s->chunks.empty() || s->chunks.front().offset != 0) return fail(XSG_ESTATE, "probe needs a shard that starts at offset 0");
+  ScanArgs a = scan_args(s);
+  // flat span: from the buffer start to the end of the last chunk, never past the capacity
+  const uint64_t flat = std::min<uint64_t>(s->chunks.back().offset + s->chunks.back().length, s->capacity);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  uint32_t* sink = s->d_counters.as<uint32_t>();
+  HIP_TRY(launch_read_probe(a, parts, flat, sink, c->stream));
+  HIP_TRY(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch_read_probe(a, parts, flat, sink, c->stream));
+  HIP_TRY(hipEventRecord(e1, c->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / (float)iters;
+  return XSG_OK;
+}
+
 // not in xsg.h: access-pattern experiments for scripts/perf_sweep.py
 extern "C" int xsg_diag_read_variant(xsg_shard* s, uint32_t tile_bytes, int variant, int iters, float* avg_ms,
                                      uint64_t* bytes_per_launch) {
@@ -473,7 +512,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
 
   // 1. bulk count per tile
   if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(ntiles, 1)));
-  HIP_TRY(hipMemsetAsync(s->d_chunk_last.p, 0, 8 * std::max<uint64_t>(nchunks, 1), st));
+  XSG_TRY(preset_tile_arrays(s, false, st));
   ScanArgs a = scan_args(s);
   HIP_TRY(launch_scan_count(a, want_nl, false, st));
 

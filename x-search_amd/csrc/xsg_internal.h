@@ -61,10 +61,10 @@ struct ScanArgs {
   uint32_t tile_bytes;          // 16384 or 32768 (selects the k_scan instantiation)
   PatternDev pat;
   // outputs of the counting pass
-  uint32_t* tile_cnt;                  // matches starting in the tile (o < limit)
+  uint32_t* tile_cnt;                  // matches starting in the tile (o < limit); ZEROED by the host before the pass
   uint32_t* tile_nl;                   // '\n' in the tile              (WANT_NL)
-  uint32_t* tile_sum;                  // line summary                  (WANT_LINES)
-  unsigned long long* chunk_last_end;  // max (match offset + plen) per chunk, chunk-local
+  uint32_t* tile_sum;                  // line summary PER WAVE (4 per tile), preset to kSumNl (WANT_LINES)
+  uint32_t* tile_last;                 // max (match offset + plen) in the tile, relative to the tile start; ZEROED by the host
   // inputs/outputs of the emit pass
   const uint64_t* tile_off;  // exclusive prefix of tile_cnt
   uint64_t* m_pos;           // chunk-local offset of every match, ascending
@@ -81,7 +81,8 @@ struct FinishArgs {
   const uint32_t* tile_cnt;
   const uint32_t* tile_nl;
   const uint32_t* tile_sum;
-  const unsigned long long* chunk_last_end;
+  const uint32_t* tile_last;
+  uint32_t tile_bytes;
   uint64_t* counters;  // XSG_NUM_COUNTERS, zeroed before the launch
   uint32_t want_nl;
   uint32_t want_lines;
@@ -92,6 +93,7 @@ struct FinishArgs {
 hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s);
 hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s);
 hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s);
+hipError_t launch_read_probe(const ScanArgs& a, int parts, uint64_t flat_bytes, uint32_t* sink, hipStream_t s);
 hipError_t launch_read_ceiling(const uint8_t* base, uint64_t bytes, uint32_t tile_bytes, int variant, uint32_t* sink,
                                hipStream_t s);
 

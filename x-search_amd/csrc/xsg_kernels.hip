@@ -209,8 +209,6 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   constexpr uint32_t kTile = kWaveSpan * kWaves;         // bytes per workgroup
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
-  __shared__ uint32_t s_sum[kWaves];
-  __shared__ unsigned long long s_last[kWaves];
   __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND == kLong ? XSG_MAX_PATTERN : 16];
 
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
@@ -328,31 +326,29 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   }
 
   if (!EMIT) {
-    // ---- block reduction -> one store per output per tile
-    const uint32_t wc = wave_sum_u32(cnt);
-    const uint32_t wn = WANT_NL ? wave_sum_u32(nlc) : 0u;
-    const uint64_t wl = wc ? wave_max_u64(last_end) : 0u;
-    if (lane == 0) {
-      s_cnt[wave] = wc;
-      s_nl[wave] = wn;
-      s_last[wave] = wl;
-      s_sum[wave] = wsum;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t tc = 0, tn = 0, ts = s_sum[0];
-      unsigned long long tl = 0;
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) {
-        tc += s_cnt[w];
-        tn += s_nl[w];
-        tl = s_last[w] > tl ? s_last[w] : tl;
-        if (w) ts = sum_combine(ts, s_sum[w]);
+    // ---- epilogue.  A store per tile, however small, interleaves writes into the
+    // read stream (DRAM bus turnarounds): a probe kernel with k_scan's loads lost
+    // 2-4 % to it (scripts/probe_parts.py).  So the per-tile arrays are preset by the
+    // host (tile_cnt = 0, tile_sum = "has a newline, no match") and only waves that
+    // found something else write: no LDS, no barrier, no store on the common path.
+    if (__any(cnt != 0)) {
+      const uint32_t wc = wave_sum_u32(cnt);
+      const uint64_t wl = wave_max_u64(last_end);
+      if (lane == 0) {
+        // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
+        // cut dense patterns to a third)
+        atomicAdd(A.tile_cnt + tile, wc);
+        atomicMax(A.tile_last + tile, (uint32_t)(wl - toff));  // >= 1: end of the last match, relative to the tile
       }
-      A.tile_cnt[tile] = tc;
-      if (WANT_NL) A.tile_nl[tile] = tn;
-      if (WANT_LINES) A.tile_sum[tile] = ts;
-      if (tc) atomicMax(A.chunk_last_end + c, tl);
+    }
+    if (WANT_LINES) {
+      if (lane == 0 && wsum != kSumNl) A.tile_sum[tile * kWaves + wave] = wsum;
+    }
+    if (WANT_NL) {  // every wave has newlines to report: one store per tile through LDS
+      const uint32_t wn = wave_sum_u32(nlc);
+      if (lane == 0) s_nl[wave] = wn;
+      __syncthreads();
+      if (tid == 0) A.tile_nl[tile] = s_nl[0] + s_nl[1] + s_nl[2] + s_nl[3];
     }
   } else {
     // ---- ordered emission: wave spans are consecutive, loads within a span
@@ -500,6 +496,82 @@ hipError_t launch_read_ceiling(const uint8_t* base, uint64_t bytes, uint32_t til
 }
 
 // ---------------------------------------------------------------------------
+// k_read_probe: diagnostic.  nt loads of k_scan's shape plus, optionally, k_scan's
+// prologue (bit 0: tile -> chunk lookups), its epilogue (bit 1: LDS + barrier +
+// one store per tile) and a stand-in for its ALU work (bit 2).  Tells where the
+// gap between k_scan and the pure read ceiling comes from.
+// ---------------------------------------------------------------------------
+template <int PARTS>
+__global__ __launch_bounds__(kBlock) void k_read_probe(const ScanArgs A, uint64_t ntiles, uint32_t* sink) {
+  __shared__ uint32_t s_x[kWaves];
+  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+  if (tile >= ntiles) return;  // ntiles: chunk tiles with the prologue, whole 16 KiB tiles of the flat span without
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint8_t* tbase;
+  uint64_t Lr = ~0ull, toff = 0;
+  if (PARTS & 1) {
+    const uint32_t c = A.tile_chunk ? A.tile_chunk[tile] : 0u;
+    const ChunkDev ch = A.chunks[c];
+    toff = (tile - A.chunk_tile0[c]) * (uint64_t)kDefaultTileBytes;
+    tbase = A.base + ch.offset + toff;
+    Lr = (ch.length + 15u) & ~(uint64_t)15u;
+  } else {
+    tbase = A.base + tile * (uint64_t)kDefaultTileBytes;
+  }
+  uint4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint64_t off = (uint64_t)wave * 4096u + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
+    if (PARTS & 1) off = toff + off < Lr - kUnit ? off : (Lr - kUnit - toff);
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tbase + off));
+    v[j] = make_uint4(t.x, t.y, t.z, t.w);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t x = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    x ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+    if (PARTS & 4) {  // ~60 dependent-free VALU ops per load, like the window compares
+      uint32_t a = v[j].x, b = v[j].y, c2 = v[j].z, d = v[j].w;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        a = __builtin_amdgcn_alignbyte(b, a, 1);
+        x += (a == A.pat.p0) + (b == A.pat.p1) + (c2 == A.pat.p0) + (d == A.pat.p1);
+        b ^= c2;
+      }
+    }
+  }
+  if (PARTS & 2) {
+    const uint32_t wx = wave_sum_u32(x);
+    if (lane == 0) s_x[wave] = wx;
+    __syncthreads();
+    if (threadIdx.x == 0) A.tile_cnt[tile] = (s_x[0] + s_x[1] + s_x[2] + s_x[3]) == 0xdeadbeefu;
+  } else {
+    if (x == 0xdeadbeefu) sink[0] = x;
+  }
+}
+
+hipError_t launch_read_probe(const ScanArgs& a, int parts, uint64_t flat_bytes, uint32_t* sink, hipStream_t s) {
+  // without the prologue the kernel walks a FLAT span: it must not exceed the buffer
+  const uint64_t ntiles = (parts & 1) ? a.ntiles : flat_bytes / kDefaultTileBytes;
+  if (!ntiles) return hipSuccess;
+  if (!(parts & 1) && (parts & 2) && ntiles > a.ntiles) return hipErrorInvalidValue;  // tile_cnt has a.ntiles entries
+  const uint64_t maxx = 1u << 30;
+  const dim3 grid = ntiles <= maxx ? dim3((unsigned)ntiles) : dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx));
+  switch (parts & 7) {
+    case 0: hipLaunchKernelGGL((k_read_probe<0>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
+    case 1: hipLaunchKernelGGL((k_read_probe<1>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
+    case 2: hipLaunchKernelGGL((k_read_probe<2>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
+    case 3: hipLaunchKernelGGL((k_read_probe<3>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
+    case 4: hipLaunchKernelGGL((k_read_probe<4>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
+    case 5: hipLaunchKernelGGL((k_read_probe<5>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
+    case 6: hipLaunchKernelGGL((k_read_probe<6>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
+    default: hipLaunchKernelGGL((k_read_probe<7>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // k_count_finish: sums the per-tile outputs and replays the reference walk
 // over every chunk's tail zone.  counters[] must be zero on entry.
 // ---------------------------------------------------------------------------
@@ -531,35 +603,56 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   __shared__ uint64_t sh[kWaves];
   const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint64_t gsz = (uint64_t)gridDim.x * kBlock;
+  const uint32_t lane = threadIdx.x & 63u;
 
   uint64_t cm = 0, cn = 0;
   for (uint64_t t = gid; t < A.ntiles; t += gsz) {
     if (A.want_matches) cm += A.tile_cnt[t];
     if (A.want_nl) cn += A.tile_nl[t];
   }
+  // one wave per chunk: where the walk stands at the end of the bulk part (from the
+  // last tile that holds a match), the chunk's matching lines, then its tail zone
   uint64_t lines = 0, bytes = 0;
-  for (uint64_t c = gid; c < A.nchunks; c += gsz) {
-    const ChunkDev ch = A.chunks[c];
-    const uint8_t* d = A.base + ch.offset;
-    bytes += ch.length;
-    if (A.want_lines) {
-      // combine the tile summaries of the chunk in order
-      const uint64_t t0 = A.chunk_tile0[c], t1 = A.chunk_tile0[c + 1];
-      if (t1 > t0) {
-        uint32_t s = A.tile_sum[t0];
-        for (uint64_t t = t0 + 1; t < t1; ++t) s = sum_combine(s, A.tile_sum[t]);
-        lines += sum_total_lines(s);
+  const uint64_t wave_id = gid >> 6, nwaves = gsz >> 6;
+  for (uint64_t c = wave_id; c < A.nchunks; c += nwaves) {
+    const uint64_t t0 = A.chunk_tile0[c], t1 = A.chunk_tile0[c + 1];
+    const bool need_tail = !A.pat.exact_tail && A.pat.plen > 1;
+    uint64_t last_end = 0;
+    if (need_tail) {
+      uint64_t t = t1;
+      while (t > t0 && last_end == 0) {  // wave-uniform
+        const uint64_t lo = t - t0 >= 64 ? t - 64 : t0;
+        const uint64_t idx = lo + lane;
+        const uint32_t v = idx < t ? A.tile_last[idx] : 0u;
+        const unsigned long long bal = __ballot(v != 0);
+        if (bal) {
+          const int hi = 63 - __clzll((long long)bal);
+          const uint32_t vv = (uint32_t)__shfl((int)v, hi);
+          last_end = (lo + (uint64_t)hi - t0) * (uint64_t)A.tile_bytes + vv;
+        }
+        t = lo;
       }
     }
-    if (!A.pat.exact_tail && A.pat.plen > 1) {
-      const uint64_t last_end = A.chunk_last_end[c];
-      if (A.want_matches) {
-        cm += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, false), false,
-                        nullptr, 0, A.pat.icase != 0);
+    if (A.want_lines) {
+      uint32_t run = 0;  // identity
+      for (uint64_t e = t0 * kWaves; e < t1 * kWaves; e += 64) {
+        const uint32_t v = e + lane < t1 * kWaves ? A.tile_sum[e + lane] : 0u;
+        const uint32_t r = wave_sum_combine(v, lane);
+        run = sum_combine(run, r);  // meaningful in lane 0
       }
-      if (A.want_lines) {
-        lines += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, true), true,
-                           nullptr, 0, A.pat.icase != 0);
+      if (lane == 0) lines += sum_total_lines(run);
+    }
+    if (lane == 0) {
+      const ChunkDev ch = A.chunks[c];
+      const uint8_t* d = A.base + ch.offset;
+      bytes += ch.length;
+      if (need_tail) {
+        if (A.want_matches)
+          cm += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, false), false,
+                          nullptr, 0, A.pat.icase != 0);
+        if (A.want_lines)
+          lines += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, true), true,
+                             nullptr, 0, A.pat.icase != 0);
       }
     }
   }
