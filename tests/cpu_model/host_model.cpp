@@ -152,4 +152,42 @@ uint64_t hm_count_lines(const uint8_t* d, uint64_t L, const uint8_t* p, uint32_t
   return lines;
 }
 
+
+// xsg::sum_combine_lanes (the ballot form k_scan uses per wave-load) against the
+// ordered reduction of the same 64 unit summaries.  Returns the number of mismatches.
+uint64_t hm_check_lane_combine(uint64_t seed, uint64_t iters) {
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1, bad = 0;
+  auto rnd = [&]() {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    return x;
+  };
+  for (uint64_t it = 0; it < iters; ++it) {
+    uint32_t us[64];
+    const int dens = (int)(rnd() % 5);
+    for (int l = 0; l < 64; ++l) {
+      uint32_t h = 0, n = 0;
+      for (int b = 0; b < 16; ++b) {
+        const int r = (int)(rnd() % (uint64_t)(4 + dens * 6));
+        if (r == 0) n |= 1u << b;
+        else if (r == 1) h |= 1u << b;
+      }
+      if (it % 7 == 0 && (rnd() & 1)) n = 0;
+      if (it % 11 == 0) h = 0;
+      us[l] = sum_of_unit(h, n);
+    }
+    uint32_t ref = us[0];
+    for (int l = 1; l < 64; ++l) ref = sum_combine(ref, us[l]);
+    unsigned long long N = 0, Fm = 0, Lm = 0;
+    uint32_t csum = 0;
+    for (int l = 0; l < 64; ++l) {
+      if (us[l] & kSumNl) N |= 1ull << l;
+      if (us[l] & kSumF) Fm |= 1ull << l;
+      if (us[l] & kSumL) Lm |= 1ull << l;
+      csum += us[l] >> kSumCShift;
+    }
+    bad += sum_combine_lanes(N, Fm, Lm, csum) != ref;
+  }
+  return bad;
+}
+
 }  // extern "C"

@@ -33,6 +33,8 @@ def hm():
     lib.hm_count_lines.argtypes = [vp, u64, C.c_char_p, u32, ci, u32]
     lib.hm_count_lines.restype = u64
     lib.hm_set_icase.argtypes = [ci]
+    lib.hm_check_lane_combine.argtypes = [u64, u64]
+    lib.hm_check_lane_combine.restype = u64
     return lib
 
 
@@ -146,3 +148,10 @@ def test_model_ignore_case(hm, oracle):
     finally:
         hm.hm_set_icase(0)
         oracle.set_exact(False)
+
+
+def test_lane_mask_combine_equals_ordered_reduction(hm):
+    """xsg::sum_combine_lanes (O(1) ballot algebra, used per wave-load on the GPU)
+    == the ordered 64-way sum_combine of the same unit summaries."""
+    assert hm.hm_check_lane_combine(1, 300000) == 0
+    assert hm.hm_check_lane_combine(99, 300000) == 0

@@ -75,6 +75,18 @@ __device__ __forceinline__ uint32_t wave_sum_combine(uint32_t v, uint32_t lane) 
   return v;
 }
 
+// Combined summary of the 64 consecutive units of one wave-load: ballots of the
+// lanes' unit summaries, then xsg_linesum.h's O(1) mask algebra (result wave-uniform).
+__device__ __forceinline__ uint32_t wave_units_combine(uint32_t us) {
+  const unsigned long long N = __ballot(us & kSumNl);
+  const unsigned long long Fm = __ballot(us & kSumF);
+  const unsigned long long Lm = __ballot(us & kSumL);
+  const uint32_t c = us >> kSumCShift;  // <= 7 closed segments inside one 16-byte unit
+  const uint32_t csum = (uint32_t)__popcll(__ballot(c & 1u)) + 2u * (uint32_t)__popcll(__ballot(c & 2u)) +
+                        4u * (uint32_t)__popcll(__ballot(c & 4u));
+  return sum_combine_lanes(N, Fm, Lm, csum);
+}
+
 // ---------------------------------------------------------------------------
 // per-unit byte tests
 // ---------------------------------------------------------------------------
@@ -260,7 +272,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
 
   uint32_t cnt = 0, nlc = 0;
   uint64_t last_end = 0;
-  uint32_t wsum = 0;  // line summary of the wave span so far (lane 0)
+  uint32_t wsum = 0;    // line summary of the wave span so far (lane 0); 0 is the identity
+  bool run_nl = false;  // the current run of match-less loads holds a newline (wave-uniform)
   uint32_t masks[kLoads];
 
 #pragma unroll
@@ -312,18 +325,20 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
         last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen;
       }
       if (WANT_LINES) {
-        // A wave-load without any match start (the common case) summarises to
-        // "has a newline or not": no cross-lane reduction needed.
-        uint32_t us;
+        // A wave-load without any match start (the common case) summarises to "has a
+        // newline or not", and a run of such loads to the OR of that: once a newline
+        // has been seen in the run, the remaining loads of the run need no test at all.
         if (__any(m != 0)) {
-          us = wave_sum_combine(sum_of_unit(m, nl_mask16(d)), lane);
-        } else {
-          us = __any(nl_any16(d)) ? kSumNl : 0u;
+          if (run_nl) wsum = sum_combine(wsum, kSumNl);
+          run_nl = false;
+          wsum = sum_combine(wsum, wave_units_combine(sum_of_unit(m, nl_mask16(d))));
+        } else if (!run_nl) {
+          run_nl = __any(nl_any16(d));
         }
-        wsum = j == 0 ? us : sum_combine(wsum, us);
       }
     }
   }
+  if (WANT_LINES && !EMIT && run_nl) wsum = sum_combine(wsum, kSumNl);
 
   if (!EMIT) {
     // ---- epilogue.  A store per tile, however small, interleaves writes into the
