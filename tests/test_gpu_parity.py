@@ -224,3 +224,55 @@ def test_ignore_case(gs, oracle, exact):
         want = oracle_all_modes(oracle, tb, p, exact, ignore_case=True)
         assert_same(got, want, f"icase text exact={exact} pat={p!r}")
         assert want["count_matches"] >= oracle_all_modes(oracle, tb, p, exact)["count_matches"]
+
+
+def test_many_tiny_chunks(gs, oracle):
+    """20 000 chunks of 0..600 bytes: every chunk is mostly 'tail zone', tiles hold
+    one chunk each, the finish kernels loop over many chunks per wave."""
+    rng = np.random.default_rng(606)
+    alph = np.frombuffer(b"ab \nSherlock", dtype=np.uint8)
+    sizes = rng.integers(0, 600, size=20000)
+    blocks = [alph[rng.integers(0, len(alph), size=int(n))].copy() for n in sizes]
+    gs.bind(blocks)
+    for p in (b"ab", b"Sher", b"ba b", b"lock\nS"):
+        for exact in (False, True):
+            got = gs.all_modes(p, xsg.FLAG_EXACT_TAIL if exact else 0, lines=(p != b"ba b"))
+            want = oracle_all_modes(oracle, blocks, p, exact)
+            if p == b"ba b":
+                want = {k: want[k] for k in ("count_matches", "newlines", "bytes", "match_byte_offsets")}
+            assert_same(got, want, f"tiny chunks pat={p!r} exact={exact}")
+
+
+def test_all_byte_values_and_long_patterns(gs, oracle):
+    rng = np.random.default_rng(77)
+    data = rng.integers(0, 256, size=300_000).astype(np.uint8)
+    # plant long patterns (incl. the maximum length) across tile / wave / load boundaries
+    pats = [bytes(rng.integers(0, 256, size=n).astype(np.uint8)).replace(b"\n", b"\x0b") for n in (9, 16, 17, 64, 1000, 1024)]
+    for k, p in enumerate(pats):
+        for pos in (16384 * (k + 1) - len(p) // 2, 4096 * (k + 3) - 3, 1024 * (k + 40) - 1, 200_000 + 2000 * k):
+            data[pos:pos + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    data[-len(pats[0]):] = np.frombuffer(pats[0], dtype=np.uint8)  # a match ending exactly at the chunk end
+    blocks = [data[:150_001].copy(), data[150_001:].copy()]
+    gs.bind(blocks)
+    for p in pats + [b"\x00", b"\xff\xff", bytes([0x80, 0x41, 0xc3])]:
+        for exact in (False, True):
+            got = gs.all_modes(p, xsg.FLAG_EXACT_TAIL if exact else 0)
+            want = oracle_all_modes(oracle, blocks, p, exact)
+            assert_same(got, want, f"bytes pat[{len(p)}] exact={exact}")
+    assert oracle_all_modes(oracle, blocks, pats[4], True)["count_matches"] >= 3
+
+
+def test_one_big_chunk_with_long_lines(gs, oracle):
+    """A single 40 MB chunk whose lines are up to 3 MB long (line starts far from
+    their matches; many tiles without any newline)."""
+    rng = np.random.default_rng(5150)
+    b = corpus.text_block(808, 0, 40_000_000, needle_rate=2e-4)
+    nl = np.flatnonzero(b == 10)
+    keep = set(rng.choice(nl[:-1], size=60, replace=False).tolist()) | {int(nl[-1])}
+    kill = np.array([i for i in nl if int(i) not in keep])
+    b[kill] = 32
+    gs.bind([b])
+    for p in (b"Sherlock", b"Holmes", b"q"):
+        got = gs.all_modes(p)
+        want = oracle_all_modes(oracle, [b], p)
+        assert_same(got, want, f"long lines pat={p!r}")
