@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--threads", default="1,2,4,8,16")
     ap.add_argument("--modes", default="count,count_lines,match_byte_offsets,lines")
+    ap.add_argument("--meta", default="", help="also run through a metafile: comma list of none,lz4,zst")
     a = ap.parse_args()
     import xsg
     from xs_oracle import Oracle
@@ -42,23 +43,40 @@ def main():
     want = sum(tc[int(c)] for c in plan)
     modes = {"count": xsg.COUNT_MATCHES, "count_lines": xsg.COUNT_LINES, "match_byte_offsets": xsg.MATCH_BYTE_OFFSETS,
              "lines": xsg.LINES, "line_indices": xsg.LINE_INDICES, "line_byte_offsets": xsg.LINE_BYTE_OFFSETS}
+    variants = [("plain", path, None)]
+    made = []
+    for kind in [k for k in a.meta.split(",") if k]:
+        comp = {"none": xsg.COMPRESSION_NONE, "lz4": xsg.COMPRESSION_LZ4, "zst": xsg.COMPRESSION_ZSTD}[kind]
+        mp, dp = path + f".{kind}.meta", path + f".{kind}"
+        t0 = time.perf_counter()
+        xsg.meta_write(path, mp, dp, comp)
+        made += [mp, dp]
+        dsz = os.path.getsize(dp) if comp != xsg.COMPRESSION_NONE else size
+        print(json.dumps({"preprocess": kind, "seconds": round(time.perf_counter() - t0, 2),
+                          "compressed_gib": round(dsz / 2**30, 3)}), flush=True)
+        variants.append((kind, dp if comp != xsg.COMPRESSION_NONE else path, mp))
     try:
+      for vname, dpath, mpath in variants:
         for name in a.modes.split(","):
             for th in [int(x) for x in a.threads.split(",")]:
                 t0 = time.perf_counter()
-                j = xsg.Job(b"Sherlock", path, modes[name], num_threads=th, num_max_readers=th)
+                j = xsg.Job(b"Sherlock", dpath, modes[name], meta_path=mpath, num_threads=th, num_max_readers=th)
                 r = j.result()
                 dt = time.perf_counter() - t0
                 st = j.stats()
                 j.close()
                 got = r if isinstance(r, int) else len(r)
                 ok = (got == want) if name in ("count", "match_byte_offsets") else None
-                print(json.dumps({"mode": name, "threads": th, "gib": round(size / 2**30, 2), "seconds": round(dt, 3),
+                print(json.dumps({"input": vname, "mode": name, "threads": th, "gib": round(size / 2**30, 2), "seconds": round(dt, 3),
                                   "gib_per_s": round(size / dt / 2**30, 2), "result": got, "parity": ok,
-                                  "read_s": round(st["seconds_read"], 2), "device_s": round(st["seconds_device"], 2)}),
+                                  "read_s": round(st["seconds_read"], 2), "decompress_s": round(st["seconds_decompress"], 2),
+                                  "device_s": round(st["seconds_device"], 2)}),
                       flush=True)
     finally:
         os.unlink(path)
+        for f in made:
+            if os.path.exists(f):
+                os.unlink(f)
 
 
 if __name__ == "__main__":

@@ -250,3 +250,50 @@ def test_xsgrep_equals_gnu_grep(tmp_path):
         wc = subprocess.run(["grep", "-F", "-c", *args, str(p)], capture_output=True, env=env).stdout
         gc = subprocess.run([str(exe), "-c", *args, str(p)], capture_output=True, env=env, timeout=120).stdout
         assert gc == wc, args
+
+
+def _dist_gpu_worker(rank, world, port, path, chunk_bytes, q):
+    import os
+    import sys
+    for p in (ROOT / "x-search_amd", ROOT / "oracle", ROOT / "tests"):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import dist_search
+    import xsg as x
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # one GPU on this box: collectives via gloo
+    out = {}
+    for mode in (x.COUNT_MATCHES, x.COUNT_LINES, x.LINE_INDICES, x.MATCH_BYTE_OFFSETS, x.LINES):
+        r = dist_search.distributed_search(b"Sherlock", path, mode, dist=dist, device=0, num_threads=2,
+                                           chunk_bytes=chunk_bytes)
+        out[mode] = r if isinstance(r, int) else [v if isinstance(v, bytes) else int(v) for v in r]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_file_gpu_scanner(files):
+    """dist_search with the real per-rank scanner (xsg.Job on a chunk range): two
+    processes on this box's one GPU, contiguous chunk ranges, all_reduce / all_gather
+    through gloo (RCCL needs one GPU per rank)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_gpu_worker, args=(r, 2, port, files["txt"], CHUNK, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = files["want"][b"Sherlock"]
+    assert got[0][xsg.COUNT_MATCHES] == got[1][xsg.COUNT_MATCHES] == want["count_matches"]
+    assert got[0][xsg.COUNT_LINES] == got[1][xsg.COUNT_LINES] == want["count_lines"]
+    assert got[0][xsg.MATCH_BYTE_OFFSETS] + got[1][xsg.MATCH_BYTE_OFFSETS] == want["match_byte_offsets"]
+    assert got[0][xsg.LINE_INDICES] + got[1][xsg.LINE_INDICES] == want["line_indices"]
+    assert got[0][xsg.LINES] + got[1][xsg.LINES] == want["lines"]
