@@ -217,7 +217,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
 
   XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
   XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
-  XSG_TRY(s->d_chunk_last.ensure(4 * std::max<uint64_t>(ntiles, 1)));  // tile_last
+  XSG_TRY(s->d_tile_last.ensure(4 * std::max<uint64_t>(ntiles, 1)));  // tile_last
   XSG_TRY(s->d_tile_cnt.ensure(4 * std::max<uint64_t>(ntiles, 1)));
   XSG_TRY(s->d_counters.ensure(8 * XSG_NUM_COUNTERS));
   static_assert(sizeof(ChunkDev) == sizeof(xsg_chunk), "layout");
@@ -292,7 +292,7 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
   a.tile_nl = s->d_tile_nl.as<uint32_t>();
   a.tile_sum = s->d_tile_sum.as<uint32_t>();
-  a.tile_last = s->d_chunk_last.as<uint32_t>();
+  a.tile_last = s->d_tile_last.as<uint32_t>();
   return a;
 }
 
@@ -306,7 +306,7 @@ static int check_ready(xsg_shard* s) {
 static int preset_tile_arrays(xsg_shard* s, bool want_lines, hipStream_t st) {
   const uint64_t nchunks = s->chunks.size();
   (void)nchunks;
-  HIP_TRY(hipMemsetAsync(s->d_chunk_last.p, 0, 4 * std::max<uint64_t>(s->ntiles, 1), st));  // tile_last
+  HIP_TRY(hipMemsetAsync(s->d_tile_last.p, 0, 4 * std::max<uint64_t>(s->ntiles, 1), st));  // tile_last
   HIP_TRY(hipMemsetAsync(s->d_tile_cnt.p, 0, 4 * std::max<uint64_t>(s->ntiles, 1), st));
   if (want_lines) {
     XSG_TRY(s->d_tile_sum.ensure(4 * kWaves * std::max<uint64_t>(s->ntiles, 1)));

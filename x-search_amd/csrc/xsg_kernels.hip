@@ -9,15 +9,17 @@
 //                 (search_wrappers.h:111-123,187-207; simd_search.cpp:116-144,297-303)
 //
 // Design: the bulk scan is a pure HBM stream.  Every lane reads
-// 16-byte units with global_load_dwordx4 (a wave-instruction = 1 KiB
-// contiguous), fetches the first 8 bytes of its right neighbour's unit with one
-// DPP wave shift (no LDS traffic), builds the 20 unaligned dword windows of its
-// unit with v_alignbyte_b32 and compares them against the first 8 pattern bytes
-// held in SGPRs.  A wave-load whose 64 lanes see no candidate -- the normal
-// case at text match densities -- costs ~3 VALU ops per byte and leaves the
-// loop without touching LDS or memory again.  Everything else (exact
-// verification, popcounts, ordered compaction, line summaries) lives in a
-// wave-uniform slow path.
+// 16-byte units with non-temporal global_load_dwordx4 (a wave-instruction = 1 KiB
+// contiguous, all loads of a wave issued before the first use), fetches the first
+// 8 bytes of its right neighbour's unit with DPP wave shifts (no LDS traffic),
+// builds the 20 unaligned dword windows of its unit with v_alignbyte_b32 and
+// compares them against the first 8 pattern bytes held in SGPRs; the lane masks
+// are OR-ed on the scalar unit.  A wave-load whose 64 lanes see no candidate --
+// the normal case at text match densities -- costs ~3 VALU ops per byte and
+// leaves the loop without touching LDS or memory again, and a wave that found
+// nothing writes nothing (the per-tile arrays are preset by the host).
+// Everything else (exact verification, popcounts, ordered compaction, line
+// summaries) lives in a wave-uniform slow path.
 #include "xsg_internal.h"
 #include "xsg_linesum.h"
 #include "xsg_tail.h"
@@ -29,8 +31,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 // cross-lane helpers (wave64)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
 // value of lane+1 (lane 63 receives `edge`)
 __device__ __forceinline__ uint32_t from_next_lane(uint32_t x, uint32_t edge, uint32_t lane) {
 #if defined(XSG_USE_DPP_SHIFT)

@@ -92,7 +92,7 @@ struct xsg_shard {
   uint64_t shard_line_base = 0;
 
   DevBuf d_chunks, d_tile_chunk, d_chunk_tile0;
-  DevBuf d_tile_cnt, d_tile_nl, d_tile_sum, d_chunk_last, d_counters;
+  DevBuf d_tile_cnt, d_tile_nl, d_tile_sum, d_tile_last, d_counters;
   DevBuf d_tile_off, d_tile_nl_off, d_scan_tmp;
   DevBuf d_m_pos, d_m_chunk, d_m_ls, d_keep, d_keep_pre;
   DevBuf d_chunk_shift0, d_tail_cnt, d_tail_pos, d_tail_pre;
@@ -105,7 +105,7 @@ struct xsg_shard {
   std::vector<uint64_t> h_line_len, h_line_off;
 
   void release_all() {
-    DevBuf* all[] = {&d_chunks, &d_tile_chunk, &d_chunk_tile0, &d_tile_cnt, &d_tile_nl, &d_tile_sum, &d_chunk_last,
+    DevBuf* all[] = {&d_chunks, &d_tile_chunk, &d_chunk_tile0, &d_tile_cnt, &d_tile_nl, &d_tile_sum, &d_tile_last,
                      &d_counters, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls, &d_keep,
                      &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
                      &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes};
