@@ -657,9 +657,19 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
       }
       if (lane == 0) lines += sum_total_lines(run);
     }
+    const ChunkDev ch = A.chunks[c];
+    const uint8_t* d = A.base + ch.offset;
+    if (need_tail && ch.length) {
+      // the walk below is one lane reading byte by byte: pull the tail zone into the
+      // caches with one coalesced sweep of the whole wave first
+      const uint64_t Lr = (ch.length + 15u) & ~(uint64_t)15u;
+      for (uint64_t off = (tail_zone_begin(ch.length, A.pat.plen) & ~(uint64_t)15u) + (uint64_t)lane * kUnit; off < Lr;
+           off += kWaveLoad) {
+        const uint4 v = *reinterpret_cast<const uint4*>(d + off);
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+      }
+    }
     if (lane == 0) {
-      const ChunkDev ch = A.chunks[c];
-      const uint8_t* d = A.base + ch.offset;
       bytes += ch.length;
       if (need_tail) {
         if (A.want_matches)
