@@ -96,9 +96,19 @@ __device__ __forceinline__ uint32_t nl_flags(uint32_t d) {
   const uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
   return ~t;  // 0x80 in every byte that was '\n'
 }
+// number of '\n' among the 16 bytes of the unit.  t = nl_flags' intermediate has
+// the low 7 bits of every byte set and bit 7 set iff the byte is NOT a newline, so
+// popcount(t) = 28 + (non-newline bytes) and the four popcounts chain through
+// v_bcnt_u32_b32's accumulator operand: 4 ops per dword + 1.
 __device__ __forceinline__ uint32_t nl_count16(const uint32_t (&d)[8]) {
-  return (uint32_t)__popc(nl_flags(d[0])) + (uint32_t)__popc(nl_flags(d[1])) + (uint32_t)__popc(nl_flags(d[2])) +
-         (uint32_t)__popc(nl_flags(d[3]));
+  uint32_t acc = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t x = d[q] ^ 0x0a0a0a0au;
+    const uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
+    acc += (uint32_t)__popc(t);
+  }
+  return 128u - acc;
 }
 // bit b set <=> byte b of the unit is '\n'
 __device__ __forceinline__ uint32_t nl_mask16(const uint32_t (&d)[8]) {
