@@ -475,14 +475,67 @@ struct Slot {
   }
 };
 
-static int slot_init(xsg_job* j, Slot& s) {
-  XSG_TRY(xsg_ctx_create(j->opts.device, &s.ctx));
-  XSG_TRY(xsg_set_pattern(s.ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
-  s.cap = ((j->max_orig + 15u) & ~(uint64_t)15u) + 256u;
-  HIP_TRY(hipHostMalloc(&s.host, s.cap, hipHostMallocDefault));
-  HIP_TRY(hipMalloc(&s.dev, s.cap));
-  XSG_TRY(xsg_shard_create(s.ctx, s.dev, s.cap, nullptr, 0, &s.shard));
-  if (j->compression != XSG_COMPRESSION_NONE) s.staging.resize(j->max_actual);
+// Slots (ctx + stream + shard scratch + pinned and device buffers) are kept in a
+// per-process pool between jobs: creating one costs ~10 ms of hipHostMalloc /
+// hipMalloc / stream setup, which dominated searches of small files.  The pool is
+// never torn down (a static destructor would race the HIP runtime's own exit).
+static std::mutex g_slot_mu;
+static std::vector<Slot*>& slot_pool() {
+  static std::vector<Slot*>* pool = new std::vector<Slot*>();
+  return *pool;
+}
+constexpr size_t kMaxIdleSlots = 64;
+
+static Slot* slot_take(int device) {
+  std::lock_guard<std::mutex> g(g_slot_mu);
+  std::vector<Slot*>& pool = slot_pool();
+  for (size_t i = 0; i < pool.size(); ++i) {
+    if (pool[i]->ctx->device == device) {
+      Slot* s = pool[i];
+      pool.erase(pool.begin() + (ptrdiff_t)i);
+      return s;
+    }
+  }
+  return nullptr;
+}
+
+static void slot_give_back(Slot* s) {
+  {
+    std::lock_guard<std::mutex> g(g_slot_mu);
+    if (slot_pool().size() < kMaxIdleSlots) {
+      slot_pool().push_back(s);
+      return;
+    }
+  }
+  delete s;
+}
+
+static int slot_prepare(xsg_job* j, Slot** out) {
+  Slot* s = slot_take(j->opts.device);
+  std::unique_ptr<Slot> fresh;
+  if (!s) {
+    fresh.reset(new (std::nothrow) Slot());
+    if (!fresh) return fail(XSG_ENOMEM, "host allocation failed");
+    s = fresh.get();
+    XSG_TRY(xsg_ctx_create(j->opts.device, &s->ctx));
+    XSG_TRY(xsg_shard_create(s->ctx, nullptr, 0, nullptr, 0, &s->shard));
+  } else {
+    fresh.reset(s);  // owned here until handed out; a failure below frees it
+  }
+  HIP_TRY(hipSetDevice(j->opts.device));
+  XSG_TRY(xsg_set_pattern(s->ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
+  const uint64_t need = ((j->max_orig + 15u) & ~(uint64_t)15u) + 256u;
+  if (need > s->cap) {
+    if (s->host) (void)hipHostFree(s->host);
+    if (s->dev) (void)hipFree(s->dev);
+    s->host = s->dev = nullptr;
+    s->cap = 0;
+    HIP_TRY(hipHostMalloc(&s->host, need, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&s->dev, need));
+    s->cap = need;
+  }
+  if (j->compression != XSG_COMPRESSION_NONE && s->staging.size() < j->max_actual) s->staging.resize(j->max_actual);
+  *out = fresh.release();
   return XSG_OK;
 }
 
@@ -561,11 +614,12 @@ static void worker_main(xsg_job* j) {
   double t_read = 0, t_dec = 0, t_dev = 0;
   uint64_t bytes = 0, rbytes = 0, chunks = 0;
   {
-    Slot s;
-    int r = slot_init(j, s);
+    Slot* sp = nullptr;
+    int r = slot_prepare(j, &sp);
     if (r != XSG_OK) {
       job_fail(j, r);
     } else {
+      Slot& s = *sp;
       while (!j->stop.load()) {
         const uint64_t i = j->next_chunk.fetch_add(1);
         if (i >= j->plan.size()) break;
@@ -578,6 +632,10 @@ static void worker_main(xsg_job* j) {
         rbytes += j->plan[i].actual_size;
         ++chunks;
       }
+      if (r == XSG_OK)
+        slot_give_back(sp);
+      else
+        delete sp;  // do not recycle a slot whose last operation failed
     }
   }
   std::lock_guard<std::mutex> g(j->mu);
