@@ -143,3 +143,26 @@ if __name__ == "__main__":  # regenerate the summary (build container only)
                                                   "sample.xszst.meta")}
     (G.GOLDEN / "ref_metafile_summary.json").write_text(json.dumps(out, indent=1))
     print(json.dumps(out, indent=1)[:600])
+
+
+def test_xsmeta_cli_cat_and_write(text_file, tmp_path):
+    """tools/xsmeta: the metafile_cat-like dump (metafile_cat.cpp:23-52 field names)
+    and the preprocessor, both GPU-free."""
+    import subprocess
+    exe = Path(__file__).resolve().parents[1] / "tools" / "build" / "xsmeta"
+    if not exe.exists():
+        pytest.skip("tools/build/xsmeta not built (make -C tools)")
+    p, data = text_file
+    meta, out = tmp_path / "t.meta", tmp_path / "t.xslz4"
+    r = subprocess.run([str(exe), "write", str(p), "--meta", str(meta), "--data", str(out), "--lz4", "--chunk-bytes",
+                        str(1 << 19)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run([str(exe), "cat", str(meta)], capture_output=True)
+    assert r.returncode == 0
+    txt = r.stdout.decode()
+    ctype, chunks = xsg.meta_read(str(meta))
+    assert txt.startswith("Compression Type: LZ4 (4)")
+    assert txt.count("Chunk ") == len(chunks)
+    assert f"  original: {int(chunks[1]['original_offset'])}" in txt
+    r = subprocess.run([str(exe), "cat", str(tmp_path / "nope.meta")], capture_output=True)
+    assert r.returncode == 1 and b"cannot open" in r.stderr
