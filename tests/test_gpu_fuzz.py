@@ -1,0 +1,62 @@
+"""Randomised differential test of the HIP path against the oracle: random
+alphabets, chunk sizes around every tile / wave / load boundary, random patterns
+(random bytes, substrings of the data, self-overlapping ones), all flags, all tags.
+Fixed seeds: a failure reproduces."""
+import numpy as np
+import pytest
+
+import xsg
+from gpu_util import GpuSearch, oracle_all_modes
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [0, 1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 39, 40, 41, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097,
+         16383, 16384, 16385, 16384 * 2 - 1, 16384 * 2 + 1, 16384 * 3 + 5]
+
+
+def rand_pattern(rng, data, alphabet):
+    kind = rng.integers(0, 5)
+    if kind == 0 and data.size > 40:  # substring of the data
+        n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 33]))
+        o = int(rng.integers(0, data.size - n))
+        p = data[o:o + n].tobytes()
+    elif kind == 1:  # self-overlapping
+        unit = bytes(alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(1, 4)))])
+        p = (unit * 6)[:int(rng.integers(2, 13))]
+    elif kind == 2:  # from the end of the data: lands in the reference's lossy tail zone
+        n = int(rng.integers(2, 10))
+        p = data[-n - int(rng.integers(0, 20)):][:n].tobytes() if data.size > 40 else b"ab"
+    else:
+        p = bytes(alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(1, 11)))])
+    return p if p else b"a"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fuzz(seed, oracle):
+    rng = np.random.default_rng(1000 + seed)
+    gs = GpuSearch()
+    alphabets = [np.frombuffer(b"ab", dtype=np.uint8), np.frombuffer(b"ab\n", dtype=np.uint8),
+                 np.frombuffer(b"abcAB \n\n", dtype=np.uint8), np.arange(256, dtype=np.uint8),
+                 np.frombuffer(b"Sherlock Holmes\n", dtype=np.uint8)]
+    for it in range(14):
+        alphabet = alphabets[int(rng.integers(0, len(alphabets)))]
+        nchunks = int(rng.integers(1, 7))
+        blocks = []
+        for _ in range(nchunks):
+            n = int(rng.choice(SIZES)) if rng.random() < 0.7 else int(rng.integers(0, 60000))
+            b = alphabet[rng.integers(0, len(alphabet), size=n)].copy()
+            if n and rng.random() < 0.6:
+                b[-1] = 10
+            blocks.append(b)
+        gs.bind(blocks)
+        big = max(blocks, key=lambda x: x.size)
+        for _ in range(5):
+            p = rand_pattern(rng, big, alphabet)
+            exact = bool(rng.integers(0, 2))
+            icase = bool(rng.integers(0, 2))
+            flags = (xsg.FLAG_EXACT_TAIL if exact else 0) | (xsg.FLAG_IGNORE_CASE if icase else 0)
+            got = gs.all_modes(p, flags)
+            want = oracle_all_modes(oracle, blocks, p, exact, ignore_case=icase)
+            for k in want:
+                assert got[k] == want[k], (f"seed={seed} it={it} pat={p!r} exact={exact} icase={icase} "
+                                           f"sizes={[b.size for b in blocks]} key={k}")
