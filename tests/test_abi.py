@@ -47,3 +47,13 @@ def test_strerror_covers_all_codes():
     lib = xsg.load()
     for code in (0, -1, -2, -3, -4, -5, -6, -7):
         assert lib.xsg_strerror(code) not in (None, b"unknown error")
+
+
+def test_reference_call_sites_compile_against_the_header():
+    """README.md:37,72, checkit.cpp:4, example/grep.cpp:69-79 and the call shapes of
+    test/src/xsearchTest.cpp compile unchanged against include/xsearch/xsearch.h."""
+    import subprocess
+    src = ROOT / "tests" / "cpp" / "api_callsites.cpp"
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src)],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
