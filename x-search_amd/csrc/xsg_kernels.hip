@@ -34,12 +34,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // value of lane+1 (lane 63 receives `edge`)
 __device__ __forceinline__ uint32_t from_next_lane(uint32_t x, uint32_t edge, uint32_t lane) {
 #if defined(XSG_USE_DPP_SHIFT)
-  // v_mov_b32_dpp wave_shl:1 -- lane i reads lane i+1 (gfx9 DPP wavefront shift)
-  uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false);
+  // v_mov_b32_dpp wave_shl:1 -- lane i reads lane i+1 (gfx9 DPP wavefront shift).
+  // Lane 63 has no source lane: with bound_ctrl off it keeps the destination's old
+  // value, which is preset to `edge` -- two instructions per dword in all.
+  (void)lane;
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130, 0xf, 0xf, false);
 #else
-  uint32_t y = (uint32_t)__shfl_down((int)x, 1);
-#endif
+  const uint32_t y = (uint32_t)__shfl_down((int)x, 1);
   return lane == 63u ? edge : y;
+#endif
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
@@ -219,6 +222,85 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
   return m;
 }
 
+// per-wave running state of k_scan
+struct WaveState {
+  uint32_t cnt = 0;       // matches found by this lane
+  uint32_t nlc = 0;       // newlines counted by this lane (WANT_NL)
+  uint64_t last_end = 0;  // end of this lane's last match, chunk-local
+  uint32_t wsum = 0;      // line summary of the wave span so far (lane 0); 0 is the identity
+  bool run_nl = false;    // the current run of match-less loads holds a newline (wave-uniform)
+  uint32_t masks[4] = {0, 0, 0, 0};
+};
+
+// One wave-load (1 KiB): `cur` is this lane's 16-byte unit, `nx` the unit that
+// follows the wave-load (lane 0's unit of the next load, or the bytes after the
+// span).  CAREFUL: the wave-load may reach past the end of the chunk.
+// Returns the lane's exact match-start bits (also accumulated into `st`).
+template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool CAREFUL>
+__device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, bool nx_is_vgpr, uint64_t unit_off,
+                                              uint32_t lane, uint64_t L, uint64_t limit, const PatternDev& P,
+                                              const uint8_t* cbase, const uint8_t* s_pat, WaveState& st) {
+  uint32_t d[8] = {cur.x, cur.y, cur.z, cur.w, 0u, 0u, 0u, 0u};
+  if (CAREFUL) {
+    // bytes at or beyond L are not part of the chunk: clear them once
+    if (unit_off + kUnit > L) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint64_t o = unit_off + 4u * q;
+        d[q] = o >= L ? 0u : (o + 4u > L ? d[q] & ((1u << (8u * (uint32_t)(L - o))) - 1u) : d[q]);
+      }
+    }
+  }
+  // the neighbour's first 8 bytes: lane+1's unit, lane 63 takes lane 0 of the next load / the edge
+  const uint32_t e0 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.x) : nx.x;
+  const uint32_t e1 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.y) : nx.y;
+  d[4] = from_next_lane(cur.x, e0, lane);
+  d[5] = from_next_lane(cur.y, e1, lane);
+
+  if (WANT_NL) st.nlc += nl_count16(d);
+  if (ICASE) {  // newlines are not letters: folding after the newline count or before is the same
+#pragma unroll
+    for (int q = 0; q < 6; ++q) d[q] = fold4(d[q]);
+  }
+
+  const bool any_c = cand_any<KIND>(d, P);
+  uint32_t m = 0;
+  if (__ballot(any_c) != 0) {
+    if (KIND == kLong) {  // the neighbour's upper 8 bytes, for the in-register check of pattern bytes 8..15
+      const uint32_t e2 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
+      const uint32_t e3 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
+      d[6] = from_next_lane(cur.z, e2, lane);
+      d[7] = from_next_lane(cur.w, e3, lane);
+      if (ICASE) {
+        d[6] = fold4(d[6]);
+        d[7] = fold4(d[7]);
+      }
+    }
+    m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat);
+  }
+  if (EMIT) {
+    st.cnt += (uint32_t)__popc(m);
+  } else {
+    if (m) {
+      st.cnt += (uint32_t)__popc(m);
+      st.last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen;
+    }
+    if (WANT_LINES) {
+      // A wave-load without any match start (the common case) summarises to "has a
+      // newline or not", and a run of such loads to the OR of that: once a newline
+      // has been seen in the run, the remaining loads of the run need no test at all.
+      if (__ballot(m != 0) != 0) {
+        if (st.run_nl) st.wsum = sum_combine(st.wsum, kSumNl);
+        st.run_nl = false;
+        st.wsum = sum_combine(st.wsum, wave_units_combine(sum_of_unit(m, nl_mask16(d))));
+      } else if (!st.run_nl) {
+        st.run_nl = __ballot(nl_any16(d)) != 0;
+      }
+    }
+  }
+  return m;
+}
+
 // ---------------------------------------------------------------------------
 // k_scan: the bulk pass.  EMIT=false: per-tile counts / newline counts / line
 // summaries.  EMIT=true: the same decisions, writing every match offset at its
@@ -240,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   const PatternDev P = A.pat;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
-  const uint32_t wave = tid >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps wbase and the branches on it scalar
 
   if (KIND == kLong) {
     for (uint32_t k = tid; k < P.plen; k += kBlock) s_pat[k] = P.d_pat[k];
@@ -263,91 +345,61 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   // unit (an L2 hit) and are cleared below, so the loads stay back to back.
   const uint64_t last_unit = Lr - kUnit;  // L >= 1 here: a chunk of length 0 has no tiles
   uint4 v[kLoads];
+  uint4 edge;
+  // non-temporal: every byte is read once, so keeping it out of L2/MALL allocation
+  // is worth +8 % on this stream (7.1 vs 6.55 TB/s, scripts/read_variants.py)
+  if (wbase + kWaveSpan + kUnit <= Lr) {  // wave-uniform: span and edge inside the chunk -> no clamping
+    const uint8_t* p0 = cbase + wbase + (uint64_t)lane * kUnit;
 #pragma unroll
-  for (int j = 0; j < kLoads; ++j) {
-    uint64_t off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
-    off = off < last_unit ? off : last_unit;
-    // non-temporal: every byte is read once, so keeping it out of L2/MALL allocation
-    // is worth +8 % on this stream (7.1 vs 6.55 TB/s, scripts/read_variants.py)
-    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(cbase + off));
-    v[j] = make_uint4(t.x, t.y, t.z, t.w);
+    for (int j = 0; j < kLoads; ++j) {
+      const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + (uint64_t)j * kWaveLoad));
+      v[j] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+    // the 16 bytes that follow the span (wave-uniform address)
+    edge = *reinterpret_cast<const uint4*>(cbase + wbase + kWaveSpan);
+  } else {
+#pragma unroll
+    for (int j = 0; j < kLoads; ++j) {
+      uint64_t off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
+      off = off < last_unit ? off : last_unit;
+      const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(cbase + off));
+      v[j] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+    uint64_t eoff = wbase + kWaveSpan;
+    eoff = eoff < last_unit ? eoff : last_unit;
+    edge = *reinterpret_cast<const uint4*>(cbase + eoff);
   }
-  // the 16 bytes that follow the span (wave-uniform address)
-  uint64_t eoff = wbase + kWaveSpan;
-  eoff = eoff < last_unit ? eoff : last_unit;
-  const uint4 edge = *reinterpret_cast<const uint4*>(cbase + eoff);
   // keep every load ahead of the first use of any of them (otherwise the
   // scheduler sinks a copy of load 0 between the loads and stalls the issue)
   __builtin_amdgcn_sched_barrier(0);
 
-  uint32_t cnt = 0, nlc = 0;
-  uint64_t last_end = 0;
-  uint32_t wsum = 0;    // line summary of the wave span so far (lane 0); 0 is the identity
-  bool run_nl = false;  // the current run of match-less loads holds a newline (wave-uniform)
-  uint32_t masks[kLoads];
-
+  // The loop body exists twice: a wave whose whole span lies inside the chunk (all
+  // but the last tile of a chunk) skips every end-of-chunk check.
+  WaveState st;
+  if (wbase + kWaveSpan <= L) {
 #pragma unroll
-  for (int j = 0; j < kLoads; ++j) {
-    const uint64_t unit_off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
-    uint32_t d[8] = {v[j].x, v[j].y, v[j].z, v[j].w, 0u, 0u, 0u, 0u};
-    // bytes at or beyond L are not part of the chunk: clear them once
-    if (unit_off + kUnit > L) {
+    for (int j = 0; j < kLoads; ++j) {
+      const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
+      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, false>(
+          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit, lane, L, limit, P, cbase,
+          s_pat, st);
+    }
+  } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint64_t o = unit_off + 4u * q;
-        d[q] = o >= L ? 0u : (o + 4u > L ? d[q] & ((1u << (8u * (uint32_t)(L - o))) - 1u) : d[q]);
-      }
-    }
-    {
-      const uint32_t e0 = j + 1 < kLoads ? __builtin_amdgcn_readfirstlane(v[j + 1 < kLoads ? j + 1 : j].x) : edge.x;
-      const uint32_t e1 = j + 1 < kLoads ? __builtin_amdgcn_readfirstlane(v[j + 1 < kLoads ? j + 1 : j].y) : edge.y;
-      d[4] = from_next_lane(v[j].x, e0, lane);
-      d[5] = from_next_lane(v[j].y, e1, lane);
-    }
-
-    if (WANT_NL) nlc += nl_count16(d);
-    if (ICASE) {  // newlines are not letters: folding after the newline count or before is the same
-#pragma unroll
-      for (int q = 0; q < 6; ++q) d[q] = fold4(d[q]);
-    }
-
-    const bool any_c = cand_any<KIND>(d, P);
-    uint32_t m = 0;
-    if (__any(any_c)) {
-      if (KIND == kLong) {  // the neighbour's upper 8 bytes, for the in-register check of pattern bytes 8..15
-        const uint32_t e2 = j + 1 < kLoads ? __builtin_amdgcn_readfirstlane(v[j + 1 < kLoads ? j + 1 : j].z) : edge.z;
-        const uint32_t e3 = j + 1 < kLoads ? __builtin_amdgcn_readfirstlane(v[j + 1 < kLoads ? j + 1 : j].w) : edge.w;
-        d[6] = from_next_lane(v[j].z, e2, lane);
-        d[7] = from_next_lane(v[j].w, e3, lane);
-        if (ICASE) {
-          d[6] = fold4(d[6]);
-          d[7] = fold4(d[7]);
-        }
-      }
-      m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat);
-    }
-    if (EMIT) {
-      masks[j] = m;
-      cnt += (uint32_t)__popc(m);
-    } else {
-      if (m) {
-        cnt += (uint32_t)__popc(m);
-        last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen;
-      }
-      if (WANT_LINES) {
-        // A wave-load without any match start (the common case) summarises to "has a
-        // newline or not", and a run of such loads to the OR of that: once a newline
-        // has been seen in the run, the remaining loads of the run need no test at all.
-        if (__any(m != 0)) {
-          if (run_nl) wsum = sum_combine(wsum, kSumNl);
-          run_nl = false;
-          wsum = sum_combine(wsum, wave_units_combine(sum_of_unit(m, nl_mask16(d))));
-        } else if (!run_nl) {
-          run_nl = __any(nl_any16(d));
-        }
-      }
+    for (int j = 0; j < kLoads; ++j) {
+      const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
+      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, true>(
+          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit, lane, L, limit, P, cbase,
+          s_pat, st);
     }
   }
+  const uint32_t cnt = st.cnt, nlc = st.nlc;
+  const uint64_t last_end = st.last_end;
+  uint32_t wsum = st.wsum;
+  const bool run_nl = st.run_nl;
+  uint32_t masks[kLoads];
+#pragma unroll
+  for (int j = 0; j < kLoads; ++j) masks[j] = st.masks[j < 4 ? j : 0];
   if (WANT_LINES && !EMIT && run_nl) wsum = sum_combine(wsum, kSumNl);
 
   if (!EMIT) {
