@@ -89,6 +89,7 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
     delete c;
     return fail(XSG_ENODEV, "device %d is %s; this library carries gfx950 (MI355X) code only", device, a.c_str());
   }
+  if (const char* tn = getenv("XSG_TUNE")) c->tune = (uint32_t)strtoul(tn, nullptr, 0);
   if (const char* tk = getenv("XSG_TILE_KIB")) {
     const int v = atoi(tk);
     if (v == 16) c->tile_bytes = (uint32_t)v * 1024u;
@@ -288,6 +289,7 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.chunk_tile0 = s->d_chunk_tile0.as<uint64_t>();
   a.ntiles = s->ntiles;
   a.tile_bytes = s->tile_bytes;
+  a.tune = s->ctx->tune;
   a.pat = s->ctx->pat;
   a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
   a.tile_nl = s->d_tile_nl.as<uint32_t>();

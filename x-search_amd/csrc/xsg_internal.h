@@ -20,6 +20,8 @@ constexpr uint32_t kWaveLoad = 64 * kUnit;
 // kLoads (units per lane) is a template parameter of k_scan: the tile is
 // kLoads KiB per wave x 4 waves = 16 KiB (kLoads 4) or 32 KiB (kLoads 8).
 constexpr uint32_t kDefaultTileBytes = 16384;
+constexpr uint32_t kDefaultStagger = 12;  // see k_scan / launch_scan
+constexpr uint32_t kTuneAuto = 0xffffffffu;  // ScanArgs::tune: let launch_scan pick the stagger per variant
 
 // Same layout as xsg_chunk (include/xsg.h).
 struct ChunkDev {
@@ -58,7 +60,8 @@ struct ScanArgs {
   const uint32_t* tile_chunk;   // tile -> chunk (null when the shard has one chunk)
   const uint64_t* chunk_tile0;  // first tile of every chunk (nchunks + 1 entries)
   uint64_t ntiles;
-  uint32_t tile_bytes;          // 16384 or 32768 (selects the k_scan instantiation)
+  uint32_t tile_bytes;          // 16384 (selects the k_scan instantiation)
+  uint32_t tune;                // bits 0-7: wave stagger in units of s_sleep(1) = 64 clocks; kTuneAuto = per variant (XSG_TUNE overrides)
   PatternDev pat;
   // outputs of the counting pass
   uint32_t* tile_cnt;                  // matches starting in the tile (o < limit); ZEROED by the host before the pass

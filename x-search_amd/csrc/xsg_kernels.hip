@@ -343,6 +343,16 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   // ---- issue all loads of the wave span up front (kLoads KiB in flight per wave).
   // No branch around a load: units past the end of the chunk re-read its last
   // unit (an L2 hit) and are cleared below, so the loads stay back to back.
+  // Stagger the load bursts of the four waves of a workgroup: wave w waits
+  // w * stagger * 64 clocks before it issues its loads, so a workgroup pulls its
+  // 16 KiB as four 4 KiB bursts one after the other instead of all at once.
+  // Measured on the 50 GiB shard, plain count (scripts/tune_sweep.py): 7.07 TB/s
+  // without, 7.22 / 7.35 / 7.46 / 7.41 / 7.23 TB/s at stagger 9 / 12 / 14 / 16 / 20,
+  // 6.56 at 32.  launch_scan picks the value per kernel variant (0 for VALU-bound ones).
+  {
+    const uint32_t n = (A.tune & 0xffu) * wave;
+    for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   const uint64_t last_unit = Lr - kUnit;  // L >= 1 here: a chunk of length 0 has no tiles
   uint4 v[kLoads];
   uint4 edge;
@@ -493,8 +503,16 @@ static dim3 tile_grid(uint64_t ntiles) {
   return dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx), 1);
 }
 
-static hipError_t launch_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, hipStream_t s) {
-  if (a.ntiles == 0) return hipSuccess;
+static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_lines, bool emit, hipStream_t s) {
+  if (a_in.ntiles == 0) return hipSuccess;
+  ScanArgs a = a_in;
+  if (a.tune == kTuneAuto) {
+    // The stagger only pays where the kernel is memory-bound: it takes issue slots
+    // away from the VALU-bound variants (scripts/tune_sweep.py: plain count +5 %,
+    // count_lines +1 % at a small stagger, every heavier variant -1..-3 %).
+    const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo) && !a.pat.icase && !want_nl && !emit;
+    a.tune = !light ? 0u : (want_lines ? 4u : kDefaultStagger);
+  }
   const dim3 grid = tile_grid(a.ntiles);
   switch (a.pat.kind) {
     case kMask1: return launch_scan_loads<kMask1>(a, want_nl, want_lines, emit, grid, s);

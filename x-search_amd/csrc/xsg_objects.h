@@ -74,6 +74,7 @@ struct xsg_ctx {
   xsg::PatternDev pat{};
   DevBuf d_pat;
   uint32_t tile_bytes = xsg::kDefaultTileBytes;  // geometry new shards get (XSG_TILE_KIB)
+  uint32_t tune = xsg::kTuneAuto;                  // wave stagger: per kernel variant (XSG_TUNE overrides)
   char arch[128] = "";
   int cus = 0;
   uint64_t hbm = 0;
