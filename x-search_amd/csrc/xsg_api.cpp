@@ -338,6 +338,7 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   f.tile_last = a.tile_last;
   f.tile_bytes = s->tile_bytes;
   f.counters = d_counters;
+  f.total_bytes = s->total_bytes;
   f.want_nl = want_nl;
   f.want_lines = want_lines;
   f.want_matches = want_matches;

@@ -87,6 +87,7 @@ struct FinishArgs {
   const uint32_t* tile_last;
   uint32_t tile_bytes;
   uint64_t* counters;  // XSG_NUM_COUNTERS, zeroed before the launch
+  uint64_t total_bytes;  // sum of the chunk lengths (host-side knowledge)
   uint32_t want_nl;
   uint32_t want_lines;
   uint32_t want_matches;

@@ -670,7 +670,7 @@ hipError_t launch_read_probe(const ScanArgs& a, int parts, uint64_t flat_bytes, 
 // k_count_finish: sums the per-tile outputs and replays the reference walk
 // over every chunk's tail zone.  counters[] must be zero on entry.
 // ---------------------------------------------------------------------------
-constexpr int kFinishBlocks = 256;
+constexpr int kFinishBlocks = 2048;
 
 __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* sh) {
   // sh: kWaves entries
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   }
   // one wave per chunk: where the walk stands at the end of the bulk part (from the
   // last tile that holds a match), the chunk's matching lines, then its tail zone
-  uint64_t lines = 0, bytes = 0;
+  uint64_t lines = 0;
   const uint64_t wave_id = gid >> 6, nwaves = gsz >> 6;
   for (uint64_t c = wave_id; c < A.nchunks; c += nwaves) {
     const uint64_t t0 = A.chunk_tile0[c], t1 = A.chunk_tile0[c + 1];
@@ -750,7 +750,6 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
       }
     }
     if (lane == 0) {
-      bytes += ch.length;
       if (need_tail) {
         if (A.want_matches)
           cm += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, false), false,
@@ -768,13 +767,15 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_LINES], (unsigned long long)t);
   t = block_sum_u64(cn, sh);
   if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_NEWLINES], (unsigned long long)t);
-  t = block_sum_u64(bytes, sh);
-  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_BYTES], (unsigned long long)t);
+  if (gid == 0) A.counters[XSG_CTR_BYTES] = A.total_bytes;  // known on the host: no fan-in of atomics for it
 }
 
 hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s) {
-  uint64_t work = a.ntiles > a.nchunks ? a.ntiles : a.nchunks;
-  uint64_t blocks = (work + kBlock - 1) / kBlock;
+  // enough workgroups that every chunk gets its own wave (the per-chunk part is a
+  // chain of dependent loads: latency-bound), capped so that the atomics stay few
+  uint64_t blocks = (a.nchunks + kWaves - 1) / kWaves;
+  const uint64_t for_tiles = (a.ntiles + (uint64_t)kBlock * 64 - 1) / ((uint64_t)kBlock * 64);
+  if (for_tiles > blocks) blocks = for_tiles;
   if (blocks < 1) blocks = 1;
   if (blocks > kFinishBlocks) blocks = kFinishBlocks;
   hipLaunchKernelGGL(k_count_finish, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
