@@ -28,3 +28,23 @@ def reference():
     if not Reference.available():
         pytest.skip("oracle/_ref/libxsref.so not built or host lacks AVX2")
     return Reference()
+
+
+def _ensure_built(target_dir, artefact):
+    """C++ test drivers / tools are built in-tree (g++ only); build them on a fresh checkout."""
+    import subprocess
+    if not artefact.exists():
+        subprocess.run(["make", "-C", str(target_dir), "--no-print-directory"], check=False)
+    return artefact.exists()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cpp_artefacts():
+    import xsg
+    try:
+        xsg.load()  # builds libxsg.so if it is missing
+    except FileNotFoundError:
+        return
+    _ensure_built(ROOT / "tests" / "cpp", ROOT / "tests" / "cpp" / "build" / "extern_search_cli")
+    _ensure_built(ROOT / "tests" / "cpp", ROOT / "tests" / "cpp" / "build" / "seam_cli")
+    _ensure_built(ROOT / "tools", ROOT / "tools" / "build" / "xsgrep")

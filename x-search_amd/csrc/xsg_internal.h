@@ -97,6 +97,8 @@ struct FinishArgs {
 hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s);
 hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s);
 hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s);
+hipError_t launch_read_exp(const uint8_t* base, uint64_t bytes, int loads, int block, uint32_t stagger, uint32_t gap,
+                           uint32_t* sink, hipStream_t s);
 hipError_t launch_read_probe(const ScanArgs& a, int parts, uint64_t flat_bytes, uint32_t* sink, hipStream_t s);
 hipError_t launch_read_ceiling(const uint8_t* base, uint64_t bytes, uint32_t tile_bytes, int variant, uint32_t* sink,
                                hipStream_t s);

@@ -591,6 +591,54 @@ hipError_t launch_read_ceiling(const uint8_t* base, uint64_t bytes, uint32_t til
 }
 
 // ---------------------------------------------------------------------------
+// k_read_exp: diagnostic.  Pure nt read of a flat span with the knobs of the burst
+// experiments: LOADS units per lane, any workgroup size, wave stagger, a pause
+// between the loads of one wave.
+// ---------------------------------------------------------------------------
+template <int LOADS>
+__global__ void k_read_exp(const uint8_t* base, uint64_t ntiles, uint32_t stagger, uint32_t gap, uint32_t* sink) {
+  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+  if (tile >= ntiles) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t nwaves = blockDim.x >> 6;
+  for (uint32_t i = 0; i < stagger * wave; ++i) __builtin_amdgcn_s_sleep(1);
+  const uint8_t* p = base + tile * (uint64_t)(kWaveLoad * LOADS) * nwaves + (uint64_t)wave * (kWaveLoad * LOADS) +
+                     (uint64_t)lane * kUnit;
+  uint4 v[LOADS];
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) {
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + (uint64_t)j * kWaveLoad));
+    v[j] = make_uint4(t.x, t.y, t.z, t.w);
+    if (gap) {
+      __builtin_amdgcn_sched_barrier(0);
+      for (uint32_t i = 0; i < gap; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  uint32_t x = 0;
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) x ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+  if (x == 0xdeadbeefu) sink[0] = x;
+}
+
+hipError_t launch_read_exp(const uint8_t* base, uint64_t bytes, int loads, int block, uint32_t stagger, uint32_t gap,
+                           uint32_t* sink, hipStream_t s) {
+  const uint64_t tile_bytes = (uint64_t)kWaveLoad * loads * (block / 64);
+  const uint64_t ntiles = bytes / tile_bytes;
+  if (!ntiles || block % 64 || block > 1024) return hipErrorInvalidValue;
+  const uint64_t maxx = 1u << 30;
+  const dim3 grid = ntiles <= maxx ? dim3((unsigned)ntiles) : dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx));
+  switch (loads) {
+    case 1: hipLaunchKernelGGL((k_read_exp<1>), grid, dim3(block), 0, s, base, ntiles, stagger, gap, sink); break;
+    case 2: hipLaunchKernelGGL((k_read_exp<2>), grid, dim3(block), 0, s, base, ntiles, stagger, gap, sink); break;
+    case 4: hipLaunchKernelGGL((k_read_exp<4>), grid, dim3(block), 0, s, base, ntiles, stagger, gap, sink); break;
+    case 8: hipLaunchKernelGGL((k_read_exp<8>), grid, dim3(block), 0, s, base, ntiles, stagger, gap, sink); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // k_read_probe: diagnostic.  nt loads of k_scan's shape plus, optionally, k_scan's
 // prologue (bit 0: tile -> chunk lookups), its epilogue (bit 1: LDS + barrier +
 // one store per tile) and a stand-in for its ALU work (bit 2).  Tells where the

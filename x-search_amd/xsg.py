@@ -80,6 +80,12 @@ def load():
         except ImportError:
             pass
     p = lib_path()
+    if not p.exists() and not os.environ.get("XSG_LIB"):
+        # a fresh checkout: compile the HIP library in-tree (hipcc cross-compiles gfx950 anywhere; ~1 min).
+        # This builds the real extension -- there is still no CPU fallback behind it.
+        import subprocess
+        print(f"[xsg] {p} missing: running make -C {HERE}", file=sys.stderr, flush=True)
+        subprocess.run(["make", "-C", str(HERE), "--no-print-directory"], check=False)
     if not p.exists():
         raise FileNotFoundError(f"{p} not found: build it with `make -C x-search_amd` (or __graft_entry__.build())")
     lib = C.CDLL(str(p))
