@@ -849,7 +849,18 @@ static int host_slot_acquire(xsg_host_searcher* hs, HostSlot** out) {
       int r = xsg_ctx_create(hs->device, &s->ctx);
       if (r == XSG_OK) r = xsg_set_pattern(s->ctx, hs->pattern.data(), hs->pattern.size(), hs->flags);
       if (r == XSG_OK) r = xsg_shard_create(s->ctx, nullptr, 0, nullptr, 0, &s->shard);
-      if (r != XSG_OK) return r;  // the half-built slot stays owned by `all` and is never handed out
+      if (r != XSG_OK) {
+        // give the place back, or later callers would wait for a slot that never comes
+        lk.lock();
+        for (size_t i = 0; i < hs->all.size(); ++i)
+          if (hs->all[i].get() == s) {
+            hs->all.erase(hs->all.begin() + (ptrdiff_t)i);
+            break;
+          }
+        lk.unlock();
+        hs->cv.notify_one();
+        return r;
+      }
       *out = s;
       return XSG_OK;
     }
