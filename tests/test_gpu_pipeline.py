@@ -297,3 +297,26 @@ def test_two_ranks_share_the_file_gpu_scanner(files):
     assert got[0][xsg.MATCH_BYTE_OFFSETS] + got[1][xsg.MATCH_BYTE_OFFSETS] == want["match_byte_offsets"]
     assert got[0][xsg.LINE_INDICES] + got[1][xsg.LINE_INDICES] == want["line_indices"]
     assert got[0][xsg.LINES] + got[1][xsg.LINES] == want["lines"]
+
+
+def test_xsgrep_stdin(tmp_path):
+    """xsgrep PATTERN - : chunks cut on the fly from stdin, searched through the functor seam."""
+    import os
+    exe = ROOT / "tools" / "build" / "xsgrep"
+    data = np.concatenate([corpus.text_block(515, i, 9_000_000, needle_rate=3e-4) for i in range(4)])  # > 2 chunks of 16 MiB
+    data = np.concatenate([data, np.frombuffer(b"plain closing line\n" * 4, dtype=np.uint8)])
+    p = tmp_path / "s.txt"
+    data.tofile(p)
+    env = dict(os.environ, LC_ALL="C")
+    for args in (["Sherlock"], ["-i", "holmes"]):
+        want = subprocess.run(["grep", "-F", *args, str(p)], capture_output=True, env=env).stdout
+        with open(p, "rb") as f:
+            got = subprocess.run([str(exe), *args, "-"], stdin=f, capture_output=True, env=env, timeout=120)
+        assert got.returncode == 0, got.stderr.decode()
+        # grep has no end-of-chunk quirk; the chunks here end on line boundaries and the needle never sits in
+        # the last 40 bytes of a 16 MiB chunk in this corpus (checked by the equality itself)
+        assert got.stdout == want, args
+        wc = subprocess.run(["grep", "-F", "-c", *args, str(p)], capture_output=True, env=env).stdout
+        with open(p, "rb") as f:
+            gc = subprocess.run([str(exe), "-c", *args, "-"], stdin=f, capture_output=True, env=env, timeout=120).stdout
+        assert gc == wc, args

@@ -1,11 +1,12 @@
 // xsgrep -- the reference's example/grep.cpp (PATTERN FILE, -c, -i; lines 23-82)
 // on the MI355X engine, without boost::program_options.
 //
-//   xsgrep [-c] [-i] [-j THREADS] [-m METAFILE] PATTERN FILE
+//   xsgrep [-c] [-i] [-j THREADS] [-m METAFILE] PATTERN FILE|-
 //
 // -c  print only a count of matching lines   (grep.cpp:45-46 -> xs::count_lines)
 // -i  ignore ASCII case                      (grep.cpp:47-48)
 // otherwise print the matching lines, live, as they are found (grep.cpp:74-79).
+#include <xsearch/tasks/gpu_searchers.h>
 #include <xsearch/xsearch.h>
 
 #include <cstdio>
@@ -48,6 +49,45 @@ int main(int argc, char** argv) {
   }
   try {
     std::ios::sync_with_stdio(false);
+    if (file == "-") {
+      // stdin (grep.cpp:37: "input file, stdin if '-' or empty"): no file to plan chunks on, so
+      // read newline-aligned chunks here and hand each to the reference-style searcher functors
+      // (include/xsearch/tasks/gpu_searchers.h), like Searcher::run_thread does with a reader.
+      const uint32_t flags = icase ? XSG_FLAG_IGNORE_CASE : 0u;
+      xs::GpuLineSearcher<std::vector<char>> lines(pattern, 0, 1, flags);
+      xs::GpuCountSearcher<std::vector<char>> counter(pattern, true, 0, 1, flags);
+      const size_t target = 16u << 20;
+      std::vector<char> chunk, carry;
+      uint64_t total = 0;
+      bool eof = false;
+      while (!eof || !carry.empty()) {
+        chunk.swap(carry);
+        carry.clear();
+        while (!eof && chunk.size() < target) {
+          const size_t at = chunk.size();
+          chunk.resize(at + (1u << 20));
+          const size_t got = std::fread(chunk.data() + at, 1, 1u << 20, stdin);
+          chunk.resize(at + got);
+          if (got == 0) eof = true;
+        }
+        if (!eof) {  // cut after the last newline; the rest opens the next chunk
+          size_t cut = chunk.size();
+          while (cut > 0 && chunk[cut - 1] != '\n') --cut;
+          if (cut == 0) continue;  // no newline yet: keep reading (the loop above extends the chunk)
+          carry.assign(chunk.begin() + (ptrdiff_t)cut, chunk.end());
+          chunk.resize(cut);
+        }
+        if (chunk.empty()) break;
+        if (count) {
+          if (auto c = counter(chunk)) total += *c;
+        } else if (auto ls = lines(chunk)) {
+          for (const auto& l : *ls) std::cout << l << '\n';
+        }
+        chunk.clear();
+      }
+      if (count) std::cout << total << std::endl;
+      return 0;
+    }
     if (count) {
       auto searcher = meta.empty() ? xs::extern_search<xs::count_lines>(pattern, file, icase, threads)
                                    : xs::extern_search<xs::count_lines>(pattern, file, meta, icase, threads, threads);
