@@ -57,33 +57,35 @@ int main(int argc, char** argv) {
       xs::GpuLineSearcher<std::vector<char>> lines(pattern, 0, 1, flags);
       xs::GpuCountSearcher<std::vector<char>> counter(pattern, true, 0, 1, flags);
       const size_t target = 16u << 20;
-      std::vector<char> chunk, carry;
+      std::vector<char> buf;  // bytes read and not searched yet
+      size_t want = target;
       uint64_t total = 0;
       bool eof = false;
-      while (!eof || !carry.empty()) {
-        chunk.swap(carry);
-        carry.clear();
-        while (!eof && chunk.size() < target) {
-          const size_t at = chunk.size();
-          chunk.resize(at + (1u << 20));
-          const size_t got = std::fread(chunk.data() + at, 1, 1u << 20, stdin);
-          chunk.resize(at + got);
+      for (;;) {
+        while (!eof && buf.size() < want) {
+          const size_t at = buf.size();
+          buf.resize(at + (1u << 20));
+          const size_t got = std::fread(buf.data() + at, 1, 1u << 20, stdin);
+          buf.resize(at + got);
           if (got == 0) eof = true;
         }
+        if (buf.empty()) break;
+        size_t cut = buf.size();
         if (!eof) {  // cut after the last newline; the rest opens the next chunk
-          size_t cut = chunk.size();
-          while (cut > 0 && chunk[cut - 1] != '\n') --cut;
-          if (cut == 0) continue;  // no newline yet: keep reading (the loop above extends the chunk)
-          carry.assign(chunk.begin() + (ptrdiff_t)cut, chunk.end());
-          chunk.resize(cut);
+          while (cut > 0 && buf[cut - 1] != '\n') --cut;
+          if (cut == 0) {  // one line longer than the chunk target: keep reading
+            want = buf.size() + target;
+            continue;
+          }
         }
-        if (chunk.empty()) break;
+        std::vector<char> chunk(buf.begin(), buf.begin() + (ptrdiff_t)cut);
+        buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)cut);
+        want = target;
         if (count) {
           if (auto c = counter(chunk)) total += *c;
         } else if (auto ls = lines(chunk)) {
           for (const auto& l : *ls) std::cout << l << '\n';
         }
-        chunk.clear();
       }
       if (count) std::cout << total << std::endl;
       return 0;
