@@ -240,7 +240,12 @@ template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool C
 __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, bool nx_is_vgpr, uint64_t unit_off,
                                               uint32_t lane, uint64_t L, uint64_t limit, const PatternDev& P,
                                               const uint8_t* cbase, const uint8_t* s_pat, WaveState& st) {
-  uint32_t d[8] = {cur.x, cur.y, cur.z, cur.w, 0u, 0u, 0u, 0u};
+  // ignore_case: fold the lane's own 4 dwords once; the neighbour's bytes then arrive
+  // already folded through the DPP exchange, and the wave-uniform edge values fold on
+  // the scalar unit ('\n' is not a letter: newline tests see the same bytes either way)
+  uint32_t d[8] = {ICASE ? fold4(cur.x) : cur.x, ICASE ? fold4(cur.y) : cur.y, ICASE ? fold4(cur.z) : cur.z,
+                   ICASE ? fold4(cur.w) : cur.w, 0u, 0u, 0u, 0u};
+  const uint32_t own0 = d[0], own1 = d[1], own2 = d[2], own3 = d[3];  // what the left neighbour reads (never cleared)
   if (CAREFUL) {
     // bytes at or beyond L are not part of the chunk: clear them once
     if (unit_off + kUnit > L) {
@@ -252,29 +257,29 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
     }
   }
   // the neighbour's first 8 bytes: lane+1's unit, lane 63 takes lane 0 of the next load / the edge
-  const uint32_t e0 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.x) : nx.x;
-  const uint32_t e1 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.y) : nx.y;
-  d[4] = from_next_lane(cur.x, e0, lane);
-  d[5] = from_next_lane(cur.y, e1, lane);
+  uint32_t e0 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.x) : nx.x;
+  uint32_t e1 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.y) : nx.y;
+  if (ICASE) {
+    e0 = fold4(e0);
+    e1 = fold4(e1);
+  }
+  d[4] = from_next_lane(own0, e0, lane);
+  d[5] = from_next_lane(own1, e1, lane);
 
   if (WANT_NL) st.nlc += nl_count16(d);
-  if (ICASE) {  // newlines are not letters: folding after the newline count or before is the same
-#pragma unroll
-    for (int q = 0; q < 6; ++q) d[q] = fold4(d[q]);
-  }
 
   const bool any_c = cand_any<KIND>(d, P);
   uint32_t m = 0;
   if (__ballot(any_c) != 0) {
     if (KIND == kLong) {  // the neighbour's upper 8 bytes, for the in-register check of pattern bytes 8..15
-      const uint32_t e2 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
-      const uint32_t e3 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
-      d[6] = from_next_lane(cur.z, e2, lane);
-      d[7] = from_next_lane(cur.w, e3, lane);
+      uint32_t e2 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
+      uint32_t e3 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
       if (ICASE) {
-        d[6] = fold4(d[6]);
-        d[7] = fold4(d[7]);
+        e2 = fold4(e2);
+        e3 = fold4(e3);
       }
+      d[6] = from_next_lane(own2, e2, lane);
+      d[7] = from_next_lane(own3, e3, lane);
     }
     m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat);
   }
