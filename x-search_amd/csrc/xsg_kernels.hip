@@ -515,7 +515,9 @@ static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_line
     // The stagger only pays where the kernel is memory-bound: it takes issue slots
     // away from the VALU-bound variants (scripts/tune_sweep.py: plain count +5 %,
     // count_lines +1 % at a small stagger, every heavier variant -1..-3 %).
-    const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo) && !a.pat.icase && !want_nl && !emit;
+    // (unmasked compares = plen >= 4; a needle that is dense in the text makes any variant VALU-heavy
+    // and loses 2-3 % to the stagger -- not knowable before the scan)
+    const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo || a.pat.kind == kLong) && !a.pat.icase && !want_nl && !emit;
     a.tune = !light ? 0u : (want_lines ? 4u : kDefaultStagger);
   }
   const dim3 grid = tile_grid(a.ntiles);
