@@ -320,3 +320,37 @@ def test_xsgrep_stdin(tmp_path):
         with open(p, "rb") as f:
             gc = subprocess.run([str(exe), "-c", *args, "-"], stdin=f, capture_output=True, env=env, timeout=120).stdout
         assert gc == wc, args
+
+
+def test_concurrent_jobs_and_early_destroy(files):
+    """Several searches at once in one process (each with its own workers, slots from the
+    shared pool), a job destroyed while it is still running, and many short jobs in a row."""
+    import threading
+    want = files["want"][b"Sherlock"]
+    results, errors = {}, []
+
+    def run(i, tag):
+        try:
+            j = xsg.Job(b"Sherlock", files["txt"], TAGS[tag], num_threads=1 + i % 3, num_max_readers=2, chunk_bytes=CHUNK)
+            results[(i, tag)] = as_py(tag, j.result())
+            j.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=run, args=(i, tag)) for i, tag in enumerate(list(TAGS) * 2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for (i, tag), got in results.items():
+        assert got == want[KEY[tag]], (i, tag)
+    # destroy without join, while workers are busy: must stop and free cleanly
+    for _ in range(5):
+        j = xsg.Job(b"e", files["txt"], xsg.LINES, num_threads=4, num_max_readers=4, chunk_bytes=CHUNK)
+        j.close()
+    # many short jobs reuse pooled slots
+    for _ in range(40):
+        j = xsg.Job(b"Sherlock", files["txt"], xsg.COUNT_MATCHES, num_threads=2, chunk_bytes=CHUNK)
+        assert j.result() == want["count_matches"]
+        j.close()
