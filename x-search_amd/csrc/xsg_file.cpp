@@ -398,15 +398,19 @@ struct xsg_job {
   std::vector<xsg_file_chunk> plan;
   uint64_t max_orig = 0, max_actual = 0;
 
+  // Two stages.  num_max_readers reader threads (Searcher.h:39,106 num_concurrent_reads)
+  // pread -- and decompress -- chunks into pinned buffers; num_threads device workers take
+  // the filled buffers, hipMemcpyAsync them on their own stream and run the scan.  The
+  // pinned buffers circulate: free -> (reader) -> ready -> (worker) -> free.
   std::vector<std::thread> threads;
   std::atomic<uint64_t> next_chunk{0};
   std::atomic<bool> stop{false};
-  std::atomic<int> active{0};
-
-  // bounded read concurrency (Searcher.h:39,106 num_concurrent_reads)
-  std::mutex rd_mu;
-  std::condition_variable rd_cv;
-  int rd_free = 1;
+  std::atomic<int> active{0};   // device workers still running
+  int readers_running = 0;      // guarded by q_mu
+  std::mutex q_mu;
+  std::condition_variable q_cv_free, q_cv_ready;
+  std::vector<struct HostBuf*> all_bufs, free_bufs;
+  std::deque<struct HostBuf*> ready_bufs;
 
   // ordered result store
   std::mutex mu;
@@ -433,6 +437,9 @@ static void job_fail(xsg_job* j, int code) {
     j->errmsg = last_error_message();
   }
   j->stop.store(true);
+  { std::lock_guard<std::mutex> lk(j->q_mu); }  // a waiter is either before its predicate check or already blocked
+  j->q_cv_free.notify_all();
+  j->q_cv_ready.notify_all();
 }
 
 static void publish(xsg_job* j, uint64_t index, Partial&& p) {
@@ -460,34 +467,47 @@ static void publish(xsg_job* j, uint64_t index, Partial&& p) {
   j->cv.notify_all();
 }
 
+// A pinned host buffer travelling between the two stages.
+struct HostBuf {
+  void* pinned = nullptr;
+  uint64_t cap = 0;
+  std::vector<uint8_t> staging;  // compressed bytes before decode
+  uint64_t index = 0;            // chunk it currently holds
+  ~HostBuf() {
+    if (pinned) (void)hipHostFree(pinned);
+  }
+};
+
+// Device side of a worker: ctx + stream + shard scratch + device buffer.
 struct Slot {
   xsg_ctx* ctx = nullptr;
   xsg_shard* shard = nullptr;
-  void* host = nullptr;  // pinned
   void* dev = nullptr;
   uint64_t cap = 0;
-  std::vector<uint8_t> staging;  // compressed bytes
   ~Slot() {
     if (shard) xsg_shard_destroy(shard);
-    if (host) (void)hipHostFree(host);
     if (dev) (void)hipFree(dev);
     if (ctx) xsg_ctx_destroy(ctx);
   }
 };
 
-// Slots (ctx + stream + shard scratch + pinned and device buffers) are kept in a
-// per-process pool between jobs: creating one costs ~10 ms of hipHostMalloc /
-// hipMalloc / stream setup, which dominated searches of small files.  The pool is
-// never torn down (a static destructor would race the HIP runtime's own exit).
-static std::mutex g_slot_mu;
+// Slots and pinned buffers are kept in per-process pools between jobs: creating them
+// costs ~10 ms of hipHostMalloc / hipMalloc / stream setup, which dominated searches of
+// small files.  The pools are never torn down (a static destructor would race the HIP
+// runtime's own exit).
+static std::mutex g_pool_mu;
 static std::vector<Slot*>& slot_pool() {
   static std::vector<Slot*>* pool = new std::vector<Slot*>();
   return *pool;
 }
-constexpr size_t kMaxIdleSlots = 64;
+static std::vector<HostBuf*>& buf_pool() {
+  static std::vector<HostBuf*>* pool = new std::vector<HostBuf*>();
+  return *pool;
+}
+constexpr size_t kMaxIdleSlots = 64, kMaxIdleBufs = 128;
 
 static Slot* slot_take(int device) {
-  std::lock_guard<std::mutex> g(g_slot_mu);
+  std::lock_guard<std::mutex> g(g_pool_mu);
   std::vector<Slot*>& pool = slot_pool();
   for (size_t i = 0; i < pool.size(); ++i) {
     if (pool[i]->ctx->device == device) {
@@ -501,7 +521,7 @@ static Slot* slot_take(int device) {
 
 static void slot_give_back(Slot* s) {
   {
-    std::lock_guard<std::mutex> g(g_slot_mu);
+    std::lock_guard<std::mutex> g(g_pool_mu);
     if (slot_pool().size() < kMaxIdleSlots) {
       slot_pool().push_back(s);
       return;
@@ -512,65 +532,124 @@ static void slot_give_back(Slot* s) {
 
 static int slot_prepare(xsg_job* j, Slot** out) {
   Slot* s = slot_take(j->opts.device);
-  std::unique_ptr<Slot> fresh;
+  std::unique_ptr<Slot> own(s);
   if (!s) {
-    fresh.reset(new (std::nothrow) Slot());
-    if (!fresh) return fail(XSG_ENOMEM, "host allocation failed");
-    s = fresh.get();
+    own.reset(new (std::nothrow) Slot());
+    if (!own) return fail(XSG_ENOMEM, "host allocation failed");
+    s = own.get();
     XSG_TRY(xsg_ctx_create(j->opts.device, &s->ctx));
     XSG_TRY(xsg_shard_create(s->ctx, nullptr, 0, nullptr, 0, &s->shard));
-  } else {
-    fresh.reset(s);  // owned here until handed out; a failure below frees it
   }
   HIP_TRY(hipSetDevice(j->opts.device));
   XSG_TRY(xsg_set_pattern(s->ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
   const uint64_t need = ((j->max_orig + 15u) & ~(uint64_t)15u) + 256u;
   if (need > s->cap) {
-    if (s->host) (void)hipHostFree(s->host);
     if (s->dev) (void)hipFree(s->dev);
-    s->host = s->dev = nullptr;
+    s->dev = nullptr;
     s->cap = 0;
-    HIP_TRY(hipHostMalloc(&s->host, need, hipHostMallocDefault));
     HIP_TRY(hipMalloc(&s->dev, need));
     s->cap = need;
   }
-  if (j->compression != XSG_COMPRESSION_NONE && s->staging.size() < j->max_actual) s->staging.resize(j->max_actual);
-  *out = fresh.release();
+  *out = own.release();
   return XSG_OK;
 }
 
-static int process_chunk(xsg_job* j, Slot& s, uint64_t index, double* t_read, double* t_dec, double* t_dev) {
-  const xsg_file_chunk& fc = j->plan[index];
+static int buf_prepare(xsg_job* j, HostBuf** out) {
+  HostBuf* b = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if (!buf_pool().empty()) {
+      b = buf_pool().back();
+      buf_pool().pop_back();
+    }
+  }
+  std::unique_ptr<HostBuf> own(b ? b : new (std::nothrow) HostBuf());
+  if (!own) return fail(XSG_ENOMEM, "host allocation failed");
+  const uint64_t need = ((j->max_orig + 15u) & ~(uint64_t)15u) + 256u;
+  if (need > own->cap) {
+    if (own->pinned) (void)hipHostFree(own->pinned);
+    own->pinned = nullptr;
+    own->cap = 0;
+    HIP_TRY(hipSetDevice(j->opts.device));
+    HIP_TRY(hipHostMalloc(&own->pinned, need, hipHostMallocDefault));
+    own->cap = need;
+  }
+  if (j->compression != XSG_COMPRESSION_NONE && own->staging.size() < j->max_actual) own->staging.resize(j->max_actual);
+  *out = own.release();
+  return XSG_OK;
+}
+
+static void bufs_release(xsg_job* j) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  for (HostBuf* b : j->all_bufs) {
+    if (buf_pool().size() < kMaxIdleBufs)
+      buf_pool().push_back(b);
+    else
+      delete b;
+  }
+  j->all_bufs.clear();
+}
+
+// ---- stage 1: read (+ decompress) into a pinned buffer ------------------------
+static void reader_main(xsg_job* j) {
+  double t_read = 0, t_dec = 0;
+  uint64_t rbytes = 0;
+  while (!j->stop.load()) {
+    const uint64_t i = j->next_chunk.fetch_add(1);
+    if (i >= j->plan.size()) break;
+    HostBuf* b = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(j->q_mu);
+      j->q_cv_free.wait(lk, [&] { return !j->free_bufs.empty() || j->stop.load(); });
+      if (j->stop.load()) break;
+      b = j->free_bufs.back();
+      j->free_bufs.pop_back();
+    }
+    const xsg_file_chunk& fc = j->plan[i];
+    auto t0 = Clock::now();
+    int r = XSG_OK;
+    if (fc.actual_size) {
+      void* dst = j->compression == XSG_COMPRESSION_NONE ? b->pinned : (void*)b->staging.data();
+      r = pread_full(j->fd, dst, fc.actual_size, fc.actual_offset);
+    }
+    t_read += seconds_since(t0);
+    if (r == XSG_OK && j->compression != XSG_COMPRESSION_NONE && fc.original_size) {
+      t0 = Clock::now();
+      r = decompress_chunk(j->compression, b->staging.data(), fc.actual_size, static_cast<uint8_t*>(b->pinned),
+                           fc.original_size);
+      t_dec += seconds_since(t0);
+    }
+    if (r != XSG_OK) {
+      job_fail(j, r);
+      std::lock_guard<std::mutex> lk(j->q_mu);
+      j->free_bufs.push_back(b);
+      break;
+    }
+    rbytes += fc.actual_size;
+    b->index = i;
+    {
+      std::lock_guard<std::mutex> lk(j->q_mu);
+      j->ready_bufs.push_back(b);
+    }
+    j->q_cv_ready.notify_one();
+  }
+  {
+    std::lock_guard<std::mutex> lk(j->q_mu);
+    --j->readers_running;
+  }
+  j->q_cv_ready.notify_all();  // the last reader leaving lets idle workers finish
+  std::lock_guard<std::mutex> g(j->mu);
+  j->stats.bytes_read += rbytes;
+  j->stats.seconds_read += t_read;
+  j->stats.seconds_decompress += t_dec;
+}
+
+// ---- stage 2: H2D on the worker's stream, scan, publish -------------------------
+static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
+  const xsg_file_chunk& fc = j->plan[hb.index];
   const uint32_t mode = j->opts.mode;
-  // ---- read (bounded concurrency)
-  {
-    std::unique_lock<std::mutex> lk(j->rd_mu);
-    j->rd_cv.wait(lk, [&] { return j->rd_free > 0; });
-    --j->rd_free;
-  }
-  auto t0 = Clock::now();
-  int r = XSG_OK;
-  if (fc.actual_size) {
-    void* dst = j->compression == XSG_COMPRESSION_NONE ? s.host : (void*)s.staging.data();
-    r = pread_full(j->fd, dst, fc.actual_size, fc.actual_offset);
-  }
-  *t_read += seconds_since(t0);
-  {
-    std::lock_guard<std::mutex> lk(j->rd_mu);
-    ++j->rd_free;
-  }
-  j->rd_cv.notify_one();
-  XSG_TRY(r);
-  if (j->compression != XSG_COMPRESSION_NONE && fc.original_size) {
-    t0 = Clock::now();
-    XSG_TRY(decompress_chunk(j->compression, s.staging.data(), fc.actual_size, static_cast<uint8_t*>(s.host),
-                             fc.original_size));
-    *t_dec += seconds_since(t0);
-  }
-  // ---- device
-  t0 = Clock::now();
   if (fc.original_size)
-    HIP_TRY(hipMemcpyAsync(s.dev, s.host, fc.original_size, hipMemcpyHostToDevice, s.ctx->stream));
+    HIP_TRY(hipMemcpyAsync(s.dev, hb.pinned, fc.original_size, hipMemcpyHostToDevice, s.ctx->stream));
   xsg_chunk ch{};
   ch.offset = 0;
   ch.length = fc.original_size;
@@ -605,45 +684,58 @@ static int process_chunk(xsg_job* j, Slot& s, uint64_t index, double* t_read, do
       XSG_TRY(xsg_result_newlines(s.shard, &p.newlines));
     }
   }
-  *t_dev += seconds_since(t0);
-  publish(j, index, std::move(p));
+  // the searches above synchronise the stream: the pinned buffer is free again
+  publish(j, hb.index, std::move(p));
   return XSG_OK;
 }
 
 static void worker_main(xsg_job* j) {
-  double t_read = 0, t_dec = 0, t_dev = 0;
-  uint64_t bytes = 0, rbytes = 0, chunks = 0;
-  {
-    Slot* sp = nullptr;
-    int r = slot_prepare(j, &sp);
-    if (r != XSG_OK) {
-      job_fail(j, r);
-    } else {
-      Slot& s = *sp;
-      while (!j->stop.load()) {
-        const uint64_t i = j->next_chunk.fetch_add(1);
-        if (i >= j->plan.size()) break;
-        r = process_chunk(j, s, i, &t_read, &t_dec, &t_dev);
-        if (r != XSG_OK) {
-          job_fail(j, r);
-          break;
-        }
-        bytes += j->plan[i].original_size;
-        rbytes += j->plan[i].actual_size;
-        ++chunks;
+  double t_dev = 0;
+  uint64_t bytes = 0, chunks = 0;
+  Slot* sp = nullptr;
+  int r = slot_prepare(j, &sp);
+  if (r != XSG_OK) {
+    job_fail(j, r);
+  } else {
+    for (;;) {
+      HostBuf* b = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(j->q_mu);
+        j->q_cv_ready.wait(lk, [&] { return !j->ready_bufs.empty() || j->readers_running == 0 || j->stop.load(); });
+        if (j->stop.load()) break;
+        if (j->ready_bufs.empty()) break;  // readers are done and nothing is left
+        b = j->ready_bufs.front();
+        j->ready_bufs.pop_front();
       }
-      if (r == XSG_OK)
-        slot_give_back(sp);
-      else
-        delete sp;  // do not recycle a slot whose last operation failed
+      const auto t0 = Clock::now();
+      r = process_chunk(j, *sp, *b);
+      t_dev += seconds_since(t0);
+      const uint64_t idx = b->index;
+      {
+        std::lock_guard<std::mutex> lk(j->q_mu);
+        j->free_bufs.push_back(b);
+      }
+      j->q_cv_free.notify_one();
+      if (r != XSG_OK) {
+        job_fail(j, r);
+        break;
+      }
+      bytes += j->plan[idx].original_size;
+      ++chunks;
     }
+    if (r == XSG_OK)
+      slot_give_back(sp);
+    else
+      delete sp;  // do not recycle a slot whose last operation failed
+  }
+  if (j->stop.load()) {  // wake everybody that may still be waiting on a queue
+    { std::lock_guard<std::mutex> lk(j->q_mu); }
+    j->q_cv_free.notify_all();
+    j->q_cv_ready.notify_all();
   }
   std::lock_guard<std::mutex> g(j->mu);
   j->stats.bytes_scanned += bytes;
-  j->stats.bytes_read += rbytes;
   j->stats.chunks += chunks;
-  j->stats.seconds_read += t_read;
-  j->stats.seconds_decompress += t_dec;
   j->stats.seconds_device += t_dev;
   if (--j->active == 0) {  // the last worker closes the result (Searcher.h:116-119)
     j->finished = true;
@@ -720,12 +812,28 @@ extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_
     j->max_orig = std::max(j->max_orig, c.original_size);
     j->max_actual = std::max(j->max_actual, c.actual_size);
   }
-  j->rd_free = opts->num_max_readers;
   j->t_start = Clock::now();
-  const int nthreads = (int)std::min<uint64_t>((uint64_t)opts->num_threads, std::max<uint64_t>(j->plan.size(), 1));
-  j->active = nthreads;
+  const uint64_t nch = std::max<uint64_t>(j->plan.size(), 1);
+  const int nworkers = (int)std::min<uint64_t>((uint64_t)opts->num_threads, nch);
+  const int nreaders = (int)std::min<uint64_t>((uint64_t)opts->num_max_readers, nch);
+  // one buffer being filled per reader, one being consumed per worker, one in between
+  const int nbufs = (int)std::min<uint64_t>((uint64_t)(nworkers + nreaders + 1), nch + 1);
+  for (int i = 0; i < nbufs; ++i) {
+    HostBuf* b = nullptr;
+    r = buf_prepare(j.get(), &b);
+    if (r != XSG_OK) {
+      bufs_release(j.get());
+      close(j->fd);
+      return r;
+    }
+    j->all_bufs.push_back(b);
+    j->free_bufs.push_back(b);
+  }
+  j->active = nworkers;
+  j->readers_running = nreaders;
   xsg_job* raw = j.release();
-  for (int t = 0; t < nthreads; ++t) raw->threads.emplace_back(worker_main, raw);
+  for (int t = 0; t < nreaders; ++t) raw->threads.emplace_back(reader_main, raw);
+  for (int t = 0; t < nworkers; ++t) raw->threads.emplace_back(worker_main, raw);
   *out = raw;
   return XSG_OK;
 }
@@ -743,8 +851,12 @@ extern "C" int xsg_job_join(xsg_job* j) {
 extern "C" void xsg_job_destroy(xsg_job* j) {
   if (!j) return;
   j->stop.store(true);
+  { std::lock_guard<std::mutex> lk(j->q_mu); }
+  j->q_cv_free.notify_all();
+  j->q_cv_ready.notify_all();
   for (std::thread& t : j->threads)
     if (t.joinable()) t.join();
+  bufs_release(j);
   if (j->fd >= 0) close(j->fd);
   delete j;
 }
