@@ -172,9 +172,11 @@ int xsg_result_newlines(xsg_shard* shard, uint64_t* newlines);
  * include/xsearch/ResultTypes.h:31-130 as the result container:
  *   - chunks are cut at '\n' (>= chunk_bytes, extended to the next newline; the
  *     layout the reference's .meta fixtures show) or taken from a metafile;
- *   - num_threads workers each own a pinned host buffer, a device buffer and a
- *     HIP stream: pread -> (decompress) -> hipMemcpyAsync -> scan -> results;
- *   - at most num_max_readers workers read at the same time;
+ *   - num_max_readers reader threads pread (and LZ4/ZSTD-decode) chunks into
+ *     pinned host buffers; num_threads device workers take the filled buffers,
+ *     hipMemcpyAsync them on their own HIP stream and run the scan.  The pinned
+ *     buffers circulate between the two stages (readers never run ahead by more
+ *     than num_threads + 1 chunks);
  *   - partial results are published in chunk order; a consumer may read them
  *     while the search is still running (blocking cursor below).
  * Errors: start fails for an unreadable file / bad metafile / no device; a
