@@ -261,7 +261,8 @@ class ExternSearcher {
 template <class Tag>
 std::shared_ptr<ExternSearcher<Tag>> extern_search(const std::string& pattern, const std::string& file_path,
                                                    bool ignore_case = false, int num_threads = 1) {
-  return std::make_shared<ExternSearcher<Tag>>(pattern, file_path, std::string(), ignore_case, num_threads, 1);
+  // no reader count in this overload: one reader thread per device worker keeps the workers fed
+  return std::make_shared<ExternSearcher<Tag>>(pattern, file_path, std::string(), ignore_case, num_threads, num_threads);
 }
 // a C string in third place is a metafile path, never a bool
 template <class Tag>
