@@ -135,16 +135,19 @@ extern "C" int xsg_plan_chunks(const char* file_path, uint64_t target_bytes, xsg
 // ---------------------------------------------------------------------------
 static int read_meta(const char* path, int32_t* compression, std::vector<xsg_file_chunk>& chunks,
                      std::vector<uint64_t>* mappings) {
+  // The mapping tables are ~3 % of the corpus size (one entry per >= 500 bytes): a
+  // search only needs the 40-byte record headers and each chunk's first entry, so
+  // the file is walked with small preads and the tables are read only on request.
   int fd;
   uint64_t size;
   XSG_TRY(open_ro(path, &fd, &size));
-  std::vector<uint8_t> buf(size);
-  int r = size ? pread_full(fd, buf.data(), size, 0) : XSG_OK;
-  close(fd);
-  if (r != XSG_OK) return r;
+  struct Closer {
+    int fd;
+    ~Closer() { close(fd); }
+  } closer{fd};
   if (size < 4) return fail(XSG_EIO, "metafile '%s' is too short", path);
   int32_t ct;
-  memcpy(&ct, buf.data(), 4);
+  XSG_TRY(pread_full(fd, &ct, 4, 0));
   if (ct != XSG_COMPRESSION_NONE && ct != XSG_COMPRESSION_ZSTD && ct != XSG_COMPRESSION_LZ4)
     return fail(XSG_EIO, "metafile '%s': unknown compression type %d", path, ct);
   *compression = ct;
@@ -153,8 +156,9 @@ static int read_meta(const char* path, int32_t* compression, std::vector<xsg_fil
   while (pos < size) {
     if (size - pos < 40) return fail(XSG_EIO, "metafile '%s': truncated chunk record at byte %llu", path,
                                      (unsigned long long)pos);
-    uint64_t f[5];
-    memcpy(f, buf.data() + pos, 40);
+    uint64_t f[7] = {0, 0, 0, 0, 0, 0, 0};  // 5 header words + the first mapping entry
+    const uint64_t want = std::min<uint64_t>(56, size - pos);
+    XSG_TRY(pread_full(fd, f, want, pos));
     pos += 40;
     const uint64_t n = f[4];
     if (n > (size - pos) / 16) return fail(XSG_EIO, "metafile '%s': mapping table of chunk %zu overruns the file", path,
@@ -170,14 +174,12 @@ static int read_meta(const char* path, int32_t* compression, std::vector<xsg_fil
       return fail(XSG_EIO, "metafile '%s': chunk %zu does not start where its predecessor ends", path, chunks.size());
     expect_orig += c.original_size;
     if (n) {
-      uint64_t first[2];
-      memcpy(first, buf.data() + pos, 16);
       // the first mapping entry of a chunk is the chunk start
-      if (first[0] == c.original_offset) c.first_line = first[1];
+      if (f[5] == c.original_offset) c.first_line = f[6];
       if (mappings) {
         const size_t at = mappings->size();
         mappings->resize(at + 2 * n);
-        memcpy(mappings->data() + at, buf.data() + pos, 16 * n);
+        XSG_TRY(pread_full(fd, mappings->data() + at, 16 * n, pos));
       }
     }
     pos += 16 * n;
