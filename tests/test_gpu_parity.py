@@ -276,3 +276,24 @@ def test_one_big_chunk_with_long_lines(gs, oracle):
         got = gs.all_modes(p)
         want = oracle_all_modes(oracle, [b], p)
         assert_same(got, want, f"long lines pat={p!r}")
+
+
+def test_one_huge_line_with_many_matches(gs, oracle):
+    """8 MB without a single newline and ~60 000 matches in it (then a few normal
+    lines): per-match work must stay bounded by the gap to the previous match."""
+    rng = np.random.default_rng(99)
+    words = [b"alpha ", b"beta ", b"needle ", b"gamma ", b"delta "]
+    idx = rng.integers(0, len(words), size=1_400_000)
+    big = np.frombuffer(b"".join(words[i] for i in idx), dtype=np.uint8).copy()
+    tail = np.frombuffer(b"\nshort needle line\nno match here\nneedle at end", dtype=np.uint8)
+    b = np.concatenate([big, tail])
+    assert (big == 10).sum() == 0 and b.size > 7_000_000
+    gs.bind([b])
+    import time
+    t0 = time.perf_counter()
+    got = gs.all_modes(b"needle")
+    dt = time.perf_counter() - t0
+    want = oracle_all_modes(oracle, [b], b"needle")
+    assert_same(got, want, "huge line")
+    assert want["count_matches"] > 50_000 and want["count_lines"] == 3  # the huge line, the short one, the unterminated last one
+    assert dt < 5.0, f"huge-line search took {dt:.1f} s"

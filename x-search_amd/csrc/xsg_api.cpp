@@ -595,8 +595,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   l.line_mode = line_mode ? 1u : 0u;
 
   if (line_mode) {
-    HIP_TRY(launch_line_starts(l, st));
-    HIP_TRY(launch_line_keep(l, st));
+    HIP_TRY(launch_line_starts_keep(l, st));
   } else if (c->bordered) {
     HIP_TRY(launch_greedy_keep(l, st));
   } else {

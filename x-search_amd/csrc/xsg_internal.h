@@ -136,8 +136,7 @@ struct ListArgs {
 };
 
 hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s);
-hipError_t launch_line_starts(const ListArgs& a, hipStream_t s);
-hipError_t launch_line_keep(const ListArgs& a, hipStream_t s);
+hipError_t launch_line_starts_keep(const ListArgs& a, hipStream_t s);
 hipError_t launch_keep_all(const ListArgs& a, hipStream_t s);
 hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s);
 hipError_t launch_tail_list(const ListArgs& a, hipStream_t s);

@@ -985,23 +985,24 @@ __global__ void k_greedy_keep(const ListArgs A) {
   }
 }
 
-// line start of every raw match: the byte after the previous '\n', or 0
-// (search_wrappers.h:111-123)
-__global__ void k_line_starts(const ListArgs A) {
+// Which raw matches survive the skip_to_nl walk, and their line starts
+// (search_wrappers.h:111-123,149-154).  A match is the first of its line iff a
+// '\n' lies between the previous match and it, so every thread scans back only as
+// far as the previous match (the first match of a chunk: to the chunk start).  The
+// scans of one chunk are disjoint: O(chunk) bytes in total however long the lines
+// are (a walk back to the line start per match would be quadratic on one huge line).
+__global__ void k_line_starts_keep(const ListArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= A.M) return;
-  const uint8_t* d = A.base + A.chunks[A.m_chunk[i]].offset;
+  const uint32_t c = A.m_chunk[i];
+  const uint8_t* d = A.base + A.chunks[c].offset;
+  const bool first_in_chunk = i == 0 || A.m_chunk[i - 1] != c;
+  const uint64_t lo = first_in_chunk ? 0 : A.m_pos[i - 1];
   uint64_t p = A.m_pos[i];
-  while (p > 0 && d[p - 1] != '\n') --p;
-  A.m_ls[i] = p;
-}
-
-// a raw match survives the skip_to_nl walk iff it is the first of its line
-__global__ void k_line_keep(const ListArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= A.M) return;
-  const bool first = i == 0 || A.m_chunk[i - 1] != A.m_chunk[i] || A.m_ls[i - 1] != A.m_ls[i];
-  A.keep[i] = first ? 1u : 0u;
+  while (p > lo && d[p - 1] != '\n') --p;
+  const bool found_nl = p > lo;  // d[p-1] is the newline that opens the match's line
+  A.keep[i] = (found_nl || first_in_chunk) ? 1u : 0u;
+  A.m_ls[i] = p;  // meaningful for kept matches only (p == 0 for a first match on the chunk's first line)
 }
 
 // per chunk: where the walk enters the tail zone, from the last kept bulk match
@@ -1073,14 +1074,9 @@ hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_greedy_keep, grid_for(a.M), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_line_starts(const ListArgs& a, hipStream_t s) {
+hipError_t launch_line_starts_keep(const ListArgs& a, hipStream_t s) {
   if (!a.M) return hipSuccess;
-  hipLaunchKernelGGL(k_line_starts, grid_for(a.M), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_line_keep(const ListArgs& a, hipStream_t s) {
-  if (!a.M) return hipSuccess;
-  hipLaunchKernelGGL(k_line_keep, grid_for(a.M), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(k_line_starts_keep, grid_for(a.M), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s) {
