@@ -26,7 +26,8 @@
 // search and is thrown by join() / by the iterator that runs into it.
 //
 // Not served here: regular expressions (the reference routes them to RE2,
-// utils/utils.h:17-25) -- every pattern is a literal.  ignore_case folds ASCII
+// utils/utils.h:17-25): a pattern the reference would treat as a regex makes
+// extern_search throw std::invalid_argument (XS_FORCE_LITERAL=1 searches it as text).  ignore_case folds ASCII
 // letters only (what the reference's simd::toLower does).
 //
 // Environment: XS_DEVICE (HIP device index, default 0), XS_CHUNK_BYTES (target
@@ -39,6 +40,7 @@
 #include <cstdlib>
 #include <iterator>
 #include <memory>
+#include <regex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -103,6 +105,19 @@ inline uint64_t env_u64(const char* name, uint64_t dflt) {
   const char* v = std::getenv(name);
   if (!v || !*v) return dflt;
   return std::strtoull(v, nullptr, 10);
+}
+
+// The reference decides per pattern whether it is a regular expression: it is one
+// iff the pattern, read as a regex, does not match itself (utils/utils.h:17-25; an
+// invalid regex counts as plain text).  Regex search is RE2's job there and is not
+// served by this engine, so such a pattern is refused loudly instead of being
+// searched as a literal with different results.  XS_FORCE_LITERAL=1 overrides.
+inline bool reference_routes_to_regex(const std::string& pattern) {
+  try {
+    return !std::regex_match(pattern, std::regex("^" + pattern + "$"));
+  } catch (const std::regex_error&) {
+    return false;
+  }
 }
 
 template <class T>
@@ -214,6 +229,10 @@ class ExternSearcher {
 
   ExternSearcher(const std::string& pattern, const std::string& file_path, const std::string& meta_file_path,
                  bool ignore_case, int num_threads, int num_max_readers) {
+    if (detail::reference_routes_to_regex(pattern) && detail::env_u64("XS_FORCE_LITERAL", 0) == 0)
+      throw std::invalid_argument("xs::extern_search: '" + pattern +
+                                  "' is a regular expression for the reference (utils/utils.h:17-25); this engine "
+                                  "searches literals only (set XS_FORCE_LITERAL=1 to search it as plain text)");
     xsg_job_opts o;
     xsg_job_opts_init(&o);
     o.mode = detail::traits<Tag>::mode;

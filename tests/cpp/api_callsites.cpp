@@ -11,6 +11,8 @@ static const std::string pattern("Sherlock");
 static const std::string file_path("test/files/sample.txt");
 static const std::string meta_file_path("test/files/sample.meta");
 
+static_assert(sizeof(&xs::detail::reference_routes_to_regex) > 0, "regex routing test present");
+
 int callsites(int argc, char** argv) {
   (void)argc;
   {  // README.md:37

@@ -354,3 +354,14 @@ def test_concurrent_jobs_and_early_destroy(files):
         j = xsg.Job(b"Sherlock", files["txt"], xsg.COUNT_MATCHES, num_threads=2, chunk_bytes=CHUNK)
         assert j.result() == want["count_matches"]
         j.close()
+
+
+def test_regex_patterns_are_refused_loudly(files):
+    """'She[r ]lock' is a regex for the reference (utils/utils.h:17-25; 53 matches in its
+    goldens, xsearchTest.cpp:19): this engine must not silently search it as text."""
+    r = run_cli("count", "join", "She[r ]lock", files["txt"])
+    assert r.returncode == 1 and b"regular expression" in r.stderr
+    r = run_cli("count", "join", "She[r ]lock", files["txt"], env={"XS_FORCE_LITERAL": "1"})
+    assert r.returncode == 0 and int(r.stdout) == 0
+    r = run_cli("count", "join", "a.b", files["txt"])  # matches itself as a regex -> plain text for the reference too
+    assert r.returncode == 0

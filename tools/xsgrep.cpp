@@ -1,7 +1,7 @@
 // xsgrep -- the reference's example/grep.cpp (PATTERN FILE, -c, -i; lines 23-82)
 // on the MI355X engine, without boost::program_options.
 //
-//   xsgrep [-c] [-i] [-j THREADS] [-m METAFILE] PATTERN FILE|-
+//   xsgrep [-c] [-i] [-F] [-j THREADS] [-m METAFILE] PATTERN FILE|-
 //
 // -c  print only a count of matching lines   (grep.cpp:45-46 -> xs::count_lines)
 // -i  ignore ASCII case                      (grep.cpp:47-48)
@@ -10,6 +10,7 @@
 #include <xsearch/xsearch.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -25,6 +26,8 @@ int main(int argc, char** argv) {
       count = true;
     } else if (a == "-i" || a == "--ignore-case") {
       icase = true;
+    } else if (a == "-F" || a == "--fixed-strings") {
+      setenv("XS_FORCE_LITERAL", "1", 1);  // like grep -F: never read the pattern as a regex
     } else if ((a == "-j" || a == "--threads") && i + 1 < argc) {
       threads = std::atoi(argv[++i]);
     } else if ((a == "-m" || a == "--meta") && i + 1 < argc) {
