@@ -268,20 +268,68 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
 
   if (WANT_NL) st.nlc += nl_count16(d);
 
-  const bool any_c = cand_any<KIND>(d, P);
   uint32_t m = 0;
-  if (__ballot(any_c) != 0) {
-    if (KIND == kLong) {  // the neighbour's upper 8 bytes, for the in-register check of pattern bytes 8..15
-      uint32_t e2 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
-      uint32_t e3 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
-      if (ICASE) {
-        e2 = fold4(e2);
-        e3 = fold4(e3);
-      }
-      d[6] = from_next_lane(own2, e2, lane);
-      d[7] = from_next_lane(own3, e3, lane);
+  if (KIND == kMask1) {
+    // plen 1..3 -- usually dense in text, so there is no cheap "nothing here" case to
+    // filter for: decide all 16 positions byte-parallel instead.  z has a zero byte at
+    // byte i of dword q iff the pattern starts at position 4q+i; fl[q] flags exactly
+    // those bytes with 0x80 (5 to 11 ops per dword instead of ~24 for windows + masks).
+    const uint32_t c0 = (P.p0 & 0xffu) * 0x01010101u;
+    const uint32_t c1 = ((P.p0 >> 8) & 0xffu) * 0x01010101u;
+    const uint32_t c2 = ((P.p0 >> 16) & 0xffu) * 0x01010101u;
+    uint32_t fl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t z = d[q] ^ c0;
+      if (P.plen >= 2) z |= __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) ^ c1;
+      if (P.plen >= 3) z |= __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2) ^ c2;
+      fl[q] = ~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu);
     }
-    m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat);
+    if (__ballot((fl[0] | fl[1] | fl[2] | fl[3]) != 0) != 0) {
+      if (unit_off + kUnit > limit) {  // positions at or beyond the limit belong to the tail walk
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint64_t o = unit_off + 4u * q;
+          fl[q] = o >= limit ? 0u : (o + 4u > limit ? fl[q] & ((1u << (8u * (uint32_t)(limit - o))) - 1u) : fl[q]);
+        }
+      }
+      if (EMIT || WANT_LINES) {
+        // these need the position bits: 0x80-per-byte flags -> one bit per position
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t f = fl[q] >> 7;  // bits 0, 8, 16, 24
+          m |= ((f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u)) << (4 * q);
+        }
+      } else {
+        // counting needs no bit mask at all
+        const uint32_t n = (uint32_t)__popc(fl[0]) + (uint32_t)__popc(fl[1]) + (uint32_t)__popc(fl[2]) +
+                           (uint32_t)__popc(fl[3]);
+        if (n) {
+          st.cnt += n;
+          const uint32_t hq = fl[3] ? 3u : fl[2] ? 2u : fl[1] ? 1u : 0u;  // highest dword with a match
+          const uint32_t hf = fl[3] ? fl[3] : fl[2] ? fl[2] : fl[1] ? fl[1] : fl[0];
+          st.last_end = unit_off + 4u * hq + ((31u - (uint32_t)__clz(hf)) >> 3) + P.plen;
+        }
+        return 0;
+      }
+    } else if (!(EMIT || WANT_LINES)) {
+      return 0;
+    }
+  } else {
+    const bool any_c = cand_any<KIND>(d, P);
+    if (__ballot(any_c) != 0) {
+      if (KIND == kLong) {  // the neighbour's upper 8 bytes, for the in-register check of pattern bytes 8..15
+        uint32_t e2 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
+        uint32_t e3 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
+        if (ICASE) {
+          e2 = fold4(e2);
+          e3 = fold4(e3);
+        }
+        d[6] = from_next_lane(own2, e2, lane);
+        d[7] = from_next_lane(own3, e3, lane);
+      }
+      m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat);
+    }
   }
   if (EMIT) {
     st.cnt += (uint32_t)__popc(m);
