@@ -19,10 +19,9 @@ for c in range(n):
     o = int(off[c]); t[o:o + dts[int(plan[c])].numel()].copy_(dts[int(plan[c])])
 torch.cuda.synchronize(); del dts
 chunks = xsg.make_chunks(off, ln); total = int(ln.sum())
-tunes = [0xffffffff, 0, 12]
-cases = [("Sherlock", xsg.COUNT_MATCHES, "count"), ("Sherlock", xsg.COUNT_MATCHES | xsg.WITH_NEWLINES, "count+nl"),
-         ("Sherlock", xsg.COUNT_LINES, "count_lines"), ("Sherl", xsg.COUNT_MATCHES, "count"),
-         ("that", xsg.COUNT_MATCHES, "count"), ("the", xsg.COUNT_MATCHES, "count"), ("SHERLOCK", xsg.COUNT_MATCHES, "icase")]
+tunes = [0, 6, 12]
+cases = [("e", xsg.COUNT_MATCHES, "count"), ("the", xsg.COUNT_MATCHES, "count"), ("~", xsg.COUNT_MATCHES, "count"),
+         ("q~", xsg.COUNT_MATCHES, "count")]
 shards = {}
 for tu in tunes:
     os.environ["XSG_TUNE"] = hex(tu)
