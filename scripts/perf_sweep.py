@@ -61,7 +61,9 @@ def main():
     cases = [("Sherlock", xsg.COUNT_MATCHES, "count"), ("Sherlock", xsg.COUNT_MATCHES | xsg.WITH_NEWLINES, "count+nl"),
              ("Sherlock", xsg.COUNT_LINES, "count_lines"), ("e", xsg.COUNT_MATCHES, "count"), ("the", xsg.COUNT_MATCHES, "count"),
              ("that", xsg.COUNT_MATCHES, "count"), ("Sherl", xsg.COUNT_MATCHES, "count"),
-             ("detective street", xsg.COUNT_MATCHES, "count"), ("e", xsg.COUNT_LINES, "count_lines")]
+             ("detective street", xsg.COUNT_MATCHES, "count"), ("Sherlock Holmes", xsg.COUNT_MATCHES, "count"),
+             ("the detective", xsg.COUNT_MATCHES, "count"), ("information", xsg.COUNT_MATCHES, "count"),
+             ("e", xsg.COUNT_LINES, "count_lines")]
     for r in range(a.rounds):
         for tk, (ctx, sh) in shards.items():
             ms, nb = sh.time_read_ceiling(a.iters)

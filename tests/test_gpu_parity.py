@@ -297,3 +297,39 @@ def test_one_huge_line_with_many_matches(gs, oracle):
     assert_same(got, want, "huge line")
     assert want["count_matches"] > 50_000 and want["count_lines"] == 3  # the huge line, the short one, the unterminated last one
     assert dt < 5.0, f"huge-line search took {dt:.1f} s"
+
+
+def test_long_patterns_with_a_shifted_filter_window(gs, oracle):
+    """Long patterns are filtered on their rarest 8-byte window, not their first 8 bytes
+    (xsg_api.cpp pick_filter_window): a match is then found where its WINDOW lies.  Plant
+    matches so that start and window fall into different units / wave-loads / tiles,
+    at the very start of a chunk, closer to it than the window offset, and around the
+    tail zone; add decoys that hold the window but not the rest."""
+    rng = np.random.default_rng(4242)
+    pats = [b"detective street", b"aaaaaaaaaaaaaaaaaaaa B aaaaaaaaaaaaaaaaaa", b"the quick brown fox jumps over",
+            b"abcabcabcabc abcabcabcabc", b"ZaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaQ z"]
+    for p in pats:
+        n = len(p)
+        words = [b"street ", b"detective ", b"aaaa", b" B ", b"fox ", b"abc", b"the quick ", b"\n", b"ective s", b"a", b"Q z"]
+        idx = rng.integers(0, len(words), size=40_000)
+        data = np.frombuffer(b"".join(words[i] for i in idx), dtype=np.uint8).copy()[:200_000]
+        pa = np.frombuffer(p, dtype=np.uint8)
+        starts = [0, 1, 7, 15, 16]
+        for t in (16384, 32768, 65536, 4096 * 5, 1024 * 37):
+            starts += [t - j for j in (0, 1, 7, 8, 9, 15, 16, 17, n - 1, n, n + 1, n // 2) if t - j > 200]
+        ends = [data.size - n - d for d in (0, 1, 5, 30, 31, 32, 33, 40, 64, 100)]  # inside and around the tail zone
+        for s in sorted(set(starts)):
+            data[s:s + n] = pa
+        blocks = [data.copy(), data[3:90_000].copy(), data[:n + 3].copy(), data[:n].copy(), data[1:n].copy()]
+        for e in ends:
+            blk = data.copy()
+            blk[e:e + n] = pa
+            blocks.append(blk[100_000:].copy())
+        gs.bind(blocks)
+        for exact in (False, True):
+            for icase in (False, True):
+                flags = (xsg.FLAG_EXACT_TAIL if exact else 0) | (xsg.FLAG_IGNORE_CASE if icase else 0)
+                got = gs.all_modes(p, flags)
+                want = oracle_all_modes(oracle, blocks, p, exact, ignore_case=icase)
+                assert_same(got, want, f"shifted window pat={p!r} exact={exact} icase={icase}")
+        assert oracle_all_modes(oracle, blocks, p, True)["count_matches"] > 15

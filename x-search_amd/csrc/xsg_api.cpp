@@ -127,6 +127,34 @@ static uint32_t le32(const uint8_t* p, size_t n) {
   for (size_t i = 0; i < 4 && i < n; ++i) v |= (uint32_t)p[i] << (8 * i);
   return v;
 }
+// Which 8 bytes of a long pattern should the hot loop look for?  The slow path runs for
+// every wave-load that holds the window somewhere, so the window should be rare in
+// text: one that spans a word boundary is (a pair of words is far rarer than either
+// word), then upper case / digits / non-ASCII, then the rarer letters.  Static
+// heuristic, no look at the data; `detective street` -> "ective s".
+static uint32_t pick_filter_window(const uint8_t* p, size_t plen) {
+  if (plen <= 8) return 0;
+  uint32_t best = 0;
+  int best_score = -1;
+  for (size_t k = 0; k + 8 <= plen; ++k) {
+    int score = 0;
+    for (int i = 0; i < 8; ++i) {
+      const uint8_t c = p[k + i];
+      const bool lower = c >= 'a' && c <= 'z', upper = c >= 'A' && c <= 'Z', digit = c >= '0' && c <= '9';
+      if (c >= 0x80) score += 30;
+      else if (!lower && !upper && !digit) score += (i >= 1 && i <= 6) ? 40 : 10;
+      else if (upper || digit) score += 12;
+      else if (strchr("jqxzvkwbypgf", c)) score += 6;
+      else score += 1;
+    }
+    if (score > best_score) {
+      best_score = score;
+      best = (uint32_t)k;
+    }
+  }
+  return best;
+}
+
 static uint32_t mask32(size_t n) { return n >= 4 ? 0xffffffffu : (n == 0 ? 0u : ((1u << (8 * n)) - 1u)); }
 
 extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uint32_t flags) {
@@ -159,14 +187,18 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
 
   PatternDev& P = c->pat;
   P.plen = (uint32_t)plen;
-  P.p0 = le32(p, plen);
-  P.m0 = mask32(plen);
-  P.p1 = plen > 4 ? le32(p + 4, plen - 4) : 0u;
-  P.m1 = plen > 4 ? mask32(plen - 4) : 0u;
-  P.p2 = plen > 8 ? le32(p + 8, plen - 8) : 0u;
-  P.m2 = plen > 8 ? mask32(plen - 8) : 0u;
-  P.p3 = plen > 12 ? le32(p + 12, plen - 12) : 0u;
-  P.m3 = plen > 12 ? mask32(plen - 12) : 0u;
+  const uint32_t koff = pick_filter_window(p, plen);  // 0 unless plen > 8
+  const uint8_t* w = p + koff;
+  const size_t wlen = plen - koff;  // >= 8 when koff > 0
+  P.koff = koff;
+  P.p0 = le32(w, wlen);
+  P.m0 = mask32(wlen);
+  P.p1 = wlen > 4 ? le32(w + 4, wlen - 4) : 0u;
+  P.m1 = wlen > 4 ? mask32(wlen - 4) : 0u;
+  P.p2 = wlen > 8 ? le32(w + 8, wlen - 8) : 0u;
+  P.m2 = wlen > 8 ? mask32(wlen - 8) : 0u;
+  P.p3 = wlen > 12 ? le32(w + 12, wlen - 12) : 0u;
+  P.m3 = wlen > 12 ? mask32(wlen - 12) : 0u;
   P.kind = plen < 4 ? kMask1 : plen == 4 ? kOne : plen < 8 ? kMask2 : plen == 8 ? kTwo : kLong;
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;

@@ -44,8 +44,9 @@ enum FilterKind : int {
 struct PatternDev {
   uint32_t plen;
   uint32_t kind;
-  uint32_t p0, m0, p1, m1;  // first 8 pattern bytes as little-endian dwords and their byte masks
-  uint32_t p2, m2, p3, m3;  // bytes 8..15 (kLong: checked in registers before any memory compare)
+  uint32_t p0, m0, p1, m1;  // the 8 pattern bytes of the filter window (pattern[koff..koff+8)) as dwords + byte masks
+  uint32_t p2, m2, p3, m3;  // the 8 bytes after the window (kLong: checked in registers before any memory compare)
+  uint32_t koff;            // kLong: offset of the 8-byte filter window inside the pattern (0 for the other kinds)
   const uint8_t* d_pat;     // device copy of the pattern
   uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL
   uint32_t has_newline;     // pattern contains '\n'

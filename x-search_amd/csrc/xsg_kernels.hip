@@ -183,15 +183,21 @@ __device__ __forceinline__ uint32_t cand_mask16(const uint32_t (&d)[8], const Pa
   return m;
 }
 
-// exact match-start bits of one unit: filter, position limit, long-pattern verify
+// Exact match bits of one unit: filter, position limit, long-pattern verify.
+// Bit b stands for the filter WINDOW at byte b of the unit; the match it belongs to
+// starts P.koff bytes earlier (koff is 0 except for long patterns).
 template <int KIND, bool ICASE>
 __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const PatternDev& P, const uint8_t* cbase,
                                                  uint64_t unit_off, uint64_t limit, const uint8_t* lds_pat) {
   uint32_t m = cand_mask16<KIND>(d, P);
-  if (unit_off >= limit) return 0;
-  if (unit_off + kUnit > limit) m &= (1u << (uint32_t)(limit - unit_off)) - 1u;
+  const uint32_t koff = KIND == kLong ? P.koff : 0u;
+  // the match starts at o = window - koff and must satisfy 0 <= o < limit
+  const uint64_t lim_w = limit + koff;
+  if (unit_off >= lim_w) return 0;
+  if (unit_off + kUnit > lim_w) m &= (1u << (uint32_t)(lim_w - unit_off)) - 1u;
   if (KIND == kLong) {
-    // bytes 8..15 of the pattern, still in registers (d[6], d[7] hold the neighbour's upper half)
+    if (unit_off < koff) m &= koff - unit_off >= kUnit ? 0u : ~((1u << (uint32_t)(koff - unit_off)) - 1u);
+    // the 8 pattern bytes after the window, still in registers (d[6], d[7] hold the neighbour's upper half)
     if (__any(m != 0)) {
       uint32_t w[28];
       windows<28>(d, w);
@@ -201,20 +207,16 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
         m2 |= (uint32_t)(((w[b + 8] & P.m2) == P.p2) & ((w[b + 12] & P.m3) == P.p3)) << b;
       m &= m2;
     }
-    // beyond 16 bytes: compare the rest from memory (rare: a 16-byte prefix already matched)
-    if (P.plen > 16) {
+    // everything outside [koff, koff+16): compare from memory (rare: 16 bytes already matched)
+    if (koff > 0 || P.plen > koff + 16) {
       uint32_t c = m;
       while (c) {
         const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
         c &= c - 1u;
-        const uint8_t* s = cbase + unit_off + b;
+        const uint8_t* s = cbase + unit_off + b - koff;  // start of the match
         bool ok = true;
-        for (uint32_t k = 16; k < P.plen; ++k) {
-          if (fold(s[k], ICASE) != lds_pat[k]) {
-            ok = false;
-            break;
-          }
-        }
+        for (uint32_t k = 0; k < koff && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
+        for (uint32_t k = koff + 16; k < P.plen && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
         if (!ok) m &= ~(1u << b);
       }
     }
@@ -336,7 +338,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
   } else {
     if (m) {
       st.cnt += (uint32_t)__popc(m);
-      st.last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen;
+      st.last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen - (KIND == kLong ? P.koff : 0u);
     }
     if (WANT_LINES) {
       // A wave-load without any match start (the common case) summarises to "has a
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
         while (mm) {
           const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
           mm &= mm - 1u;
-          A.m_pos[r] = unit_off + b;
+          A.m_pos[r] = unit_off + b - (KIND == kLong ? P.koff : 0u);
           A.m_chunk[r] = c;
           ++r;
         }
