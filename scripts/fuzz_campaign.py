@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Long differential fuzz run of the HIP path against the oracle (the same generator as
+tests/test_gpu_fuzz.py, many more seeds).  Runs for --minutes, prints a progress line
+every few seeds, stops at the first difference (the assertion message reproduces it).
+Result summary -> gpurun_out/fuzz_campaign.json."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+for d in ("", "x-search_amd", "oracle", "tests"):
+    sys.path.insert(0, str(ROOT / d))
+import xs_oracle  # noqa: E402
+from gpu_util import GpuSearch  # noqa: E402
+from test_gpu_fuzz import fuzz_rounds  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--minutes", type=float, default=8.0)
+ap.add_argument("--first-seed", type=int, default=100)
+a = ap.parse_args()
+oracle = xs_oracle.Oracle()
+gs = GpuSearch()
+t0 = time.time()
+seed = a.first_seed
+out = ROOT / "gpurun_out" / "fuzz_campaign.json"
+out.parent.mkdir(exist_ok=True)
+status = {"first_seed": a.first_seed, "seeds_done": 0, "failed": None}
+while time.time() - t0 < a.minutes * 60:
+    try:
+        fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000 if seed % 4 else 600000)
+    except AssertionError as e:
+        status["failed"] = {"seed": seed, "message": str(e)[:2000]}
+        print("FAIL", seed, str(e)[:2000], flush=True)
+        break
+    seed += 1
+    status["seeds_done"] = seed - a.first_seed
+    status["elapsed_s"] = round(time.time() - t0, 1)
+    if (seed - a.first_seed) % 5 == 0:
+        print(json.dumps(status), flush=True)
+        out.write_text(json.dumps(status) + "\n")
+out.write_text(json.dumps(status) + "\n")
+print(json.dumps(status), flush=True)
+sys.exit(1 if status["failed"] else 0)

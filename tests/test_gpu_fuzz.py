@@ -15,8 +15,12 @@ SIZES = [0, 1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 39, 40, 41, 63, 64, 65, 1023,
 
 
 def rand_pattern(rng, data, alphabet):
-    kind = rng.integers(0, 5)
-    if kind == 0 and data.size > 40:  # substring of the data
+    kind = rng.integers(0, 6)
+    if kind == 5 and data.size > 200:  # long substring: the filter window may sit anywhere in it
+        n = int(rng.integers(9, 90))
+        o = int(rng.integers(0, data.size - n))
+        p = data[o:o + n].tobytes()
+    elif kind == 0 and data.size > 40:  # substring of the data
         n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 33]))
         o = int(rng.integers(0, data.size - n))
         p = data[o:o + n].tobytes()
@@ -31,20 +35,25 @@ def rand_pattern(rng, data, alphabet):
     return p if p else b"a"
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_fuzz(seed, oracle):
+def fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000):
+    """`rounds` random shards x 5 random patterns each; raises AssertionError on the first difference."""
     rng = np.random.default_rng(1000 + seed)
-    gs = GpuSearch()
     alphabets = [np.frombuffer(b"ab", dtype=np.uint8), np.frombuffer(b"ab\n", dtype=np.uint8),
                  np.frombuffer(b"abcAB \n\n", dtype=np.uint8), np.arange(256, dtype=np.uint8),
                  np.frombuffer(b"Sherlock Holmes\n", dtype=np.uint8)]
-    for it in range(14):
+    words = [b"the ", b"detective ", b"street ", b"She", b"Sherlock ", b"Holmes ", b"a ", b"of the ", b"\n", b"B ", b"lock"]
+    for it in range(rounds):
         alphabet = alphabets[int(rng.integers(0, len(alphabets)))]
+        wordy = rng.random() < 0.3  # text made of a few words: long patterns with repeated parts
         nchunks = int(rng.integers(1, 7))
         blocks = []
         for _ in range(nchunks):
-            n = int(rng.choice(SIZES)) if rng.random() < 0.7 else int(rng.integers(0, 60000))
-            b = alphabet[rng.integers(0, len(alphabet), size=n)].copy()
+            n = int(rng.choice(SIZES)) if rng.random() < 0.7 else int(rng.integers(0, max_chunk))
+            if wordy:
+                idx = rng.integers(0, len(words), size=n // 3 + 1)
+                b = np.frombuffer(b"".join(words[i] for i in idx), dtype=np.uint8)[:n].copy()
+            else:
+                b = alphabet[rng.integers(0, len(alphabet), size=n)].copy()
             if n and rng.random() < 0.6:
                 b[-1] = 10
             blocks.append(b)
@@ -60,3 +69,8 @@ def test_fuzz(seed, oracle):
             for k in want:
                 assert got[k] == want[k], (f"seed={seed} it={it} pat={p!r} exact={exact} icase={icase} "
                                            f"sizes={[b.size for b in blocks]} key={k}")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fuzz(seed, oracle):
+    fuzz_rounds(seed, oracle, GpuSearch())
