@@ -144,7 +144,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # XSG_BENCH_FORCE_DIST=1 (rehearsal, not used by the driver): take the N>1 code path -- RCCL
+    # process group, all_reduce per step, barriers -- with a single rank, on a one-GPU box.
+    if world > 1 or os.environ.get("XSG_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_mod
         dist = dist_mod
         if backend == "nccl":
@@ -181,7 +183,7 @@ def main():
     ctx = xsg.Context(dev_index)
     ctx.set_pattern(pattern)
     shard = xsg.Shard(ctx, shard_t.data_ptr(), cap, chunks)
-    counters = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device=dev)
+    counters = torch.zeros((2, xsg.NUM_COUNTERS), dtype=torch.int64, device=dev)  # double-buffered, see step()
     # a dedicated stream: a NULL handle would mean "the ctx's own stream" to xsg_count_async
     torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)
@@ -207,10 +209,29 @@ def main():
     else:
         expected_total = expected_local
 
-    def step():
-        shard.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, counters.data_ptr())
-        if dist is not None:
-            all_reduce_(counters)  # RCCL sum of the 4 uint64 counters, same stream order
+    # N>1: the 32-byte all_reduce of step i runs on its own stream while the scan of step i+1 already
+    # reads HBM (two counter buffers; events order scan -> all_reduce -> reuse of the buffer).
+    coll_stream = torch.cuda.Stream(device=dev) if dist is not None else None
+    scan_done = [torch.cuda.Event(), torch.cuda.Event()]
+    coll_done = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def step(i, results=None):
+        b = i & 1
+        c = counters[b]
+        if dist is None:
+            shard.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
+            if results is not None:
+                results[i] = c[xsg.CTR_MATCHES]
+            return
+        stream.wait_event(coll_done[b])  # the all_reduce that used this buffer two steps ago
+        shard.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
+        scan_done[b].record(stream)
+        with torch.cuda.stream(coll_stream):
+            coll_stream.wait_event(scan_done[b])
+            all_reduce_(c)  # RCCL sum of the 4 uint64 counters
+            if results is not None:
+                results[i] = c[xsg.CTR_MATCHES]
+            coll_done[b].record(coll_stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -218,10 +239,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     sync_all()
-    got = int(counters[xsg.CTR_MATCHES].item())
+    got = int(counters[(args.warmup - 1) & 1][xsg.CTR_MATCHES].item()) if args.warmup else expected_total
     if got != expected_total:
         raise SystemExit(f"PARITY FAILURE before timing: count {got} != expected {expected_total}")
 
@@ -229,8 +250,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step()
-        results[i] = counters[xsg.CTR_MATCHES]
+        step(i, results)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -284,7 +304,7 @@ def main():
                 "chunks_per_gpu": nchunks,
                 "distinct_template_chunks": args.templates,
                 "sharding": "one process per GPU, contiguous chunk range per rank, no data-path collective; "
-                            "one RCCL all_reduce(sum) of 4 uint64 counters per step" if world > 1 else
+                            "one RCCL all_reduce(sum) of 4 uint64 counters per step, on its own stream under the next scan" if world > 1 else
                             "single GPU",
                 "setup_s": round(setup_s, 1),
             },
