@@ -25,10 +25,11 @@
 // opened/parsed or no MI355X is usable; a failure inside a worker ends the
 // search and is thrown by join() / by the iterator that runs into it.
 //
-// Not served here: regular expressions (the reference routes them to RE2,
-// utils/utils.h:17-25): a pattern the reference would treat as a regex makes
-// extern_search throw std::invalid_argument (XS_FORCE_LITERAL=1 searches it as text).  ignore_case folds ASCII
-// letters only (what the reference's simd::toLower does).
+// Regular expressions: a pattern the reference would hand to RE2 (utils/utils.h:17-25) is searched as a
+// regex here too IF it is a fixed-length sequence of byte classes (`She[r ]lock`, `[0-9]{4}-\d\d`: XSG_FLAG_REGEX
+// in xsg.h -- every regex the reference's tests use); any other regex makes extern_search throw
+// std::invalid_argument instead of being searched as text with different results (XS_FORCE_LITERAL=1 searches
+// it as plain text).  ignore_case folds ASCII letters only (what the reference's simd::toLower does).
 //
 // Environment: XS_DEVICE (HIP device index, default 0), XS_CHUNK_BYTES (target
 // chunk size without a metafile, default 16 MiB).
@@ -109,8 +110,8 @@ inline uint64_t env_u64(const char* name, uint64_t dflt) {
 
 // The reference decides per pattern whether it is a regular expression: it is one
 // iff the pattern, read as a regex, does not match itself (utils/utils.h:17-25; an
-// invalid regex counts as plain text).  Regex search is RE2's job there and is not
-// served by this engine, so such a pattern is refused loudly instead of being
+// invalid regex counts as plain text).  Such a pattern goes to the kernel's class-sequence
+// matcher when that can decide it (xsg_regex_check) and is refused loudly otherwise, never
 // searched as a literal with different results.  XS_FORCE_LITERAL=1 overrides.
 inline bool reference_routes_to_regex(const std::string& pattern) {
   try {
@@ -118,6 +119,21 @@ inline bool reference_routes_to_regex(const std::string& pattern) {
   } catch (const std::regex_error&) {
     return false;
   }
+}
+
+// XSG_FLAG_* for a pattern, routed as the reference routes it; throws std::invalid_argument for a
+// regular expression the GPU matcher does not serve.
+inline uint32_t pattern_flags(const std::string& pattern, bool ignore_case) {
+  uint32_t flags = ignore_case ? XSG_FLAG_IGNORE_CASE : 0u;  // ASCII, as simd::toLower (string_utils.cpp:11-33)
+  if (reference_routes_to_regex(pattern) && env_u64("XS_FORCE_LITERAL", 0) == 0) {
+    if (xsg_regex_check(pattern.data(), pattern.size(), flags, nullptr, nullptr) != XSG_OK)
+      throw std::invalid_argument("xs::extern_search: '" + pattern +
+                                  "' is a regular expression for the reference (utils/utils.h:17-25) that the GPU "
+                                  "matcher does not serve: " + xsg_last_error() +
+                                  " (set XS_FORCE_LITERAL=1 to search it as plain text)");
+    flags |= XSG_FLAG_REGEX;
+  }
+  return flags;
 }
 
 template <class T>
@@ -229,14 +245,10 @@ class ExternSearcher {
 
   ExternSearcher(const std::string& pattern, const std::string& file_path, const std::string& meta_file_path,
                  bool ignore_case, int num_threads, int num_max_readers) {
-    if (detail::reference_routes_to_regex(pattern) && detail::env_u64("XS_FORCE_LITERAL", 0) == 0)
-      throw std::invalid_argument("xs::extern_search: '" + pattern +
-                                  "' is a regular expression for the reference (utils/utils.h:17-25); this engine "
-                                  "searches literals only (set XS_FORCE_LITERAL=1 to search it as plain text)");
     xsg_job_opts o;
     xsg_job_opts_init(&o);
+    o.pattern_flags = detail::pattern_flags(pattern, ignore_case);
     o.mode = detail::traits<Tag>::mode;
-    if (ignore_case) o.pattern_flags |= XSG_FLAG_IGNORE_CASE;  // ASCII, as simd::toLower (string_utils.cpp:11-33)
     o.device = static_cast<int32_t>(detail::env_u64("XS_DEVICE", 0));
     o.num_threads = num_threads < 1 ? 1 : num_threads;
     o.num_max_readers = num_max_readers < 1 ? 1 : num_max_readers;

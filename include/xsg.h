@@ -73,6 +73,19 @@ enum xsg_mode {
  * and xs::lines returns the ORIGINAL bytes (goldens keep their case,
  * test/src/xsearchTest.cpp:227-240). */
 #define XSG_FLAG_IGNORE_CASE 0x2u
+/* The pattern is a regular expression.  The reference hands a pattern that "does
+ * not match itself as a regex" (include/xsearch/utils/utils.h:17-25) to RE2 and
+ * walks the chunk with RE2::PartialMatch
+ * (include/xsearch/string_search/search_wrappers.h:63-87,209-271).  Served here:
+ * fixed-length sequences of byte classes -- literals, [positive ASCII classes],
+ * \d \w \s, escapes, atom{n}, transparent ( ) -- which is every regex the
+ * reference's tests use (`She[r ]lock`, test/src/xsearchTest.cpp:9; `(a[n|m]t)`,
+ * test/src/string_search/search_wrappersTest.cpp:78).  Up to 32 positions.
+ * Anything else (repetition, alternation, anchors, '.', negated classes) returns
+ * XSG_ENOTSUP from xsg_set_pattern: refused, never approximated.  No tail
+ * quirk applies (RE2 is exact); XSG_FLAG_IGNORE_CASE folds ASCII letters in the
+ * data and in every class, as for literals. */
+#define XSG_FLAG_REGEX 0x4u
 
 #define XSG_MAX_PATTERN 1024u
 
@@ -112,10 +125,18 @@ int xsg_device_count(int* count);
 /* ---- context -------------------------------------------------------------- */
 int xsg_ctx_create(int device, xsg_ctx** out);
 void xsg_ctx_destroy(xsg_ctx* ctx);
-/* Literal pattern, 1..XSG_MAX_PATTERN bytes, any byte values.  Patterns
- * containing '\n' are accepted for XSG_COUNT_MATCHES / XSG_MATCH_BYTE_OFFSETS
- * only (the line modes return XSG_ENOTSUP for them). */
+/* Literal pattern, 1..XSG_MAX_PATTERN bytes, any byte values (or, with
+ * XSG_FLAG_REGEX, a class-sequence expression).  Patterns that can match a
+ * '\n' are accepted for XSG_COUNT_MATCHES / XSG_MATCH_BYTE_OFFSETS only (the
+ * line modes return XSG_ENOTSUP for them). */
 int xsg_set_pattern(xsg_ctx* ctx, const void* pattern, size_t plen, uint32_t flags);
+/* Would XSG_FLAG_REGEX accept this expression?  XSG_OK, or XSG_ENOTSUP with the
+ * reason in xsg_last_error().  Needs no device (callers route on it the way the
+ * reference routes on use_str_as_regex, utils/utils.h:17-25).  Optional outputs:
+ * the number of byte positions, and their 256-bit sets (room for 32 x 8 uint32;
+ * bit b of sets[8*k + b/32] set <=> position k accepts byte b; folded if
+ * XSG_FLAG_IGNORE_CASE is in flags). */
+int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets);
 
 /* ---- shards ---------------------------------------------------------------- */
 /* d_base/capacity: device memory owned by the caller (hipMalloc, a torch

@@ -407,3 +407,149 @@ uint64_t xso_count_chunks_mt(const char* base, const uint64_t* offsets, const ui
   pthread_mutex_destroy(&job.mu);
   return job.total;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Regex wrappers for fixed-length class sequences                           */
+/* (include/xsearch/string_search/search_wrappers.h:63-103, 209-271).        */
+/*                                                                           */
+/* The reference calls re2::RE2::PartialMatch(input, pattern, &match).  RE2  */
+/* is a git submodule of the reference without a recorded commit and is not  */
+/* in the snapshot: version UNPINNED.  For the only family    */
+/* served -- a fixed number of positions, each accepting a set of bytes,     */
+/* the whole expression inside capture group 1 -- RE2's published semantics  */
+/* (leftmost match; all alternatives have the same length, so there is       */
+/* nothing for "first" or "longest" to decide) reduce to: the smallest       */
+/* offset at which every set accepts its byte.  cs_partial_match is that;    */
+/* the walks above it restate the reference's loops line by line.  Pinned by */
+/* search_wrappersTest.cpp:74-105 ("(a[n|m]t)" -> {2,151,197,507},           */
+/* {0,113,176,460}, 4) and cross-checked against CPython's `re`              */
+/* (tests/test_oracle_regex.py).                                             */
+/* ------------------------------------------------------------------------ */
+static int cs_accepts(const xso_classseq* cs, uint32_t k, unsigned char b) {
+  return (cs->sets[k][b >> 5] >> (b & 31u)) & 1u;
+}
+
+/* stand-in for RE2::PartialMatch(input, "(<class sequence>)", &match): offset of the match in input or -1
+ * (match.size() is always cs->plen) */
+static int64_t cs_partial_match(const xso_classseq* cs, const char* input, size_t len) {
+  if (cs->plen == 0 || len < cs->plen) return -1;
+  const size_t last = len - cs->plen;
+  for (size_t o = 0; o <= last; ++o) {
+    uint32_t k = 0;
+    while (k < cs->plen && cs_accepts(cs, k, (unsigned char)input[o + k])) ++k;
+    if (k == cs->plen) return (int64_t)o;
+  }
+  return -1;
+}
+
+/* _regex_byte_offsets (:63-87); as_line_start = the func of regex::byte_offsets_line (:220-225) */
+static uint64_t regex_byte_offsets(const char* data, size_t len, const xso_classseq* cs, int skip_to_nl,
+                                   int as_line_start, uint64_t* out, uint64_t cap) {
+  uint64_t n = 0;
+  const char* input = data; /* re2::StringPiece input(data.data(), data.size()) */
+  size_t input_len = len;
+  size_t total_shift = 0;
+  for (;;) {
+    const int64_t at = cs_partial_match(cs, input, input_len); /* :72 */
+    if (at < 0) break;
+    size_t shift = (size_t)at; /* :73 match.data() - input.data() */
+    const uint64_t v = shift + total_shift;
+    if (n < cap) out[n] = as_line_start ? line_start_of(data, v) : v; /* :74 */
+    ++n;
+    shift += cs->plen; /* :75 match.size() */
+    input += shift;    /* :76 remove_prefix */
+    input_len -= shift;
+    if (skip_to_nl) { /* :77-85 */
+      const char* nl = (const char*)memchr(input, '\n', input_len);
+      if (!nl) break;
+      const size_t next_nl = (size_t)(nl - input) + 1;
+      shift += next_nl;
+      input += next_nl;
+      input_len -= next_nl;
+    }
+    total_shift += shift; /* :86 */
+  }
+  return n;
+}
+
+/* regex::byte_offsets_match (:242-245) */
+uint64_t xso_regex_byte_offsets_match(const char* data, size_t len, const xso_classseq* cs, int skip_to_nl,
+                                      uint64_t* out, uint64_t cap) {
+  return regex_byte_offsets(data, len, cs, skip_to_nl, 0, out, cap);
+}
+
+/* regex::byte_offsets_line (:220-225) */
+uint64_t xso_regex_byte_offsets_line(const char* data, size_t len, const xso_classseq* cs, uint64_t* out,
+                                     uint64_t cap) {
+  return regex_byte_offsets(data, len, cs, 1, 1, out, cap);
+}
+
+/* regex::count (:250-271) */
+uint64_t xso_regex_count(const char* data, size_t len, const xso_classseq* cs, int skip_to_nl) {
+  uint64_t counter = 0;
+  const char* input = data;
+  size_t input_len = len;
+  for (;;) {
+    const int64_t at = cs_partial_match(cs, input, input_len); /* :255 */
+    if (at < 0) break;
+    size_t shift = (size_t)at;
+    counter++;
+    shift += cs->plen;
+    input += shift;
+    input_len -= shift;
+    if (skip_to_nl) { /* :260-267 */
+      const char* nl = (const char*)memchr(input, '\n', input_len);
+      if (!nl) break;
+      const size_t next_nl = (size_t)(nl - input) + 1;
+      input += next_nl;
+      input_len -= next_nl;
+    }
+  }
+  return counter;
+}
+
+/* The snapshot has no regex `line` / line_indices wrapper; xs::lines and xs::line_indices with a regex
+ * (test/src/xsearchTest.cpp:102-125,173-335) are modelled as the literal walks (:187-207, header note on
+ * line_indices) with the regex find in place of findNext. */
+uint64_t xso_regex_lines(const char* data, size_t len, const xso_classseq* cs, uint64_t* begin, uint64_t* length,
+                         uint64_t cap) {
+  uint64_t n = 0;
+  size_t shift = 0;
+  while (shift < len) {
+    const int64_t at = cs_partial_match(cs, data + shift, len - shift);
+    if (at < 0) break;
+    const uint64_t m = shift + (uint64_t)at;
+    const uint64_t b = line_start_of(data, m);
+    shift = (size_t)m + cs->plen;
+    const char* nl = (const char*)memchr(data + shift, '\n', len - shift);
+    if (!nl) break;
+    const uint64_t e = (uint64_t)(nl - data);
+    shift = (size_t)e + 1;
+    if (n < cap) {
+      begin[n] = b;
+      length[n] = e - b;
+    }
+    ++n;
+  }
+  return n;
+}
+
+uint64_t xso_regex_line_indices(const char* data, size_t len, const xso_classseq* cs, uint64_t line_base,
+                                uint64_t* out, uint64_t cap) {
+  uint64_t n = 0, counted_to = 0, nl_seen = 0;
+  size_t shift = 0;
+  while (shift < len) {
+    const int64_t at = cs_partial_match(cs, data + shift, len - shift);
+    if (at < 0) break;
+    const uint64_t m = shift + (uint64_t)at;
+    const uint64_t b = line_start_of(data, m);
+    for (; counted_to < b; ++counted_to) nl_seen += data[counted_to] == '\n';
+    if (n < cap) out[n] = line_base + nl_seen;
+    ++n;
+    shift = (size_t)m + cs->plen;
+    const char* nl = (const char*)memchr(data + shift, '\n', len - shift);
+    if (!nl) break;
+    shift = (size_t)(nl - data) + 1;
+  }
+  return n;
+}

@@ -75,6 +75,25 @@ uint64_t xso_line_indices(const char* data, size_t len, const char* pat, size_t 
                           uint64_t* out, uint64_t cap);
 uint64_t xso_count_newlines(const char* data, size_t len);
 
+/* ---- regex wrappers, class-sequence family only (search_wrappers.h:63-103,209-271) ---- */
+/* RE2 (unpinned submodule, absent) is restated for fixed-length sequences of byte sets only: see the
+ * block comment in xs_oracle.c.  The expression -> sets parser of the oracle lives in xs_oracle.py
+ * (compile_class_sequence); bit b of sets[k] set <=> position k accepts byte b. */
+typedef struct xso_classseq {
+  uint32_t plen;          /* 1..32 positions */
+  uint32_t sets[32][8];
+} xso_classseq;
+uint64_t xso_regex_byte_offsets_match(const char* data, size_t len, const xso_classseq* cs, int skip_to_nl,
+                                      uint64_t* out, uint64_t cap);                              /* :242-245 */
+uint64_t xso_regex_byte_offsets_line(const char* data, size_t len, const xso_classseq* cs, uint64_t* out,
+                                     uint64_t cap);                                               /* :220-225 */
+uint64_t xso_regex_count(const char* data, size_t len, const xso_classseq* cs, int skip_to_nl); /* :250-271 */
+/* no regex line()/line_indices in the snapshot: the literal walks with the regex find (inferred) */
+uint64_t xso_regex_lines(const char* data, size_t len, const xso_classseq* cs, uint64_t* begin, uint64_t* length,
+                         uint64_t cap);
+uint64_t xso_regex_line_indices(const char* data, size_t len, const xso_classseq* cs, uint64_t line_base,
+                                uint64_t* out, uint64_t cap);
+
 /* ---- ignore_case building block (src/utils/string_utils.cpp:11-33) ------- */
 /* simd::toLower: bytes 'A'..'Z' += 32 in place (signed compares in the AVX2 body,
  * std::tolower in the C locale for the remainder: ASCII only, bytes >= 0x80 untouched).

@@ -101,7 +101,15 @@ def main():
         # stale (the test is not registered with ctest).  Contract: no trailing \n.
         "line_as_asserted_stale": lines_with_nl,
         "line": [s[:-1] for s in lines_with_nl],
+        # the regex wrappers on the same text (:74-105); the expression is passed to re2::RE2 wrapped in a group
+        "regex": {
+            "pattern": "(a[n|m]t)",
+            "byte_offsets_match": [2, 151, 197, 507],   # :77-78, :82-83
+            "byte_offsets_line": [0, 113, 176, 460],    # :90-91, :95-96
+            "count": 4,                                   # :103
+        },
     }
+    assert '"(a[n|m]t)"' in wr_src and "res{2, 151, 197, 507}" in wr_src and "res{0, 113, 176, 460}" in wr_src
     (OUT / "ref_search_wrappers_known_answers.json").write_text(json.dumps(wr, indent=1))
     print("ok", len(text), len(wtext))
 

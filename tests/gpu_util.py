@@ -37,7 +37,8 @@ class GpuSearch:
         return chunks
 
     def all_modes(self, pattern: bytes, flags=0, lines=True):
-        """-> dict with every xs:: tag's result for the bound shard."""
+        """-> dict with every xs:: tag's result for the bound shard (lines=False: the pattern can match a
+        newline, so only the match tags apply)."""
         self.ctx.set_pattern(pattern, flags)
         s = self.shard
         out = {}
@@ -46,7 +47,7 @@ class GpuSearch:
         out["newlines"] = int(c[xsg.CTR_NEWLINES])
         out["bytes"] = int(c[xsg.CTR_BYTES])
         out["match_byte_offsets"] = s.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
-        if lines and b"\n" not in pattern:
+        if lines and (b"\n" not in pattern or (flags & xsg.FLAG_REGEX)):
             out["count_lines"] = int(s.count(xsg.COUNT_LINES)[xsg.CTR_LINES])
             out["line_byte_offsets"] = s.search_u64(xsg.LINE_BYTE_OFFSETS).tolist()
             out["line_indices"] = s.search_u64(xsg.LINE_INDICES).tolist()
@@ -92,3 +93,35 @@ def oracle_all_modes(oracle, blocks, pattern: bytes, exact=False, global_offsets
         return out
     finally:
         oracle.set_exact(False)
+
+
+def oracle_regex_all_modes(oracle, blocks, expr: bytes, ignore_case=False, global_offsets=None, line_bases=None):
+    """oracle_all_modes for a class-sequence regex (search_wrappers.h:63-103,209-271 restated in oracle/)."""
+    from xs_oracle import compile_class_sequence
+    cs = compile_class_sequence(expr, ignore_case)
+    orig_blocks = blocks
+    if ignore_case:
+        blocks = [oracle.lower(b) for b in blocks]
+    with_lines = not any(cs.accepts(k, 10) for k in range(cs.plen))
+    out = {"count_matches": 0, "newlines": 0, "bytes": 0, "match_byte_offsets": []}
+    if with_lines:
+        out.update({"count_lines": 0, "line_byte_offsets": [], "line_indices": [], "lines": [], "lines_offsets": []})
+    goff, nl_before = 0, 0
+    for i, b in enumerate(blocks):
+        g = goff if global_offsets is None else int(global_offsets[i])
+        lb = nl_before if line_bases is None else int(line_bases[i])
+        out["count_matches"] += oracle.regex_count(b, cs, False)
+        out["match_byte_offsets"] += [int(x) + g for x in oracle.regex_byte_offsets_match(b, cs)]
+        if with_lines:
+            out["count_lines"] += oracle.regex_count(b, cs, True)
+            out["line_byte_offsets"] += [int(x) + g for x in oracle.regex_byte_offsets_line(b, cs)]
+            out["line_indices"] += [int(x) for x in oracle.regex_line_indices(b, cs, lb)]
+            beg, ln = oracle.regex_lines_spans(b, cs)
+            out["lines"] += [orig_blocks[i][int(s):int(s + l)].tobytes() for s, l in zip(beg, ln)]
+            out["lines_offsets"] += [int(s) + g for s in beg]
+        nl = oracle.count_newlines(b)
+        out["newlines"] += nl
+        out["bytes"] += int(b.size)
+        goff += int(b.size)
+        nl_before += nl
+    return out, with_lines

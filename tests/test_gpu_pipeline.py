@@ -356,12 +356,32 @@ def test_concurrent_jobs_and_early_destroy(files):
         j.close()
 
 
-def test_regex_patterns_are_refused_loudly(files):
-    """'She[r ]lock' is a regex for the reference (utils/utils.h:17-25; 53 matches in its
-    goldens, xsearchTest.cpp:19): this engine must not silently search it as text."""
-    r = run_cli("count", "join", "She[r ]lock", files["txt"])
-    assert r.returncode == 1 and b"regular expression" in r.stderr
+def test_regex_routing_of_extern_search(files, oracle):
+    """'She[r ]lock' is a regex for the reference (utils/utils.h:17-25; 53 matches in its goldens,
+    xsearchTest.cpp:19): xs::extern_search serves it through the kernel's class-sequence matcher, for every
+    tag, with and without ignore_case; a regex outside that family is refused loudly, never searched as text."""
+    from gpu_util import oracle_regex_all_modes
+    data = np.fromfile(files["txt"], dtype=np.uint8)
+    plan = xsg.plan_chunks(files["txt"], CHUNK)
+    chunks = [data[int(c["original_offset"]):int(c["original_offset"] + c["original_size"])] for c in plan]
+    for icase in (False, True):
+        want, _ = oracle_regex_all_modes(oracle, chunks, b"She[r ]lock", icase)
+        lit = oracle_all_modes(oracle, chunks, b"Sherlock", ignore_case=icase)
+        assert want["count_matches"] >= lit["count_matches"] > 0
+        for tag in TAGS:
+            r = run_cli(tag, "join", "She[r ]lock", files["txt"], env={"XS_IGNORE_CASE": "1"} if icase else None)
+            assert r.returncode == 0, r.stderr
+            if tag in ("count", "count_lines"):
+                assert int(r.stdout) == want[KEY[tag]], (tag, icase)
+            elif tag == "lines":
+                assert r.stdout.split(b"\n")[:-1] == want["lines"], icase
+            else:
+                assert [int(x) for x in r.stdout.split()] == want[KEY[tag]], (tag, icase)
     r = run_cli("count", "join", "She[r ]lock", files["txt"], env={"XS_FORCE_LITERAL": "1"})
     assert r.returncode == 0 and int(r.stdout) == 0
-    r = run_cli("count", "join", "a.b", files["txt"])  # matches itself as a regex -> plain text for the reference too
-    assert r.returncode == 0
+    for expr in ("Sherlock|Holmes", "Sher?lock", "^Sherlock", "She[^r]lock"):
+        r = run_cli("count", "join", expr, files["txt"])
+        assert r.returncode == 1 and b"regular expression" in r.stderr and b"does not serve" in r.stderr, (expr, r.stderr)
+    for expr in ("a.b", "She.*lock"):  # these match themselves as regexes -> plain text for the reference too
+        r = run_cli("count", "join", expr, files["txt"])
+        assert r.returncode == 0 and int(r.stdout) == 0

@@ -1,0 +1,128 @@
+"""XSG_FLAG_REGEX on the GPU (class-sequence expressions decided inside k_scan) against the oracle's
+restatement of the reference's regex walks (search_wrappers.h:63-103,209-271), all six tags, bit-exact."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import corpus
+import xsg
+from gpu_util import GpuSearch, oracle_all_modes, oracle_regex_all_modes
+from test_oracle_regex import ACCEPTED, REFUSED, rand_expr
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def gs():
+    return GpuSearch()
+
+
+def check(gs, oracle, blocks, expr, icase=False, ctx="", **kw):
+    want, with_lines = oracle_regex_all_modes(oracle, blocks, expr, icase, **kw)
+    got = gs.all_modes(expr, xsg.FLAG_REGEX | (xsg.FLAG_IGNORE_CASE if icase else 0), lines=with_lines)
+    for k in want:
+        assert got[k] == want[k], f"{ctx} expr={expr!r} icase={icase}: {k}: got {str(got[k])[:160]} want {str(want[k])[:160]}"
+    return want
+
+
+def test_reference_known_answers(gs, oracle):
+    ka = json.loads((GOLD / "ref_search_wrappers_known_answers.json").read_text())
+    text = np.frombuffer(ka["text"].encode("latin-1"), dtype=np.uint8)
+    gs.bind([text])
+    r = ka["regex"]
+    got = gs.all_modes(r["pattern"].encode(), xsg.FLAG_REGEX)
+    assert got["match_byte_offsets"] == r["byte_offsets_match"]   # search_wrappersTest.cpp:77-83
+    assert got["line_byte_offsets"] == r["byte_offsets_line"]     # :90-96
+    assert got["count_lines"] == r["count"]                       # :103
+    assert [x.decode() for x in got["lines"]] == ka["line"]
+    check(gs, oracle, [text], r["pattern"].encode())
+
+
+def test_the_integration_tests_expression_on_text(gs, oracle):
+    """`She[r ]lock` (test/src/xsearchTest.cpp:9) on generated text with both spellings planted, several chunks."""
+    rng = np.random.default_rng(31)
+    blocks = []
+    for i in range(4):
+        b = corpus.text_block(900 + i, 0, 3_000_000 + 777 * i, needle_rate=3e-5)
+        nl = np.flatnonzero(b == 10)
+        for pos in rng.choice(nl[:-2], size=40, replace=False):
+            w = [b"She lock", b"SHE LOCK", b"sherlock", b"She\tlock", b"Sherlocc"][int(rng.integers(0, 5))]
+            b[pos + 1:pos + 1 + len(w)] = np.frombuffer(w, dtype=np.uint8)
+        blocks.append(b)
+    gs.bind(blocks)
+    for icase in (False, True):
+        want = check(gs, oracle, blocks, b"She[r ]lock", icase, "text")
+        lit = oracle_all_modes(oracle, blocks, b"Sherlock", True, ignore_case=icase)
+        assert want["count_matches"] > lit["count_matches"] > 50   # the class adds the `She lock` spellings
+    assert check(gs, oracle, blocks, b"She[r ]lock", True)["count_matches"] > check(gs, oracle, blocks, b"She[r ]lock")["count_matches"]
+
+
+def test_accepted_expressions_and_literal_only_ones(gs, oracle):
+    rng = np.random.default_rng(8)
+    alphabet = np.frombuffer(b"abcABC xyz019_-.]\n\tgreyant[|m\xc3\xa9", dtype=np.uint8)
+    blocks = [alphabet[rng.integers(0, len(alphabet), size=n)].copy() for n in (70_000, 16384, 16385, 33, 5, 0, 40_001)]
+    for b in blocks:
+        if b.size:
+            b[-1] = 10
+    gs.bind(blocks)
+    for expr in ACCEPTED + [b"a\\.b", b"\\]\\.", b"A", b"\\n", b"[ab]\\n", b"\\s\\s"]:
+        for icase in (False, True):
+            check(gs, oracle, blocks, expr, icase, "accepted")
+    # an expression of singletons is an ordinary literal without the reference's scalar-tail quirk
+    gs.ctx.set_pattern(b"ab\\.", xsg.FLAG_REGEX)
+    a = gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
+    gs.ctx.set_pattern(b"ab.", xsg.FLAG_EXACT_TAIL)
+    assert a == gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
+
+
+@pytest.mark.parametrize("expr", REFUSED[:12])
+def test_refused_expressions_fail_loudly(gs, expr):
+    with pytest.raises(xsg.XsgError) as ei:
+        gs.ctx.set_pattern(expr, xsg.FLAG_REGEX)
+    assert ei.value.code in (xsg.ENOTSUP, xsg.EINVAL)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_expressions(gs, oracle, seed):
+    rng = np.random.default_rng(5000 + seed)
+    sizes = [0, 1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1023, 1024, 1025, 4096, 4097, 16383, 16384, 16385, 32769]
+    alphabets = [np.frombuffer(b"abcABC xyz019_-.]\n\n\t", dtype=np.uint8), np.frombuffer(b"ab\n", dtype=np.uint8),
+                 np.frombuffer(b"abc019 \n", dtype=np.uint8)]
+    for it in range(20):
+        alphabet = alphabets[int(rng.integers(0, len(alphabets)))]
+        blocks = []
+        for _ in range(int(rng.integers(1, 6))):
+            n = int(rng.choice(sizes)) if rng.random() < 0.7 else int(rng.integers(0, 80_000))
+            b = alphabet[rng.integers(0, len(alphabet), size=n)].copy()
+            if n and rng.random() < 0.6:
+                b[-1] = 10
+            blocks.append(b)
+        gs.bind(blocks)
+        for _ in range(6):
+            expr = rand_expr(rng)
+            try:
+                xsg.regex_check(expr)
+            except xsg.XsgError:
+                continue
+            check(gs, oracle, blocks, expr, bool(rng.integers(0, 2)), f"seed={seed} it={it} sizes={[b.size for b in blocks]}")
+
+
+def test_global_offsets_line_bases_and_job_api(gs, oracle, tmp_path):
+    blocks = [corpus.text_block(77, i, 200_000) for i in range(3)]
+    goffs = [10**9, 5 * 10**9, 2**40]
+    bases = [7, 1000, 123456789]
+    gs.bind(blocks, goffs, bases)
+    check(gs, oracle, blocks, b"[Tt]he [a-z]{3} ", False, "global", global_offsets=goffs, line_bases=bases)
+    # through the file pipeline (xsg_job_*): pattern_flags carries XSG_FLAG_REGEX
+    data = np.concatenate(blocks)
+    path = tmp_path / "t.txt"
+    data.tofile(path)
+    want, _ = oracle_regex_all_modes(oracle, [data], b"[Tt]he [a-z]{3} ")
+    j = xsg.Job(b"[Tt]he [a-z]{3} ", str(path), mode=xsg.MATCH_BYTE_OFFSETS, flags=xsg.FLAG_REGEX, chunk_bytes=65536,
+                num_threads=2, num_max_readers=2)
+    got = j.result().tolist()
+    # chunks are newline-aligned, so per-chunk walks concatenate to the whole-file walk
+    assert got == want["match_byte_offsets"]

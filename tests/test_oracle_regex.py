@@ -1,0 +1,139 @@
+"""The regex row, class-sequence family: the oracle's restatement of the reference's
+regex walks (include/xsearch/string_search/search_wrappers.h:63-103,209-271) against the reference's own
+known answers, and both expression parsers -- the oracle's (oracle/xs_oracle.py) and the product's
+(x-search_amd/csrc/xsg_classseq.cpp through the C ABI, no GPU needed) -- against each other and against
+CPython's `re` as an independent reading of the syntax."""
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import xs_oracle
+import xsg
+from xs_oracle import UnsupportedRegex, compile_class_sequence
+
+GOLD = Path(__file__).parent / "golden"
+
+REFUSED = [b"a.b", b"a*", b"ab+", b"colou?r", b"a|b", b"^ab", b"ab$", b"[^a]b", b"x{2,3}", b"x{2,}", b"\\Dab", b"\\Wab",
+           b"\\Sab", b"\\bab", b"(?i)ab", b"(?:ab)", b"(ab){2}", b"(ab)*", b"[[:alpha:]]b", b"ab\\", b"[ab", b"(ab", b"ab)",
+           b"\\pLab", b"\\Qab\\E", b"\\1", b"[\xc3\xa9]", b"\xff", b"a{0}", b"{2}", b"\\x{100}", b"\\xzz", b"()",
+           b"a" * 33, b"\xc3\xa9{2}"]
+ACCEPTED = [b"She[r ]lock", b"(a[n|m]t)", b"[0-9]{4}-\\d\\d", b"a\\.b", b"\\w{3} \\w", b"[]a]x", b"[a\\]]x", b"[a-]x", b"[-a]x",
+            b"gr[ae]y", b"((a)[bc])d", b"\\x41\\x{42}[\\x43-\\x45]", b"caf\xc3\xa9 [ab]", b"a]b}", b"\\t[ \\t]x", b"[\\d_]x",
+            b"\\[a\\]", b"a{3}b{1}", b"[a-c]{32}"]
+
+
+def product_sets(expr, icase=False):
+    n, sets = xsg.regex_check(expr, xsg.FLAG_IGNORE_CASE if icase else 0)
+    return n, sets
+
+
+def oracle_sets(expr, icase=False):
+    cs = compile_class_sequence(expr, icase)
+    return cs.plen, np.array([[cs.sets[k][q] for q in range(8)] for k in range(cs.plen)], dtype=np.uint32)
+
+
+def test_reference_known_answers_for_the_regex_wrappers(oracle):
+    ka = json.loads((GOLD / "ref_search_wrappers_known_answers.json").read_text())
+    text = ka["text"].encode("latin-1")
+    r = ka["regex"]
+    cs = compile_class_sequence(r["pattern"].encode())
+    assert oracle.regex_byte_offsets_match(text, cs).tolist() == r["byte_offsets_match"]   # search_wrappersTest.cpp:77-83
+    assert oracle.regex_byte_offsets_line(text, cs).tolist() == r["byte_offsets_line"]     # :90-96
+    assert oracle.regex_count(text, cs) == r["count"]                                      # :103
+    # the same text and the literal `ant`: the regex answers equal the literal ones in the reference's tests
+    assert r["byte_offsets_match"] == ka["byte_offsets_match"] and r["byte_offsets_line"] == ka["byte_offsets_line"]
+    beg, ln = oracle.regex_lines_spans(text, cs)
+    assert [text[int(b):int(b + l)].decode() for b, l in zip(beg, ln)] == ka["line"]
+
+
+@pytest.mark.parametrize("expr", REFUSED)
+def test_both_parsers_refuse(expr):
+    with pytest.raises(UnsupportedRegex):
+        compile_class_sequence(expr)
+    with pytest.raises(xsg.XsgError) as ei:
+        xsg.regex_check(expr)
+    assert ei.value.code in (xsg.ENOTSUP, xsg.EINVAL)
+    assert "not supported" in str(ei.value)
+
+
+@pytest.mark.parametrize("expr", ACCEPTED)
+def test_both_parsers_agree(expr):
+    for icase in (False, True):
+        no, so = oracle_sets(expr, icase)
+        npr, sp = product_sets(expr, icase)
+        assert no == npr
+        assert (so == sp).all(), expr
+
+
+def rand_expr(rng):
+    """A random class-sequence expression in the syntax both RE2 and CPython read the same way."""
+    letters = b"abcABC xyz019_-.]"
+    out = []
+    npos = 0
+    while npos < int(rng.integers(1, 9)):
+        k = int(rng.integers(0, 10))
+        if k <= 3:
+            c = letters[int(rng.integers(0, len(letters)))]
+            out.append(b"\\" + bytes([c]) if c in b".-]" else bytes([c]))
+        elif k <= 6:
+            members = bytes(letters[int(i)] for i in rng.integers(0, 13, size=int(rng.integers(1, 4))))
+            body = b"".join(b"\\" + bytes([m]) if m in b"]-\\^" else bytes([m]) for m in members)
+            if rng.random() < 0.3:
+                body += b"a-c" if rng.random() < 0.5 else b"0-9"
+            out.append(b"[" + body + b"]")
+        elif k == 7:
+            out.append([b"\\d", b"\\w", b"\\s"][int(rng.integers(0, 3))])
+        elif k == 8 and out and not out[-1].endswith(b"}") and out[-1] != b"(" and out[-1] != b")":
+            r = int(rng.integers(1, 4))
+            out.append(b"{%d}" % r)
+            npos += r - 1
+            continue
+        else:
+            c = letters[int(rng.integers(0, 12))]
+            out.append(bytes([c]))
+        npos += 1
+    e = b"".join(out)
+    return b"(" + e + b")" if rng.random() < 0.3 else e
+
+
+def test_parsers_and_walk_against_cpython_re(oracle):
+    rng = np.random.default_rng(20231)
+    alphabet = np.frombuffer(b"abcABC xyz019_-.]\n\n\t", dtype=np.uint8)
+    done = 0
+    for it in range(400):
+        expr = rand_expr(rng)
+        icase = bool(rng.integers(0, 2))
+        try:
+            pyre = re.compile(expr, re.IGNORECASE if icase else 0)
+        except re.error:
+            continue
+        no, so = oracle_sets(expr, icase)
+        npr, sp = product_sets(expr, icase)
+        assert no == npr and (so == sp).all(), expr
+        data = alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 3000)))].tobytes()
+        cs = compile_class_sequence(expr, icase)
+        hay = oracle.lower(data).tobytes() if icase else data
+        got = oracle.regex_byte_offsets_match(hay, cs).tolist()
+        want = [m.start() for m in pyre.finditer(data)]  # leftmost, non-overlapping: the walk of :63-87
+        assert got == want, (expr, icase)
+        assert oracle.regex_count(hay, cs, False) == len(want)
+        # one match per line (skip_to_nl): first match of every line that has one
+        per_line = []
+        pos = 0
+        while True:
+            m = pyre.search(data, pos)
+            if not m:
+                break
+            per_line.append(m.start())
+            nl = data.find(b"\n", m.end())
+            if nl < 0:
+                break
+            pos = nl + 1
+        if not any(cs.accepts(k, 10) for k in range(cs.plen)):
+            assert oracle.regex_byte_offsets_match(hay, cs, True).tolist() == per_line, (expr, icase)
+            assert oracle.regex_count(hay, cs, True) == len(per_line)
+        done += 1
+    assert done > 300

@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
       // stdin (grep.cpp:37: "input file, stdin if '-' or empty"): no file to plan chunks on, so
       // read newline-aligned chunks here and hand each to the reference-style searcher functors
       // (include/xsearch/tasks/gpu_searchers.h), like Searcher::run_thread does with a reader.
-      const uint32_t flags = icase ? XSG_FLAG_IGNORE_CASE : 0u;
+      const uint32_t flags = xs::detail::pattern_flags(pattern, icase);
       xs::GpuLineSearcher<std::vector<char>> lines(pattern, 0, 1, flags);
       xs::GpuCountSearcher<std::vector<char>> counter(pattern, true, 0, 1, flags);
       const size_t target = 16u << 20;

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "xsg_classseq.h"
 #include "xsg_objects.h"
 #include "xsg_linesum.h"
 #include "xsg_tail.h"
@@ -132,21 +133,22 @@ static uint32_t le32(const uint8_t* p, size_t n) {
 // text: one that spans a word boundary is (a pair of words is far rarer than either
 // word), then upper case / digits / non-ASCII, then the rarer letters.  Static
 // heuristic, no look at the data; `detective street` -> "ective s".
+static int byte_rarity(uint8_t c, int pos_in_window) {
+  const bool lower = c >= 'a' && c <= 'z', upper = c >= 'A' && c <= 'Z', digit = c >= '0' && c <= '9';
+  if (c >= 0x80) return 30;
+  if (!lower && !upper && !digit) return (pos_in_window >= 1 && pos_in_window <= 6) ? 40 : 10;
+  if (upper || digit) return 12;
+  if (strchr("jqxzvkwbypgf", c)) return 6;
+  return 1;
+}
+
 static uint32_t pick_filter_window(const uint8_t* p, size_t plen) {
   if (plen <= 8) return 0;
   uint32_t best = 0;
   int best_score = -1;
   for (size_t k = 0; k + 8 <= plen; ++k) {
     int score = 0;
-    for (int i = 0; i < 8; ++i) {
-      const uint8_t c = p[k + i];
-      const bool lower = c >= 'a' && c <= 'z', upper = c >= 'A' && c <= 'Z', digit = c >= '0' && c <= '9';
-      if (c >= 0x80) score += 30;
-      else if (!lower && !upper && !digit) score += (i >= 1 && i <= 6) ? 40 : 10;
-      else if (upper || digit) score += 12;
-      else if (strchr("jqxzvkwbypgf", c)) score += 6;
-      else score += 1;
-    }
+    for (int i = 0; i < 8; ++i) score += byte_rarity(p[k + i], i);
     if (score > best_score) {
       best_score = score;
       best = (uint32_t)k;
@@ -157,11 +159,86 @@ static uint32_t pick_filter_window(const uint8_t* p, size_t plen) {
 
 static uint32_t mask32(size_t n) { return n >= 4 ? 0xffffffffu : (n == 0 ? 0u : ((1u << (8 * n)) - 1u)); }
 
+// XSG_FLAG_REGEX: a fixed-length class sequence (xsg_classseq.h).  RE2 has no lossy tail, so the
+// matching is exact up to the end of the chunk (as with XSG_FLAG_EXACT_TAIL).
+static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t flags) {
+  std::vector<xsg::ByteSet> seq;
+  std::string err;
+  if (!xsg::compile_class_sequence(re, n, &seq, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
+  const bool icase = (flags & XSG_FLAG_IGNORE_CASE) != 0;
+  if (icase) xsg::fold_sets(&seq);
+  const size_t plen = seq.size();
+  bool literal = true;
+  std::vector<uint8_t> lit(plen);
+  for (size_t k = 0; k < plen; ++k) {
+    const int b = xsg::set_single(seq[k]);
+    literal &= b >= 0;
+    lit[k] = (uint8_t)(b >= 0 ? b : 0);
+  }
+  if (literal)  // e.g. `a\.b`: an ordinary literal, minus the reference's scalar-tail quirk (RE2 has none)
+    return xsg_set_pattern(c, lit.data(), plen, (flags & XSG_FLAG_IGNORE_CASE) | XSG_FLAG_EXACT_TAIL);
+
+  HIP_TRY(hipSetDevice(c->device));
+  c->pattern.assign(re, re + n);
+  c->flags = flags;
+  c->bordered = xsg::sequence_can_overlap(seq);
+  // the window with the most (and rarest) literal bytes; class positions inside it are don't-care bytes
+  uint32_t koff = 0;
+  int best = -1;
+  for (size_t k = 0; k < plen; ++k) {
+    int score = 0;
+    for (int i = 0; i < 8 && k + i < plen; ++i)
+      if (xsg::set_single(seq[k + i]) >= 0) score += 100 + byte_rarity(lit[k + i], i);
+    if (score > best) best = score, koff = (uint32_t)k;
+  }
+  uint32_t pw[2] = {0, 0}, mw[2] = {0, 0};
+  for (int i = 0; i < 8 && koff + i < plen; ++i)
+    if (xsg::set_single(seq[koff + i]) >= 0) {
+      pw[i >> 2] |= (uint32_t)lit[koff + i] << (8 * (i & 3));
+      mw[i >> 2] |= 0xffu << (8 * (i & 3));
+    }
+  XSG_TRY(c->d_pat.ensure(XSG_MAX_PATTERN + 16));
+  static_assert(xsg::kMaxClassSeq * sizeof(xsg::ByteSet) <= XSG_MAX_PATTERN, "sets must fit the pattern buffer");
+  std::vector<uint8_t> padded(XSG_MAX_PATTERN + 16, 0);
+  memcpy(padded.data(), seq.data(), plen * sizeof(xsg::ByteSet));
+  HIP_TRY(hipMemcpyAsync(c->d_pat.p, padded.data(), padded.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+
+  PatternDev& P = c->pat;
+  P = PatternDev{};
+  P.plen = (uint32_t)plen;
+  P.kind = kClass;
+  P.koff = koff;
+  P.p0 = pw[0], P.m0 = mw[0], P.p1 = pw[1], P.m1 = mw[1];
+  P.d_pat = c->d_pat.as<uint8_t>();
+  P.exact_tail = 1u;
+  P.icase = icase ? 1u : 0u;
+  P.has_newline = 0;
+  for (const xsg::ByteSet& s : seq) P.has_newline |= xsg::set_has(s, '\n') ? 1u : 0u;
+  return XSG_OK;
+}
+
+extern "C" int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets) {
+  if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
+  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  std::vector<xsg::ByteSet> seq;
+  std::string err;
+  if (!xsg::compile_class_sequence(static_cast<const uint8_t*>(expr), n, &seq, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
+  if (flags & XSG_FLAG_IGNORE_CASE) xsg::fold_sets(&seq);
+  if (positions) *positions = (uint32_t)seq.size();
+  if (sets) memcpy(sets, seq.data(), seq.size() * sizeof(xsg::ByteSet));
+  return XSG_OK;
+}
+
 extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uint32_t flags) {
   if (!c) return fail(XSG_EINVAL, "ctx is null");
   if (!pattern || plen == 0) return fail(XSG_EINVAL, "empty pattern");
   if (plen > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "pattern longer than %u bytes", XSG_MAX_PATTERN);
-  if (flags & ~(XSG_FLAG_EXACT_TAIL | XSG_FLAG_IGNORE_CASE)) return fail(XSG_EINVAL, "unknown pattern flags 0x%x", flags);
+  if (flags & ~(XSG_FLAG_EXACT_TAIL | XSG_FLAG_IGNORE_CASE | XSG_FLAG_REGEX))
+    return fail(XSG_EINVAL, "unknown pattern flags 0x%x", flags);
+  if (flags & XSG_FLAG_REGEX) return set_class_pattern(c, static_cast<const uint8_t*>(pattern), plen, flags);
   HIP_TRY(hipSetDevice(c->device));
   c->pattern.assign(static_cast<const uint8_t*>(pattern), static_cast<const uint8_t*>(pattern) + plen);
   if (flags & XSG_FLAG_IGNORE_CASE)  // simd::toLower on the pattern (string_utils.cpp:11-33)

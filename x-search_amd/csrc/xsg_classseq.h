@@ -1,0 +1,45 @@
+// xsg_classseq.h -- the regular expressions the scan kernel can decide itself.
+//
+// The reference sends a pattern to RE2 when it "does not match itself as a
+// regex" (include/xsearch/utils/utils.h:17-25) and then walks the chunk with
+// RE2::PartialMatch (include/xsearch/string_search/search_wrappers.h:63-87,
+// 209-271).  The only regexes its tests use are fixed-length sequences of byte
+// classes -- `She[r ]lock` (test/src/xsearchTest.cpp:9), `(a[n|m]t)`
+// (test/src/string_search/search_wrappersTest.cpp:78).  For exactly that family
+// a match is a position where every class accepts its byte: the same
+// position-wise decision as a literal, so it runs in k_scan.  Everything else
+// (repetition, alternation, anchors, `.`, negated classes -- the last two match
+// multi-byte UTF-8 code points in RE2) is refused, never approximated.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <array>
+#include <string>
+#include <vector>
+
+namespace xsg {
+
+constexpr uint32_t kMaxClassSeq = 32;  // positions; 32 x 256 bits = 1 KiB, the LDS the long-pattern path already has
+
+using ByteSet = std::array<uint32_t, 8>;  // bit b set <=> byte b is accepted
+
+inline bool set_has(const ByteSet& s, uint32_t b) { return (s[b >> 5] >> (b & 31u)) & 1u; }
+inline void set_add(ByteSet& s, uint32_t b) { s[b >> 5] |= 1u << (b & 31u); }
+uint32_t set_size(const ByteSet& s);
+// the only member of a singleton set, else -1
+int set_single(const ByteSet& s);
+
+// Parses `re` (RE2 syntax subset, see the .cpp) into one byte set per position.
+// Returns false with a message in `err` if the expression is not a fixed-length
+// class sequence of 1..kMaxClassSeq positions.
+bool compile_class_sequence(const uint8_t* re, size_t n, std::vector<ByteSet>* seq, std::string* err);
+
+// ignore_case as for literals (toLower on data and pattern, src/utils/string_utils.cpp:11-33):
+// the kernel folds the data bytes, so every set is replaced by the fold of its members.
+void fold_sets(std::vector<ByteSet>* seq);
+
+// true if two occurrences can overlap: some shift 0 < s < n with seq[k] and seq[k+s] intersecting for all k
+bool sequence_can_overlap(const std::vector<ByteSet>& seq);
+
+}  // namespace xsg

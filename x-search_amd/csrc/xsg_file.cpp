@@ -766,9 +766,16 @@ extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_
                                                                   XSG_MAX_PATTERN);
   if (opts->mode > XSG_LINES) return fail(XSG_EINVAL, "bad mode %u", opts->mode);
   if (opts->num_threads < 1 || opts->num_max_readers < 1) return fail(XSG_EINVAL, "num_threads/num_max_readers < 1");
-  if (opts->mode != XSG_COUNT_MATCHES && opts->mode != XSG_MATCH_BYTE_OFFSETS &&
-      memchr(pattern, '\n', plen) != nullptr)
+  const bool line_mode = opts->mode != XSG_COUNT_MATCHES && opts->mode != XSG_MATCH_BYTE_OFFSETS;
+  if (opts->pattern_flags & XSG_FLAG_REGEX) {  // refuse an expression the kernel cannot decide here, not in a worker
+    uint32_t npos = 0;
+    std::vector<uint32_t> sets(32 * 8, 0);
+    XSG_TRY(xsg_regex_check(pattern, plen, opts->pattern_flags & XSG_FLAG_IGNORE_CASE, &npos, sets.data()));
+    for (uint32_t k = 0; line_mode && k < npos; ++k)
+      if (sets[8 * k] & (1u << '\n')) return fail(XSG_ENOTSUP, "line modes do not accept a pattern that can match '\\n'");
+  } else if (line_mode && memchr(pattern, '\n', plen) != nullptr) {
     return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+  }
   // fail early and loudly without a device: there is no CPU search path
   int ndev = 0;
   XSG_TRY(xsg_device_count(&ndev));
@@ -1022,6 +1029,7 @@ extern "C" int xsg_host_searcher_create(int device, const void* pattern, size_t 
   *out = nullptr;
   if (!pattern || plen == 0 || plen > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "pattern must be 1..%u bytes",
                                                                   XSG_MAX_PATTERN);
+  if (flags & XSG_FLAG_REGEX) XSG_TRY(xsg_regex_check(pattern, plen, flags & XSG_FLAG_IGNORE_CASE, nullptr, nullptr));
   int ndev = 0;
   XSG_TRY(xsg_device_count(&ndev));
   if (device < 0 || device >= ndev) return fail(XSG_ENODEV, "device %d out of range", device);

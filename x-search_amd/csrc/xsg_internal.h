@@ -38,7 +38,9 @@ enum FilterKind : int {
   kOne = 1,    // plen 4    : one dword compare
   kMask2 = 2,  // plen 5..7 : one dword + one masked dword
   kTwo = 3,    // plen 8    : two dword compares (exact)
-  kLong = 4    // plen > 8  : two dword compares, then bytes 8..15 in registers, then memory for the rest
+  kLong = 4,   // plen > 8  : two dword compares, then bytes 8..15 in registers, then memory for the rest
+  kClass = 5   // class sequence (xsg_classseq.h): two masked dword compares over the literal bytes of the window,
+               // then every position against its 256-bit set (d_pat holds the sets, 32 bytes per position)
 };
 
 struct PatternDev {
@@ -46,7 +48,7 @@ struct PatternDev {
   uint32_t kind;
   uint32_t p0, m0, p1, m1;  // the 8 pattern bytes of the filter window (pattern[koff..koff+8)) as dwords + byte masks
   uint32_t p2, m2, p3, m3;  // the 8 bytes after the window (kLong: checked in registers before any memory compare)
-  uint32_t koff;            // kLong: offset of the 8-byte filter window inside the pattern (0 for the other kinds)
+  uint32_t koff;            // kLong, kClass: offset of the 8-byte filter window inside the pattern (0 for the other kinds)
   const uint8_t* d_pat;     // device copy of the pattern
   uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL
   uint32_t has_newline;     // pattern contains '\n'

@@ -157,6 +157,7 @@ __device__ __forceinline__ void windows(const uint32_t (&d)[8], uint32_t (&w)[N]
 template <int KIND>
 __device__ __forceinline__ bool cand_at(const uint32_t (&w)[20], int b, const PatternDev& P) {
   if (KIND == kMask1) return (w[b] & P.m0) == P.p0;
+  if (KIND == kClass) return ((w[b] & P.m0) == P.p0) & ((w[b + 4] & P.m1) == P.p1);
   if (KIND == kOne) return w[b] == P.p0;
   if (KIND == kMask2) return (w[b] == P.p0) & ((w[b + 4] & P.m1) == P.p1);
   return (w[b] == P.p0) & (w[b + 4] == P.p1);
@@ -190,13 +191,14 @@ template <int KIND, bool ICASE>
 __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const PatternDev& P, const uint8_t* cbase,
                                                  uint64_t unit_off, uint64_t limit, const uint8_t* lds_pat) {
   uint32_t m = cand_mask16<KIND>(d, P);
-  const uint32_t koff = KIND == kLong ? P.koff : 0u;
+  const uint32_t koff = KIND >= kLong ? P.koff : 0u;
   // the match starts at o = window - koff and must satisfy 0 <= o < limit
   const uint64_t lim_w = limit + koff;
   if (unit_off >= lim_w) return 0;
   if (unit_off + kUnit > lim_w) m &= (1u << (uint32_t)(lim_w - unit_off)) - 1u;
+  if (KIND >= kLong && unit_off < koff)
+    m &= koff - unit_off >= kUnit ? 0u : ~((1u << (uint32_t)(koff - unit_off)) - 1u);
   if (KIND == kLong) {
-    if (unit_off < koff) m &= koff - unit_off >= kUnit ? 0u : ~((1u << (uint32_t)(koff - unit_off)) - 1u);
     // the 8 pattern bytes after the window, still in registers (d[6], d[7] hold the neighbour's upper half)
     if (__any(m != 0)) {
       uint32_t w[28];
@@ -219,6 +221,22 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
         for (uint32_t k = koff + 16; k < P.plen && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
         if (!ok) m &= ~(1u << b);
       }
+    }
+  }
+  if (KIND == kClass) {
+    // the window compare saw only the literal bytes: every position against its byte set (LDS, 8 dwords each)
+    const uint32_t* sets = reinterpret_cast<const uint32_t*>(lds_pat);
+    uint32_t c = m;
+    while (c) {
+      const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
+      c &= c - 1u;
+      const uint8_t* s = cbase + unit_off + b - koff;
+      bool ok = true;
+      for (uint32_t k = 0; k < P.plen && ok; ++k) {
+        const uint32_t x = fold(s[k], ICASE);
+        ok = (sets[k * 8u + (x >> 5)] >> (x & 31u)) & 1u;
+      }
+      if (!ok) m &= ~(1u << b);
     }
   }
   return m;
@@ -338,7 +356,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
   } else {
     if (m) {
       st.cnt += (uint32_t)__popc(m);
-      st.last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen - (KIND == kLong ? P.koff : 0u);
+      st.last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen - (KIND >= kLong ? P.koff : 0u);
     }
     if (WANT_LINES) {
       // A wave-load without any match start (the common case) summarises to "has a
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   constexpr uint32_t kTile = kWaveSpan * kWaves;         // bytes per workgroup
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
-  __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND == kLong ? XSG_MAX_PATTERN : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND >= kLong ? XSG_MAX_PATTERN : 16];
 
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (tile >= A.ntiles) return;
@@ -381,6 +399,11 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
 
   if (KIND == kLong) {
     for (uint32_t k = tid; k < P.plen; k += kBlock) s_pat[k] = P.d_pat[k];
+    __syncthreads();
+  }
+  if (KIND == kClass) {  // 256-bit set per position (P.plen <= 32: at most 1 KiB)
+    for (uint32_t k = tid; k < P.plen * 8u; k += kBlock)
+      reinterpret_cast<uint32_t*>(s_pat)[k] = reinterpret_cast<const uint32_t*>(P.d_pat)[k];
     __syncthreads();
   }
 
@@ -513,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
         while (mm) {
           const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
           mm &= mm - 1u;
-          A.m_pos[r] = unit_off + b - (KIND == kLong ? P.koff : 0u);
+          A.m_pos[r] = unit_off + b - (KIND >= kLong ? P.koff : 0u);
           A.m_chunk[r] = c;
           ++r;
         }
@@ -576,6 +599,7 @@ static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_line
     case kOne: return launch_scan_loads<kOne>(a, want_nl, want_lines, emit, grid, s);
     case kMask2: return launch_scan_loads<kMask2>(a, want_nl, want_lines, emit, grid, s);
     case kTwo: return launch_scan_loads<kTwo>(a, want_nl, want_lines, emit, grid, s);
+    case kClass: return launch_scan_loads<kClass>(a, want_nl, want_lines, emit, grid, s);
     default: return launch_scan_loads<kLong>(a, want_nl, want_lines, emit, grid, s);
   }
 }

@@ -22,6 +22,7 @@ EINVAL, ENODEV, EHIP, ENOMEM, ENOTSUP, EIO, ESTATE = -1, -2, -3, -4, -5, -6, -7
 COUNT_MATCHES, COUNT_LINES, MATCH_BYTE_OFFSETS, LINE_BYTE_OFFSETS, LINE_INDICES, LINES = range(6)
 FLAG_EXACT_TAIL = 0x1
 FLAG_IGNORE_CASE = 0x2
+FLAG_REGEX = 0x4
 WITH_NEWLINES = 0x100
 CTR_MATCHES, CTR_LINES, CTR_NEWLINES, CTR_BYTES = range(4)
 NUM_COUNTERS = 4
@@ -98,6 +99,7 @@ def load():
         "xsg_ctx_create": (ci, [ci, C.POINTER(vp)]),
         "xsg_ctx_destroy": (None, [vp]),
         "xsg_set_pattern": (ci, [vp, C.c_char_p, sz, u32]),
+        "xsg_regex_check": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32)]),
         "xsg_shard_create": (ci, [vp, vp, u64, vp, u64, C.POINTER(vp)]),
         "xsg_shard_rebind": (ci, [vp, vp, u64, vp, u64]),
         "xsg_shard_destroy": (None, [vp]),
@@ -141,7 +143,7 @@ def load():
 
 
 EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_count", "xsg_ctx_create",
-           "xsg_ctx_destroy", "xsg_set_pattern", "xsg_shard_create", "xsg_shard_rebind", "xsg_shard_destroy",
+           "xsg_ctx_destroy", "xsg_set_pattern", "xsg_regex_check", "xsg_shard_create", "xsg_shard_rebind", "xsg_shard_destroy",
            "xsg_shard_set_line_base", "xsg_count_async", "xsg_count", "xsg_search", "xsg_result_u64",
            "xsg_result_lines_size", "xsg_result_lines", "xsg_ctx_info", "xsg_time_scan_kernel", "xsg_time_read_ceiling", "xsg_result_newlines",
            "xsg_job_opts_init", "xsg_job_start", "xsg_job_join", "xsg_job_destroy", "xsg_job_total", "xsg_job_wait", "xsg_job_poll",
@@ -153,6 +155,15 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
 def _check(rc):
     if rc != OK:
         raise XsgError(rc, load().xsg_last_error().decode("utf-8", "replace"))
+
+
+def regex_check(expr: bytes, flags: int = 0):
+    """-> (positions, sets[positions, 8] uint32) if XSG_FLAG_REGEX serves `expr`; raises XsgError otherwise.  No GPU needed."""
+    lib = load()
+    n = C.c_uint32(0)
+    sets = np.zeros((32, 8), dtype=np.uint32)
+    _check(lib.xsg_regex_check(expr, len(expr), flags, C.byref(n), sets.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return int(n.value), sets[:n.value].copy()
 
 
 def device_count() -> int:
