@@ -23,7 +23,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", type=float, default=8.0)
     ap.add_argument("--dir", default="/dev/shm")
-    ap.add_argument("--threads", default="1,2,4,8,16")
+    ap.add_argument("--threads", default="1,2,4,8,16",
+                    help="comma list of worker counts; W:R sets the reader (pread + decompress) threads separately")
     ap.add_argument("--modes", default="count,count_lines,match_byte_offsets,lines")
     ap.add_argument("--meta", default="", help="also run through a metafile: comma list of none,lz4,zst")
     a = ap.parse_args()
@@ -58,16 +59,17 @@ def main():
     try:
       for vname, dpath, mpath in variants:
         for name in a.modes.split(","):
-            for th in [int(x) for x in a.threads.split(",")]:
+            for spec in a.threads.split(","):
+                th, rd = (int(x) for x in spec.split(":")) if ":" in spec else (int(spec), int(spec))
                 t0 = time.perf_counter()
-                j = xsg.Job(b"Sherlock", dpath, modes[name], meta_path=mpath, num_threads=th, num_max_readers=th)
+                j = xsg.Job(b"Sherlock", dpath, modes[name], meta_path=mpath, num_threads=th, num_max_readers=rd)
                 r = j.result()
                 dt = time.perf_counter() - t0
                 st = j.stats()
                 j.close()
                 got = r if isinstance(r, int) else len(r)
                 ok = (got == want) if name in ("count", "match_byte_offsets") else None
-                print(json.dumps({"input": vname, "mode": name, "threads": th, "gib": round(size / 2**30, 2), "seconds": round(dt, 3),
+                print(json.dumps({"input": vname, "mode": name, "threads": th, "readers": rd, "gib": round(size / 2**30, 2), "seconds": round(dt, 3),
                                   "gib_per_s": round(size / dt / 2**30, 2), "result": got, "parity": ok,
                                   "read_s": round(st["seconds_read"], 2), "decompress_s": round(st["seconds_decompress"], 2),
                                   "device_s": round(st["seconds_device"], 2)}),
