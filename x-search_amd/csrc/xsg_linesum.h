@@ -51,16 +51,15 @@ XSG_LS_HD uint32_t sum_of_unit(uint32_t h, uint32_t n) {
   const uint32_t F = (h & (first - 1u)) != 0;               // match before the first newline
   const uint32_t top = 31u - (uint32_t)__builtin_clz(n);    // index of the highest newline bit
   const uint32_t Lh = (h >> (top + 1u)) != 0;               // match after the last newline
-  uint32_t C = 0;
-  uint32_t rest = n & (n - 1u);  // newlines after the first
-  uint32_t lo = first;           // a closed segment = the bits strictly between lo and the next newline bit
-  while (rest) {
-    const uint32_t nx = rest & (0u - rest);
-    const uint32_t between = (nx - 1u) & ~(lo | (lo - 1u));
-    C += (h & between) != 0;
-    lo = nx;
-    rest &= rest - 1u;
-  }
+  // Closed segments that hold a match, without walking the newlines: with g = the positions that are neither
+  // match nor newline, adding a 1 just above every newline ripples through the gap bits and lands on the first
+  // event after that newline (the next newline stops a ripple before it can meet the next injection).  Where it
+  // lands on a match, the segment that starts at that newline holds one; it is closed iff it lies below the
+  // last newline.
+  const uint32_t ev = h | n;
+  const uint32_t g = ~ev & 0xffffu;
+  const uint32_t first_after_nl = (g + (n << 1)) & ev & h;
+  const uint32_t C = (uint32_t)__builtin_popcount(first_after_nl & ((1u << top) - 1u));
   return kSumNl | (F << 1) | (Lh << 2) | (C << kSumCShift);
 }
 
