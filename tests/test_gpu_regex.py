@@ -85,13 +85,13 @@ def test_refused_expressions_fail_loudly(gs, expr):
     assert ei.value.code in (xsg.ENOTSUP, xsg.EINVAL)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_expressions(gs, oracle, seed):
+def regex_rounds(seed, oracle, gs, rounds=20):
+    """`rounds` random shards x up to 6 random class-sequence expressions; AssertionError on the first difference."""
     rng = np.random.default_rng(5000 + seed)
     sizes = [0, 1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1023, 1024, 1025, 4096, 4097, 16383, 16384, 16385, 32769]
     alphabets = [np.frombuffer(b"abcABC xyz019_-.]\n\n\t", dtype=np.uint8), np.frombuffer(b"ab\n", dtype=np.uint8),
                  np.frombuffer(b"abc019 \n", dtype=np.uint8)]
-    for it in range(20):
+    for it in range(rounds):
         alphabet = alphabets[int(rng.integers(0, len(alphabets)))]
         blocks = []
         for _ in range(int(rng.integers(1, 6))):
@@ -108,6 +108,11 @@ def test_random_expressions(gs, oracle, seed):
             except xsg.XsgError:
                 continue
             check(gs, oracle, blocks, expr, bool(rng.integers(0, 2)), f"seed={seed} it={it} sizes={[b.size for b in blocks]}")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_expressions(gs, oracle, seed):
+    regex_rounds(seed, oracle, gs)
 
 
 def test_global_offsets_line_bases_and_job_api(gs, oracle, tmp_path):
