@@ -75,6 +75,11 @@ def main():
                 ms = sh.time_scan_kernel(mode, a.iters)
                 emit(round=r, tile_kib=tk, what="k_scan", pattern=pat, mode=name, ms=ms, gbs=shard_bytes / ms / 1e6)
             if r == 0:
+                for pat in ("Sherlock", "Sherl", "that", "Sherlock Holmes", "the"):
+                    ctx.set_pattern(pat.encode(), xsg.FLAG_IGNORE_CASE)
+                    ms = sh.time_scan_kernel(xsg.COUNT_MATCHES, a.iters)
+                    emit(round=r, tile_kib=tk, what="k_scan", pattern=pat, mode="icase count", ms=ms,
+                         gbs=shard_bytes / ms / 1e6)
                 for expr in ("She[r ]lock", "[Ss]herlock", "[0-9]{4}-[0-9]{2}", "[Tt]he [a-z]{3} "):
                     ctx.set_pattern(expr.encode(), xsg.FLAG_REGEX)
                     ms = sh.time_scan_kernel(xsg.COUNT_MATCHES, a.iters)

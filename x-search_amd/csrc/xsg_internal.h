@@ -48,6 +48,7 @@ struct PatternDev {
   uint32_t kind;
   uint32_t p0, m0, p1, m1;  // the 8 pattern bytes of the filter window (pattern[koff..koff+8)) as dwords + byte masks
   uint32_t p2, m2, p3, m3;  // the 8 bytes after the window (kLong: checked in registers before any memory compare)
+  uint32_t q0, q1;          // ignore_case hot filter: (p0 | 0x20202020) & m0, (p1 | 0x20202020) & m1 (k_scan, LAZY)
   uint32_t koff;            // kLong, kClass: offset of the 8-byte filter window inside the pattern (0 for the other kinds)
   const uint8_t* d_pat;     // device copy of the pattern
   uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL

@@ -260,11 +260,19 @@ template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool C
 __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, bool nx_is_vgpr, uint64_t unit_off,
                                               uint32_t lane, uint64_t L, uint64_t limit, const PatternDev& P,
                                               const uint8_t* cbase, const uint8_t* s_pat, WaveState& st) {
-  // ignore_case: fold the lane's own 4 dwords once; the neighbour's bytes then arrive
-  // already folded through the DPP exchange, and the wave-uniform edge values fold on
-  // the scalar unit ('\n' is not a letter: newline tests see the same bytes either way)
-  uint32_t d[8] = {ICASE ? fold4(cur.x) : cur.x, ICASE ? fold4(cur.y) : cur.y, ICASE ? fold4(cur.z) : cur.z,
-                   ICASE ? fold4(cur.w) : cur.w, 0u, 0u, 0u, 0u};
+  // ignore_case, patterns of 4+ bytes (LAZY): the hot filter does not need the exact fold.  (x | 0x20) == (p | 0x20)
+  // holds for every byte x that folds to the pattern byte p (exactly those when p is a letter, one more byte value
+  // otherwise), so the candidate test runs on data OR-ed with 0x20 -- one op per dword instead of fold4's seven --
+  // against P.q0/q1, and only a wave-load with a candidate folds its bytes properly for the exact decision.
+  // Patterns of 1..3 bytes (byte-parallel exact path, usually dense) fold up front: the neighbour's bytes then
+  // arrive already folded through the DPP exchange and the wave-uniform edge values fold on the scalar unit.
+  // '\n' is not a letter, but OR-ing changes it: the newline tests read the raw bytes (`r`).
+  constexpr bool LAZY = ICASE && KIND != kMask1;
+  constexpr uint32_t k20 = 0x20202020u;
+  uint32_t r[8] = {cur.x, cur.y, cur.z, cur.w, 0u, 0u, 0u, 0u};
+  uint32_t d[8] = {LAZY ? (cur.x | k20) : ICASE ? fold4(cur.x) : cur.x, LAZY ? (cur.y | k20) : ICASE ? fold4(cur.y) : cur.y,
+                   LAZY ? (cur.z | k20) : ICASE ? fold4(cur.z) : cur.z, LAZY ? (cur.w | k20) : ICASE ? fold4(cur.w) : cur.w,
+                   0u, 0u, 0u, 0u};
   const uint32_t own0 = d[0], own1 = d[1], own2 = d[2], own3 = d[3];  // what the left neighbour reads (never cleared)
   if (CAREFUL) {
     // bytes at or beyond L are not part of the chunk: clear them once
@@ -272,21 +280,22 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint64_t o = unit_off + 4u * q;
-        d[q] = o >= L ? 0u : (o + 4u > L ? d[q] & ((1u << (8u * (uint32_t)(L - o))) - 1u) : d[q]);
+        const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+        d[q] &= keep;
+        r[q] &= keep;
       }
     }
   }
   // the neighbour's first 8 bytes: lane+1's unit, lane 63 takes lane 0 of the next load / the edge
-  uint32_t e0 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.x) : nx.x;
-  uint32_t e1 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.y) : nx.y;
-  if (ICASE) {
-    e0 = fold4(e0);
-    e1 = fold4(e1);
-  }
+  const uint32_t e0r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.x) : nx.x;
+  const uint32_t e1r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.y) : nx.y;
+  const uint32_t e0 = LAZY ? (e0r | k20) : ICASE ? fold4(e0r) : e0r;
+  const uint32_t e1 = LAZY ? (e1r | k20) : ICASE ? fold4(e1r) : e1r;
   d[4] = from_next_lane(own0, e0, lane);
   d[5] = from_next_lane(own1, e1, lane);
+  const uint32_t(&nlsrc)[8] = LAZY ? r : d;  // own bytes as the newline tests must see them
 
-  if (WANT_NL) st.nlc += nl_count16(d);
+  if (WANT_NL) st.nlc += nl_count16(nlsrc);
 
   uint32_t m = 0;
   if (KIND == kMask1) {
@@ -336,8 +345,19 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
       return 0;
     }
   } else {
-    const bool any_c = cand_any<KIND>(d, P);
+    PatternDev Pf = P;  // what the hot filter compares against
+    if (LAZY) {
+      Pf.p0 = P.q0;
+      Pf.p1 = P.q1;
+    }
+    const bool any_c = cand_any<KIND>(d, Pf);
     if (__ballot(any_c) != 0) {
+      if (LAZY) {  // now the exact view: properly folded bytes, own and neighbour's
+        const uint32_t f0 = fold4(cur.x), f1 = fold4(cur.y);
+        d[0] = fold4(r[0]), d[1] = fold4(r[1]), d[2] = fold4(r[2]), d[3] = fold4(r[3]);  // r is already cleared
+        d[4] = from_next_lane(f0, fold4(e0r), lane);
+        d[5] = from_next_lane(f1, fold4(e1r), lane);
+      }
       if (KIND == kLong) {  // the neighbour's upper 8 bytes, for the in-register check of pattern bytes 8..15
         uint32_t e2 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
         uint32_t e3 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
@@ -345,8 +365,8 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
           e2 = fold4(e2);
           e3 = fold4(e3);
         }
-        d[6] = from_next_lane(own2, e2, lane);
-        d[7] = from_next_lane(own3, e3, lane);
+        d[6] = from_next_lane(LAZY ? fold4(cur.z) : own2, e2, lane);
+        d[7] = from_next_lane(LAZY ? fold4(cur.w) : own3, e3, lane);
       }
       m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat);
     }
@@ -365,9 +385,9 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
       if (__ballot(m != 0) != 0) {
         if (st.run_nl) st.wsum = sum_combine(st.wsum, kSumNl);
         st.run_nl = false;
-        st.wsum = sum_combine(st.wsum, wave_units_combine(sum_of_unit(m, nl_mask16(d))));
+        st.wsum = sum_combine(st.wsum, wave_units_combine(sum_of_unit(m, nl_mask16(nlsrc))));
       } else if (!st.run_nl) {
-        st.run_nl = __ballot(nl_any16(d)) != 0;
+        st.run_nl = __ballot(nl_any16(nlsrc)) != 0;
       }
     }
   }
@@ -590,7 +610,10 @@ static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_line
     // count_lines +1 % at a small stagger, every heavier variant -1..-3 %).
     // (unmasked compares = plen >= 4; a needle that is dense in the text makes any variant VALU-heavy
     // and loses 2-3 % to the stagger -- not knowable before the scan)
-    const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo || a.pat.kind == kLong) && !a.pat.icase && !want_nl && !emit;
+    // ignore_case: the hot loop of an 8-byte pattern only ORs 0x20 into the data (LAZY in scan_load) and stays
+    // memory-bound (7.0 -> 7.36 TB/s with the stagger); the other kinds measured 2-3 % slower with it
+    const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo || a.pat.kind == kLong) &&
+                       (!a.pat.icase || a.pat.kind == kTwo) && !want_nl && !emit;
     a.tune = !light ? 0u : (want_lines ? 4u : kDefaultStagger);
   }
   const dim3 grid = tile_grid(a.ntiles);
