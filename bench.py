@@ -310,7 +310,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "xsg::k_scan<3 /*kTwo*/, false, false, false, 4>",
+                "kernel": "xsg::k_scan<3, false, false, false, 4, false>",  # KIND kTwo, no NL/LINES/EMIT, 4 loads, no icase
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -17,6 +17,7 @@ step() {
   return $rc
 }
 : > $OUT/bench_round.log
+rm -rf $OUT/prof_${TAG}_stats $OUT/prof_${TAG}_fetch $OUT/prof_${TAG}_write  # gpurun_out/ is merged across calls: no stale CSVs
 step bench_4g 600 python bench.py --gib-per-gpu 4 --steps 10 --warmup 2 --cpu-seconds 6 || exit 1
 step bench_50g 900 python bench.py || exit 1
 grep '^{' $OUT/bench_50g.log > $OUT/BENCH_${TAG}_local.json
