@@ -250,6 +250,18 @@ def test_xsgrep_equals_gnu_grep(tmp_path):
         wc = subprocess.run(["grep", "-F", "-c", *args, str(p)], capture_output=True, env=env).stdout
         gc = subprocess.run([str(exe), "-c", *args, str(p)], capture_output=True, env=env, timeout=120).stdout
         assert gc == wc, args
+    # regular expressions of the class-sequence family: grep reads them as basic regexes the same way
+    for args in (["She[r ]lock"], ["-i", "she[r ]lock"], ["[Hh]olmes[ ,.]"], ["[0-9][0-9]*"]):
+        got = subprocess.run([str(exe), "-j", "2", *args, str(p)], capture_output=True, env=env, timeout=120)
+        if args == ["[0-9][0-9]*"]:  # not fixed-length: refused, not searched as text
+            assert got.returncode == 1 and b"does not serve" in got.stderr
+            continue
+        want = subprocess.run(["grep", *args, str(p)], capture_output=True, env=env).stdout
+        assert got.returncode == 0, got.stderr.decode()
+        assert got.stdout == want and len(want) > 0, args
+        wc = subprocess.run(["grep", "-c", *args, str(p)], capture_output=True, env=env).stdout
+        gc = subprocess.run([str(exe), "-c", *args, str(p)], capture_output=True, env=env, timeout=120).stdout
+        assert gc == wc, args
 
 
 def _dist_gpu_worker(rank, world, port, path, chunk_bytes, q):
