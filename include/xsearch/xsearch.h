@@ -232,6 +232,25 @@ class Result {
     for (uint64_t i = 0; i < n; ++i) out.push_back(detail::fetch<value_type>::get(_job, i));
     return out;
   }
+  // the read side of ResultTypes.h:91-115 (get / operator[] / at / is_closed); elements are flat
+  // values here (the reference's containers hold one partial result per chunk, its API layer flattens)
+  std::vector<value_type> get() const { return copyResultSafe(); }
+  value_type operator[](size_t index) const { return detail::fetch<value_type>::get(_job, index); }
+  value_type at(size_t index) const {
+    uint64_t n = 0;
+    int fin = 0;
+    const int r = xsg_job_poll(_job, &n, &fin);
+    if (r != XSG_OK) detail::throw_last("xs::Result::at", r);
+    if (index >= n) throw std::out_of_range("xs::Result::at");
+    return detail::fetch<value_type>::get(_job, index);
+  }
+  bool is_closed() const {
+    uint64_t n = 0;
+    int fin = 0;
+    const int r = xsg_job_poll(_job, &n, &fin);
+    if (r != XSG_OK) detail::throw_last("xs::Result::is_closed", r);
+    return fin != 0;
+  }
 
  private:
   xsg_job* _job;

@@ -50,6 +50,15 @@ int callsites(int argc, char** argv) {
     for (auto r : *res->getResult()) result.push_back(r);
     std::sort(result.begin(), result.end());
   }
+  {  // the read side of ResultTypes.h:91-115, and the regex of xsearchTest.cpp:9,391-396
+    auto res = xs::extern_search<xs::match_byte_offsets>("She[r ]lock", file_path, false, 1);
+    res->join();
+    auto& r = *res->getResult();
+    if (r.is_closed() && !r.empty()) {
+      std::vector<uint64_t> all = r.get();
+      if (all[0] != r[0] || r.at(0) != all.front()) return 1;
+    }
+  }
   {  // test/src/xsearchTest.cpp:735-739 (live count: the last value is the total)
     auto res = xs::extern_search<xs::count_matches>(pattern, file_path, false, 1);
     uint64_t result = 0;
