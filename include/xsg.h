@@ -69,9 +69,13 @@ enum xsg_mode {
  * implementation of the case-insensitive wrappers; the semantics here are the
  * reference's building block applied to both sides: simd::toLower
  * (src/utils/string_utils.cpp:11-33: 'A'..'Z' += 32, other bytes unchanged) on
- * the chunk and on the pattern, then the normal search.  Offsets are unchanged
- * and xs::lines returns the ORIGINAL bytes (goldens keep their case,
- * test/src/xsearchTest.cpp:227-240). */
+ * the chunk and on the pattern, then the normal search.  That is also exactly
+ * what the reference's own (uncalled) case-insensitive primitive computes:
+ * simd::strcasestr (src/string_search/simd_search.cpp:220-287) returns the same
+ * offset as strstr on the lowered chunk and pattern, end-of-chunk behaviour
+ * included (checked on the compiled reference, tests/test_oracle_golden.py).
+ * Offsets are unchanged and xs::lines returns the ORIGINAL bytes (goldens keep
+ * their case, test/src/xsearchTest.cpp:227-240). */
 #define XSG_FLAG_IGNORE_CASE 0x2u
 /* The pattern is a regular expression.  The reference hands a pattern that "does
  * not match itself as a regex" (include/xsearch/utils/utils.h:17-25) to RE2 and

@@ -409,6 +409,7 @@ class Reference:
         "strstr": "_ZN2xs6search4simd6strstrEPKcmS3_m",
         "strchr": "_ZN2xs6search4simd6strchrEPKcmc",
         "scalar_strstr": "_ZN2xs6search4simd13scalar_strstrEPKcmS3_m",
+        "strcasestr": "_ZN2xs6search4simd10strcasestrEPKcmS3_m",  # simd_search.cpp:220-287 (no caller in the snapshot)
     }
 
     @staticmethod
@@ -442,6 +443,17 @@ class Reference:
         self.fn_scalar_strstr = getattr(lib, self.SYM["scalar_strstr"])
         self.fn_scalar_strstr.argtypes = [vp, sz, cp, sz]
         self.fn_scalar_strstr.restype = vp
+        self.fn_strcasestr = getattr(lib, self.SYM["strcasestr"])
+        self.fn_strcasestr.argtypes = [vp, sz, cp, sz]
+        self.fn_strcasestr.restype = vp
+
+    def strcasestr(self, data, pat) -> int:
+        """Offset of simd::strcasestr's result or -1.  Patterns of 2+ bytes only: with one byte the reference
+        passes pattern_len - 2 == SIZE_MAX to compare_case_insensitive (simd_search.cpp:211)."""
+        b, p = _Buf(data), _as_bytes(pat)
+        assert len(p) >= 2
+        r = self.fn_strcasestr(b.addr, b.len, p, len(p))
+        return -1 if not r else r - b.addr
 
     def find_next(self, pat, data, shift=0) -> int:
         b, p = _Buf(data), _as_bytes(pat)

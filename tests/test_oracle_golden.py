@@ -127,3 +127,34 @@ def test_chunk_driver_matches_single_thread(oracle):
     for nt in (1, 4):
         tot, per = oracle.count_chunks_mt(buf, off, ln, b"Sherlock", False, nt)
         assert per.tolist() == want and tot == sum(want)
+
+
+def test_ignore_case_semantics_equal_the_references_strcasestr(oracle, reference):
+    """ignore_case is served as search(toLower(chunk), toLower(pattern)).  The snapshot has no
+    caller of its case-insensitive primitive, but the primitive exists: simd::strcasestr
+    (src/string_search/simd_search.cpp:220-287, scalar tail :80-104).  On the compiled reference, strcasestr(data, pat)
+    returns exactly what strstr(toLower(data), toLower(pat)) returns -- body, lossy tail and block anchoring included
+    -- so the convention is the reference's own (patterns of 2+ bytes; strcasestr is undefined for one byte)."""
+    import numpy as np
+    rng = np.random.default_rng(4711)
+    alphabets = [np.frombuffer(b"abAB", dtype=np.uint8), np.frombuffer(b"abcABC \n", dtype=np.uint8),
+                 np.frombuffer(b"Sherlock sHERLOCK\n", dtype=np.uint8), np.arange(256, dtype=np.uint8)]
+    n = 0
+    for it in range(6000):
+        al = alphabets[it % len(alphabets)]
+        size = int(rng.integers(0, 300))
+        data = al[rng.integers(0, len(al), size=size)].copy()
+        plen = int(rng.integers(2, 9))
+        if size > plen + 2 and rng.random() < 0.7:
+            o = int(rng.integers(0, size - plen))
+            pat = data[o:o + plen].copy()
+            flip = rng.random(plen) < 0.5  # change the case of some letters of the needle
+            pat = np.where(flip & (((pat | 0x20) >= 97) & ((pat | 0x20) <= 122)), pat ^ 0x20, pat).astype(np.uint8)
+        else:
+            pat = al[rng.integers(0, len(al), size=plen)].copy()
+        got = reference.strcasestr(data, pat.tobytes())
+        want = reference.strstr(oracle.lower(data), oracle.lower(pat).tobytes())
+        assert got == want, (data.tobytes(), pat.tobytes())
+        assert oracle.strstr(oracle.lower(data), oracle.lower(pat).tobytes()) == want
+        n += got >= 0
+    assert n > 1500
