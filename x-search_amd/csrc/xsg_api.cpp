@@ -273,12 +273,8 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   P.m0 = mask32(wlen);
   P.p1 = wlen > 4 ? le32(w + 4, wlen - 4) : 0u;
   P.m1 = wlen > 4 ? mask32(wlen - 4) : 0u;
-  P.p2 = wlen > 8 ? le32(w + 8, wlen - 8) : 0u;
-  P.m2 = wlen > 8 ? mask32(wlen - 8) : 0u;
-  P.p3 = wlen > 12 ? le32(w + 12, wlen - 12) : 0u;
   P.q0 = (P.p0 | 0x20202020u) & P.m0;
   P.q1 = (P.p1 | 0x20202020u) & P.m1;
-  P.m3 = wlen > 12 ? mask32(wlen - 12) : 0u;
   P.kind = plen < 4 ? kMask1 : plen == 4 ? kOne : plen < 8 ? kMask2 : plen == 8 ? kTwo : kLong;
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;

@@ -38,7 +38,7 @@ enum FilterKind : int {
   kOne = 1,    // plen 4    : one dword compare
   kMask2 = 2,  // plen 5..7 : one dword + one masked dword
   kTwo = 3,    // plen 8    : two dword compares (exact)
-  kLong = 4,   // plen > 8  : two dword compares, then bytes 8..15 in registers, then memory for the rest
+  kLong = 4,   // plen > 8  : two dword compares on the 8-byte filter window (koff), then memory for the rest
   kClass = 5   // class sequence (xsg_classseq.h): two masked dword compares over the literal bytes of the window,
                // then every position against its 256-bit set (d_pat holds the sets, 32 bytes per position)
 };
@@ -47,7 +47,6 @@ struct PatternDev {
   uint32_t plen;
   uint32_t kind;
   uint32_t p0, m0, p1, m1;  // the 8 pattern bytes of the filter window (pattern[koff..koff+8)) as dwords + byte masks
-  uint32_t p2, m2, p3, m3;  // the 8 bytes after the window (kLong: checked in registers before any memory compare)
   uint32_t q0, q1;          // ignore_case hot filter: (p0 | 0x20202020) & m0, (p1 | 0x20202020) & m1 (k_scan, LAZY)
   uint32_t koff;            // kLong, kClass: offset of the 8-byte filter window inside the pattern (0 for the other kinds)
   const uint8_t* d_pat;     // device copy of the pattern

@@ -199,28 +199,18 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
   if (KIND >= kLong && unit_off < koff)
     m &= koff - unit_off >= kUnit ? 0u : ~((1u << (uint32_t)(koff - unit_off)) - 1u);
   if (KIND == kLong) {
-    // the 8 pattern bytes after the window, still in registers (d[6], d[7] hold the neighbour's upper half)
-    if (__any(m != 0)) {
-      uint32_t w[28];
-      windows<28>(d, w);
-      uint32_t m2 = 0;
-#pragma unroll
-      for (int b = 0; b < 16; ++b)
-        m2 |= (uint32_t)(((w[b + 8] & P.m2) == P.p2) & ((w[b + 12] & P.m3) == P.p3)) << b;
-      m &= m2;
-    }
-    // everything outside [koff, koff+16): compare from memory (rare: 16 bytes already matched)
-    if (koff > 0 || P.plen > koff + 16) {
-      uint32_t c = m;
-      while (c) {
-        const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
-        c &= c - 1u;
-        const uint8_t* s = cbase + unit_off + b - koff;  // start of the match
-        bool ok = true;
-        for (uint32_t k = 0; k < koff && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
-        for (uint32_t k = koff + 16; k < P.plen && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
-        if (!ok) m &= ~(1u << b);
-      }
+    // everything outside the window [koff, koff+8): compare from memory against the pattern in LDS (rare: the
+    // 8 bytes of the window already matched).  An in-register check of the next 8 bytes (28 windows live) was
+    // dropped: it raised the kernel to 69-87 VGPRs = 5-7 waves per SIMD instead of 8, for every long pattern.
+    uint32_t c = m;
+    while (c) {
+      const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
+      c &= c - 1u;
+      const uint8_t* s = cbase + unit_off + b - koff;  // start of the match
+      bool ok = true;
+      for (uint32_t k = 0; k < koff && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
+      for (uint32_t k = koff + 8; k < P.plen && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
+      if (!ok) m &= ~(1u << b);
     }
   }
   if (KIND == kClass) {
@@ -273,7 +263,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
   uint32_t d[8] = {LAZY ? (cur.x | k20) : ICASE ? fold4(cur.x) : cur.x, LAZY ? (cur.y | k20) : ICASE ? fold4(cur.y) : cur.y,
                    LAZY ? (cur.z | k20) : ICASE ? fold4(cur.z) : cur.z, LAZY ? (cur.w | k20) : ICASE ? fold4(cur.w) : cur.w,
                    0u, 0u, 0u, 0u};
-  const uint32_t own0 = d[0], own1 = d[1], own2 = d[2], own3 = d[3];  // what the left neighbour reads (never cleared)
+  const uint32_t own0 = d[0], own1 = d[1];  // what the left neighbour reads (never cleared)
   if (CAREFUL) {
     // bytes at or beyond L are not part of the chunk: clear them once
     if (unit_off + kUnit > L) {
@@ -357,16 +347,6 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         d[0] = fold4(r[0]), d[1] = fold4(r[1]), d[2] = fold4(r[2]), d[3] = fold4(r[3]);  // r is already cleared
         d[4] = from_next_lane(f0, fold4(e0r), lane);
         d[5] = from_next_lane(f1, fold4(e1r), lane);
-      }
-      if (KIND == kLong) {  // the neighbour's upper 8 bytes, for the in-register check of pattern bytes 8..15
-        uint32_t e2 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
-        uint32_t e3 = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
-        if (ICASE) {
-          e2 = fold4(e2);
-          e3 = fold4(e3);
-        }
-        d[6] = from_next_lane(LAZY ? fold4(cur.z) : own2, e2, lane);
-        d[7] = from_next_lane(LAZY ? fold4(cur.w) : own3, e3, lane);
       }
       m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat);
     }
