@@ -166,3 +166,33 @@ def test_xsmeta_cli_cat_and_write(text_file, tmp_path):
     assert f"  original: {int(chunks[1]['original_offset'])}" in txt
     r = subprocess.run([str(exe), "cat", str(tmp_path / "nope.meta")], capture_output=True)
     assert r.returncode == 1 and b"cannot open" in r.stderr
+
+
+def test_builtin_lz4_codec_selftest():
+    """x-search_amd/csrc/xsg_lz4.h (the fallback when the host has no liblz4): round trips, interop with the host's
+    liblz4 in both directions, hostile blocks -- under AddressSanitizer + UBSan (tests/cpp/lz4_selftest.cpp)."""
+    import subprocess
+    exe = Path(__file__).resolve().parent / "cpp" / "build" / "lz4_selftest"
+    if not exe.exists():
+        pytest.fail(f"{exe} not built (make -C tests/cpp)")
+    r = subprocess.run([str(exe)], capture_output=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr).decode()
+    assert b"lz4 selftest ok" in r.stdout
+
+
+def test_builtin_lz4_writes_what_liblz4_reads(text_file, tmp_path):
+    """xsmeta write with XSG_NO_LIBLZ4=1 (built-in encoder): same chunk table as with liblz4, a valid data file."""
+    import os
+    import subprocess
+    exe = Path(__file__).resolve().parents[1] / "tools" / "build" / "xsmeta"
+    p, data = text_file
+    outs = {}
+    for tag, env in (("lib", {}), ("own", {"XSG_NO_LIBLZ4": "1"})):
+        meta, out = tmp_path / f"{tag}.meta", tmp_path / f"{tag}.xslz4"
+        r = subprocess.run([str(exe), "write", str(p), "--meta", str(meta), "--data", str(out), "--lz4", "--chunk-bytes",
+                            str(1 << 19)], capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()
+        outs[tag] = (xsg.meta_read(str(meta))[1], out.stat().st_size)
+    a, b = outs["lib"][0], outs["own"][0]
+    assert len(a) == len(b) and (a["original_offset"] == b["original_offset"]).all() and (a["original_size"] == b["original_size"]).all()
+    assert 0 < outs["own"][1] < data.size  # it does compress text

@@ -149,6 +149,9 @@ def test_cpp_extern_search_with_meta_and_errors(files):
     assert r.returncode == 0 and r.stdout.split(b"\n")[:-1] == files["want"][b"Sherlock"]["lines"]
     r = run_cli("count", "join", "Sherlock", "/nonexistent/file.txt")
     assert r.returncode == 1 and b"cannot open" in r.stderr
+    # the same LZ4 corpus through the built-in block decoder (what a host without liblz4 uses)
+    r = run_cli("match_byte_offsets", "join", "Sherlock", data_path, meta_path, "4", "4", env={"XSG_NO_LIBLZ4": "1"})
+    assert r.returncode == 0 and [int(x) for x in r.stdout.split()] == files["want"][b"Sherlock"]["match_byte_offsets"]
 
 
 def test_config1_shape_100mb_six_chunks(oracle, tmp_path):

@@ -18,6 +18,7 @@
 #include <new>
 #include <thread>
 
+#include "xsg_lz4.h"
 #include "xsg_objects.h"
 
 using namespace xsg;
@@ -235,20 +236,41 @@ static void* open_any(const char* const* names) {
   return nullptr;
 }
 
+// the built-in block codec (xsg_lz4.h) behind liblz4's signatures
+static int builtin_lz4_decompress_safe(const char* src, char* dst, int src_n, int dst_cap) {
+  if (src_n < 0 || dst_cap < 0) return -1;
+  const int64_t r = xsg::lz4_block_decode((const uint8_t*)src, (size_t)src_n, (uint8_t*)dst, (size_t)dst_cap);
+  return r < 0 ? -1 : (int)r;
+}
+static int builtin_lz4_compress_default(const char* src, char* dst, int src_n, int dst_cap) {
+  return xsg::lz4_block_encode((const uint8_t*)src, src_n, (uint8_t*)dst, dst_cap);
+}
+static int builtin_lz4_compress_bound(int n) { return xsg::lz4_compress_bound(n); }
+static char g_builtin_lz4_token;  // non-null marker for Codecs::lz4 when the built-in codec is in use
+
+// liblz4 if the host has one, else the built-in codec (XSG_NO_LIBLZ4=1 forces the built-in one: tests)
 static int need_lz4() {
   std::lock_guard<std::mutex> g(g_codec_mu);
   Codecs& c = codecs();
   if (c.lz4) return XSG_OK;
   static const char* names[] = {"liblz4.so.1", "liblz4.so", "/opt/conda/lib/liblz4.so.1", nullptr};
-  void* h = open_any(names);
-  if (!h) return fail(XSG_ENOTSUP, "liblz4 not found on this host (needed for LZ4 metafiles)");
-  c.LZ4_decompress_safe = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_decompress_safe");
-  c.LZ4_compress_default = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_compress_default");
-  c.LZ4_compress_HC = (int (*)(const char*, char*, int, int, int))dlsym(h, "LZ4_compress_HC");
-  c.LZ4_compressBound = (int (*)(int))dlsym(h, "LZ4_compressBound");
-  if (!c.LZ4_decompress_safe || !c.LZ4_compress_default || !c.LZ4_compressBound)
-    return fail(XSG_ENOTSUP, "liblz4 lacks the expected symbols");
-  c.lz4 = h;
+  const char* no = getenv("XSG_NO_LIBLZ4");
+  void* h = (no && *no && *no != '0') ? nullptr : open_any(names);
+  if (h) {
+    c.LZ4_decompress_safe = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_decompress_safe");
+    c.LZ4_compress_default = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_compress_default");
+    c.LZ4_compress_HC = (int (*)(const char*, char*, int, int, int))dlsym(h, "LZ4_compress_HC");
+    c.LZ4_compressBound = (int (*)(int))dlsym(h, "LZ4_compressBound");
+    if (c.LZ4_decompress_safe && c.LZ4_compress_default && c.LZ4_compressBound) {
+      c.lz4 = h;
+      return XSG_OK;
+    }
+  }
+  c.LZ4_decompress_safe = builtin_lz4_decompress_safe;
+  c.LZ4_compress_default = builtin_lz4_compress_default;
+  c.LZ4_compress_HC = nullptr;
+  c.LZ4_compressBound = builtin_lz4_compress_bound;
+  c.lz4 = &g_builtin_lz4_token;
   return XSG_OK;
 }
 
