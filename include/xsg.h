@@ -6,7 +6,9 @@
  *   src/string_search/simd_search.cpp                       (AVX2 primitives)
  *   include/xsearch/string_search/search_wrappers.h:29-207  (per-chunk walks)
  * and calls from the task functors include/xsearch/tasks/searchers.h:38-93
- * inside the worker loop include/xsearch/Searcher.h:100-120.
+ * inside the worker loop include/xsearch/Searcher.h:100-120.  With
+ * XSG_FLAG_REGEX the same entry points stand in for the regex walks
+ * (search_wrappers.h:63-103, 209-271) on fixed-length class-sequence expressions.
  *
  * Everything here is plain C: opaque handles, pointers and sizes.  No torch
  * or C++ types cross this boundary.  The C++ surface the reference's users see
