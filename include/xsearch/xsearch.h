@@ -31,7 +31,8 @@
 // std::invalid_argument instead of being searched as text with different results (XS_FORCE_LITERAL=1 searches
 // it as plain text).  ignore_case folds ASCII letters only (what the reference's simd::toLower does).
 //
-// Environment: XS_DEVICE (HIP device index, default 0), XS_CHUNK_BYTES (target
+// Environment: XS_DEVICE (HIP device index, default 0), XS_DEVICES ("0,1,2,3" or "all": one search fans its chunk
+// ranges out over several devices of the node, one job each, results in file order), XS_CHUNK_BYTES (target
 // chunk size without a metafile, default 16 MiB).
 #pragma once
 
@@ -108,6 +109,48 @@ inline uint64_t env_u64(const char* name, uint64_t dflt) {
   return std::strtoull(v, nullptr, 10);
 }
 
+// Devices of one search.  XS_DEVICES="0,1,2,3" or "all": the chunks fan out over these devices, one job each
+// (one process, no collective: only counts and newline totals cross devices, on the host).  Unset: the single
+// device XS_DEVICE (default 0).  One process per GPU under torch.distributed is x-search_amd/dist_search.py.
+inline std::vector<int> device_list() {
+  std::vector<int> out;
+  const char* v = std::getenv("XS_DEVICES");
+  if (!v || !*v) {
+    out.push_back(static_cast<int>(env_u64("XS_DEVICE", 0)));
+    return out;
+  }
+  if (std::string(v) == "all") {
+    int n = 0;
+    const int r = xsg_device_count(&n);
+    if (r != XSG_OK) throw_last("xs::extern_search", r);
+    for (int i = 0; i < n; ++i) out.push_back(i);
+  } else {
+    const char* p = v;
+    while (*p) {
+      char* e = nullptr;
+      const long d = std::strtol(p, &e, 10);
+      if (e == p || d < 0) throw std::invalid_argument(std::string("XS_DEVICES: cannot parse '") + v + "'");
+      out.push_back(static_cast<int>(d));
+      p = *e == ',' ? e + 1 : e;
+      if (*e && *e != ',') throw std::invalid_argument(std::string("XS_DEVICES: cannot parse '") + v + "'");
+    }
+  }
+  if (out.empty()) throw std::invalid_argument("XS_DEVICES names no device");
+  return out;
+}
+
+// number of chunks of the search plan (metafile, or the newline-aligned plan of a plain file)
+inline uint64_t count_chunks(const std::string& file_path, const char* meta, uint64_t chunk_bytes) {
+  xsg_file_chunk* chunks = nullptr;
+  uint64_t n = 0;
+  int32_t comp = 0;
+  const int r = meta ? xsg_meta_read(meta, &comp, &chunks, &n, nullptr, nullptr)
+                     : xsg_plan_chunks(file_path.c_str(), chunk_bytes, &chunks, &n);
+  if (r != XSG_OK) throw_last("xs::extern_search", r);
+  xsg_free(chunks);
+  return n;
+}
+
 // The reference decides per pattern whether it is a regular expression: it is one
 // iff the pattern, read as a regex, does not match itself (utils/utils.h:17-25; an
 // invalid regex counts as plain text).  Such a pattern goes to the kernel's class-sequence
@@ -160,6 +203,83 @@ struct fetch<std::string> {
 
 }  // namespace detail
 
+// ---- the jobs of one search ---------------------------------------------------
+// One xsg_job per device.  With several devices (XS_DEVICES) the chunks of the file fan out in contiguous
+// ranges, device g taking chunks [g*C/G, (g+1)*C/G), so the concatenation of the jobs' results in
+// device order is the file order.  Only two things cross jobs, both a single integer: a count tag's value is the
+// sum of the jobs' counts, and without a metafile a line index needs the number of newlines in all earlier ranges.
+namespace detail {
+
+struct JobSet {
+  std::vector<xsg_job*> jobs;
+  bool is_count = false;
+  bool add_newline_base = false;  // xs::line_indices without a metafile
+
+  // Finds the job that holds element i of the concatenated sequence; blocks until the element exists or every
+  // job is closed.  Every job before the returned one is finished.
+  bool locate(uint64_t i, size_t* jx, uint64_t* local) const {
+    uint64_t base = 0;
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      uint64_t avail = 0;
+      int fin = 0;
+      const int r = xsg_job_wait(jobs[k], i - base, &avail, &fin);
+      if (r != XSG_OK) throw_last("xs::Result", r);
+      if (avail > i - base) {
+        *jx = k;
+        *local = i - base;
+        return true;
+      }
+      base += avail;  // job k is closed and holds `avail` elements in all
+    }
+    return false;
+  }
+  // what the finished jobs before job k add to a value of job k
+  uint64_t carry(size_t k) const {
+    uint64_t c = 0;
+    for (size_t h = 0; h < k && (is_count || add_newline_base); ++h) {
+      if (is_count) {
+        uint64_t t = 0;
+        const int r = xsg_job_total(jobs[h], &t);
+        if (r != XSG_OK) throw_last("xs::Result", r);
+        c += t;
+      } else {
+        xsg_job_stats st{};
+        const int r = xsg_job_stats_get(jobs[h], &st);
+        if (r != XSG_OK) throw_last("xs::Result", r);
+        c += st.newlines;
+      }
+    }
+    return c;
+  }
+  template <class V>
+  V get(size_t k, uint64_t local) const {
+    return adjust(fetch<V>::get(jobs[k], local), k);
+  }
+  uint64_t adjust(uint64_t v, size_t k) const { return k == 0 ? v : v + carry(k); }
+  std::string adjust(std::string v, size_t) const { return v; }
+  // elements that can be read now without waiting, in order: all of every finished job, then what the first
+  // unfinished one has so far
+  uint64_t available(bool* all_finished) const {
+    uint64_t n = 0;
+    bool fin_all = true;
+    for (xsg_job* j : jobs) {
+      uint64_t a = 0;
+      int fin = 0;
+      const int r = xsg_job_poll(j, &a, &fin);
+      if (r != XSG_OK) throw_last("xs::Result", r);
+      n += a;
+      if (!fin) {
+        fin_all = false;
+        break;
+      }
+    }
+    if (all_finished) *all_finished = fin_all;
+    return n;
+  }
+};
+
+}  // namespace detail
+
 // ---- result container (semantics of include/xsearch/ResultTypes.h:31-130) -----
 template <class Tag>
 class Result {
@@ -176,8 +296,13 @@ class Result {
     using pointer = const value_type*;
     using reference = value_type;
 
-    iterator(xsg_job* job, uint64_t index, bool is_end) : _job(job), _index(index), _end(is_end) {}
-    value_type operator*() const { return detail::fetch<value_type>::get(_job, _index); }
+    iterator(const detail::JobSet* set, uint64_t index, bool is_end) : _set(set), _index(index), _end(is_end) {}
+    value_type operator*() const {
+      size_t k = 0;
+      uint64_t local = 0;
+      if (!_set->locate(_index, &k, &local)) throw std::out_of_range("xs::Result::iterator");
+      return _set->template get<value_type>(k, local);
+    }
     iterator& operator++() {
       ++_index;
       return *this;
@@ -187,73 +312,68 @@ class Result {
       if (_end && other._end) return true;
       if (!_end && !other._end) return _index == other._index;
       const iterator& it = _end ? other : *this;
-      return !it.exists();
+      size_t k = 0;
+      uint64_t local = 0;
+      return !it._set->locate(it._index, &k, &local);
     }
 
    private:
-    bool exists() const {
-      uint64_t avail = 0;
-      int fin = 0;
-      const int r = xsg_job_wait(_job, _index, &avail, &fin);
-      if (r != XSG_OK) detail::throw_last("xs::Result", r);
-      return avail > _index;
-    }
-    xsg_job* _job;
+    const detail::JobSet* _set;
     uint64_t _index;
     bool _end;
   };
 
-  explicit Result(xsg_job* job) : _job(job) {}
+  explicit Result(const detail::JobSet* set) : _set(set) {}
   Result(const Result&) = delete;
   Result& operator=(const Result&) = delete;
 
-  iterator begin() { return iterator(_job, 0, false); }
-  iterator end() { return iterator(_job, 0, true); }
+  iterator begin() { return iterator(_set, 0, false); }
+  iterator end() { return iterator(_set, 0, true); }
 
   // count tags: the count (so far; final after join()).  Vector tags: number of
   // elements available so far.  (test/src/xsearchTest.cpp:346)
   size_t size() const {
-    uint64_t t = 0;
-    const int r = xsg_job_total(_job, &t);
-    if (r != XSG_OK) detail::throw_last("xs::Result::size", r);
-    return static_cast<size_t>(t);
+    uint64_t sum = 0;
+    for (xsg_job* j : _set->jobs) {
+      uint64_t t = 0;
+      const int r = xsg_job_total(j, &t);
+      if (r != XSG_OK) detail::throw_last("xs::Result::size", r);
+      sum += t;
+    }
+    return static_cast<size_t>(sum);
   }
   bool empty() const { return size() == 0; }
 
   // Thread-safe copy of everything available now (test/src/xsearchTest.cpp:450).
   // Count tags: the running totals published so far (one per chunk).
   std::vector<value_type> copyResultSafe() const {
-    uint64_t n = 0;
-    int fin = 0;
-    const int r = xsg_job_poll(_job, &n, &fin);
-    if (r != XSG_OK) detail::throw_last("xs::Result::copyResultSafe", r);
+    const uint64_t n = _set->available(nullptr);
     std::vector<value_type> out;
     out.reserve(n);
-    for (uint64_t i = 0; i < n; ++i) out.push_back(detail::fetch<value_type>::get(_job, i));
+    for (uint64_t i = 0; i < n; ++i) out.push_back((*this)[i]);
     return out;
   }
   // the read side of ResultTypes.h:91-115 (get / operator[] / at / is_closed); elements are flat
   // values here (the reference's containers hold one partial result per chunk, its API layer flattens)
   std::vector<value_type> get() const { return copyResultSafe(); }
-  value_type operator[](size_t index) const { return detail::fetch<value_type>::get(_job, index); }
+  value_type operator[](size_t index) const {
+    size_t k = 0;
+    uint64_t local = 0;
+    if (!_set->locate(index, &k, &local)) throw std::out_of_range("xs::Result::operator[]");
+    return _set->template get<value_type>(k, local);
+  }
   value_type at(size_t index) const {
-    uint64_t n = 0;
-    int fin = 0;
-    const int r = xsg_job_poll(_job, &n, &fin);
-    if (r != XSG_OK) detail::throw_last("xs::Result::at", r);
-    if (index >= n) throw std::out_of_range("xs::Result::at");
-    return detail::fetch<value_type>::get(_job, index);
+    if (index >= _set->available(nullptr)) throw std::out_of_range("xs::Result::at");
+    return (*this)[index];
   }
   bool is_closed() const {
-    uint64_t n = 0;
-    int fin = 0;
-    const int r = xsg_job_poll(_job, &n, &fin);
-    if (r != XSG_OK) detail::throw_last("xs::Result::is_closed", r);
-    return fin != 0;
+    bool fin = false;
+    _set->available(&fin);
+    return fin;
   }
 
  private:
-  xsg_job* _job;
+  const detail::JobSet* _set;
 };
 
 // ---- the handle xs::extern_search returns --------------------------------------
@@ -268,17 +388,36 @@ class ExternSearcher {
     xsg_job_opts_init(&o);
     o.pattern_flags = detail::pattern_flags(pattern, ignore_case);
     o.mode = detail::traits<Tag>::mode;
-    o.device = static_cast<int32_t>(detail::env_u64("XS_DEVICE", 0));
     o.num_threads = num_threads < 1 ? 1 : num_threads;
     o.num_max_readers = num_max_readers < 1 ? 1 : num_max_readers;
     o.chunk_bytes = detail::env_u64("XS_CHUNK_BYTES", 16u << 20);
-    const int r = xsg_job_start(pattern.data(), pattern.size(), file_path.c_str(),
-                                meta_file_path.empty() ? nullptr : meta_file_path.c_str(), &o, &_job);
-    if (r != XSG_OK) detail::throw_last("xs::extern_search", r);
-    _result.reset(new ResultT(_job));
+    const char* meta = meta_file_path.empty() ? nullptr : meta_file_path.c_str();
+    _set.is_count = detail::traits<Tag>::is_count;
+    _set.add_newline_base = o.mode == XSG_LINE_INDICES && meta == nullptr;
+    const std::vector<int> devices = detail::device_list();
+    try {
+      if (devices.size() == 1) {
+        o.device = devices[0];
+        start(pattern, file_path, meta, o);
+      } else {
+        // contiguous chunk ranges, one job per device; devices left without a chunk start no job
+        const uint64_t nchunks = detail::count_chunks(file_path, meta, o.chunk_bytes);
+        const uint64_t G = devices.size();
+        for (uint64_t g = 0; g < G; ++g) {
+          o.device = devices[g];
+          o.chunk_begin = g * nchunks / G;
+          o.chunk_end = (g + 1) * nchunks / G;
+          if (o.chunk_end > o.chunk_begin || (nchunks == 0 && g == 0)) start(pattern, file_path, meta, o);
+        }
+      }
+    } catch (...) {
+      for (xsg_job* j : _set.jobs) xsg_job_destroy(j);
+      throw;
+    }
+    _result.reset(new ResultT(&_set));
   }
   ~ExternSearcher() {
-    if (_job) xsg_job_destroy(_job);  // joins the workers (README.md:91)
+    for (xsg_job* j : _set.jobs) xsg_job_destroy(j);  // joins the workers (README.md:91)
   }
   ExternSearcher(const ExternSearcher&) = delete;
   ExternSearcher& operator=(const ExternSearcher&) = delete;
@@ -287,23 +426,48 @@ class ExternSearcher {
 
   // Blocks until all workers are done (README.md:84); throws the first worker error.
   void join() {
-    const int r = xsg_job_join(_job);
-    if (r != XSG_OK) detail::throw_last("xs::ExternSearcher::join", r);
+    int first = XSG_OK;
+    std::string msg;
+    for (xsg_job* j : _set.jobs) {
+      const int r = xsg_job_join(j);
+      if (r != XSG_OK && first == XSG_OK) {
+        first = r;
+        msg = xsg_last_error();
+      }
+    }
+    if (first != XSG_OK)
+      throw std::runtime_error(std::string("xs::ExternSearcher::join: ") + xsg_strerror(first) + " (" + msg + ")");
   }
   ResultT* getResult() { return _result.get(); }
-  bool running() const {
-    uint64_t n = 0;
-    int fin = 0;
-    return xsg_job_poll(_job, &n, &fin) == XSG_OK && !fin;
-  }
+  bool running() const { return !_result->is_closed(); }
+  size_t num_devices() const { return _set.jobs.size(); }
+  // summed over the devices; the seconds are those of the slowest device
   xsg_job_stats stats() const {
-    xsg_job_stats st{};
-    xsg_job_stats_get(_job, &st);
-    return st;
+    xsg_job_stats sum{};
+    for (xsg_job* j : _set.jobs) {
+      xsg_job_stats st{};
+      xsg_job_stats_get(j, &st);
+      sum.chunks += st.chunks;
+      sum.bytes_read += st.bytes_read;
+      sum.bytes_scanned += st.bytes_scanned;
+      sum.newlines += st.newlines;
+      sum.plan_chunks = st.plan_chunks;
+      sum.seconds_total = st.seconds_total > sum.seconds_total ? st.seconds_total : sum.seconds_total;
+      sum.seconds_read += st.seconds_read;
+      sum.seconds_decompress += st.seconds_decompress;
+      sum.seconds_device += st.seconds_device;
+    }
+    return sum;
   }
 
  private:
-  xsg_job* _job = nullptr;
+  void start(const std::string& pattern, const std::string& file_path, const char* meta, const xsg_job_opts& o) {
+    xsg_job* j = nullptr;
+    const int r = xsg_job_start(pattern.data(), pattern.size(), file_path.c_str(), meta, &o, &j);
+    if (r != XSG_OK) detail::throw_last("xs::extern_search", r);
+    _set.jobs.push_back(j);
+  }
+  detail::JobSet _set;
   std::unique_ptr<ResultT> _result;
 };
 

@@ -400,3 +400,28 @@ def test_regex_routing_of_extern_search(files, oracle):
     for expr in ("a.b", "She.*lock"):  # these match themselves as regexes -> plain text for the reference too
         r = run_cli("count", "join", expr, files["txt"])
         assert r.returncode == 0 and int(r.stdout) == 0
+
+
+@pytest.mark.parametrize("how", ["join", "live"])
+def test_extern_search_fans_out_over_devices(files, how):
+    """XS_DEVICES: one xs::extern_search call runs one job per listed device on contiguous chunk ranges (SURVEY 8e)
+    and merges on the host -- counts add up, a live count ends on the global total, list tags come back in file
+    order with global offsets, line indices carry the newlines of the earlier ranges.  One GPU here, so the same
+    device is listed two and three times: the merge logic does not care."""
+    want = files["want"][b"Sherlock"]
+    data_path, meta_path = files["metas"]["xslz4"]
+    for devs in ("0,0", "0,0,0"):
+        for tag in TAGS:
+            for src, meta in ((files["txt"], "-"), (data_path, meta_path)):
+                r = run_cli(tag, how, "Sherlock", src, meta, "2", "2", env={"XS_DEVICES": devs})
+                assert r.returncode == 0, r.stderr
+                if tag in ("count", "count_lines"):
+                    assert int(r.stdout) == want[KEY[tag]], (tag, devs, meta)
+                elif tag == "lines":
+                    assert r.stdout.split(b"\n")[:-1] == want["lines"], (devs, meta)
+                else:
+                    assert [int(x) for x in r.stdout.split()] == want[KEY[tag]], (tag, devs, meta)
+    r = run_cli("count", "join", "Sherlock", files["txt"], env={"XS_DEVICES": "0,x"})
+    assert r.returncode == 1 and b"XS_DEVICES" in r.stderr
+    r = run_cli("count", "join", "Sherlock", files["txt"], env={"XS_DEVICES": "0,99"})
+    assert r.returncode == 1 and b"device" in r.stderr
