@@ -12,7 +12,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -112,6 +114,60 @@ int main(int argc, char** argv) {
       munmap(m, size);
       fflush(stdout);
     }
+  }
+  for (int T : {1, 2, 4, 8}) {  // T threads, each: register its next 16 MiB chunk, copy on its own stream, unregister
+    void* m = mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0);
+    std::atomic<size_t> next{0};
+    const size_t nchunks = size / chunk;
+    double t0 = now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&] {
+        CK(hipSetDevice(0));
+        hipStream_t st;
+        CK(hipStreamCreate(&st));
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= nchunks) break;
+          CK(hipHostRegister((char*)m + k * chunk, chunk, hipHostRegisterPortable));
+          CK(hipMemcpyAsync((char*)dev + k * chunk, (char*)m + k * chunk, chunk, hipMemcpyHostToDevice, st));
+          CK(hipStreamSynchronize(st));
+          CK(hipHostUnregister((char*)m + k * chunk));
+        }
+        CK(hipStreamDestroy(st));
+      });
+    for (auto& x : th) x.join();
+    double dt = now() - t0;
+    printf("fresh mmap, %d threads register+copy+unregister: %.2f GiB/s\n", T, size / dt / (1 << 30));
+    munmap(m, size);
+    fflush(stdout);
+  }
+  for (int T : {1, 2, 4, 8}) {  // the same with pread into a per-thread pinned buffer (what the pipeline does today)
+    std::atomic<size_t> next{0};
+    const size_t nchunks = size / chunk;
+    double t0 = now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&] {
+        CK(hipSetDevice(0));
+        hipStream_t st;
+        CK(hipStreamCreate(&st));
+        void* pin = nullptr;
+        CK(hipHostMalloc(&pin, chunk, hipHostMallocDefault));
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= nchunks) break;
+          (void)!pread(fd, pin, chunk, (off_t)(k * chunk));
+          CK(hipMemcpyAsync((char*)dev + k * chunk, pin, chunk, hipMemcpyHostToDevice, st));
+          CK(hipStreamSynchronize(st));
+        }
+        CK(hipHostFree(pin));
+        CK(hipStreamDestroy(st));
+      });
+    for (auto& x : th) x.join();
+    double dt = now() - t0;
+    printf("%d threads pread->pinned->H2D (serial per thread): %.2f GiB/s\n", T, size / dt / (1 << 30));
+    fflush(stdout);
   }
   {  // pread into a pinned buffer, then H2D (what the reader threads do now), one thread
     void* pin = nullptr;
