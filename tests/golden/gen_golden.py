@@ -104,6 +104,31 @@ def cases():
     return out
 
 
+def icase_cases():
+    """ignore_case vectors.  The snapshot has no case-insensitive wrapper, but it has the primitive
+    (simd::strcasestr, simd_search.cpp:220-287): the expected values come from the wrapper loops driven on a
+    findNext that calls the REFERENCE's strcasestr where simd::findNext (:289-295) calls strstr.
+    Patterns of 2+ bytes (strcasestr is undefined for one byte, :211)."""
+    out = []
+
+    def lit(name, text, pats):
+        out.append({"name": name, "input": {"kind": "literal", "text": text}, "patterns": pats})
+
+    lit("icase_mixed", "Sherlock SHERLOCK sherlock sHeRlOcK\nno match here\nshe sherlocked\n" + "x" * 70 + "\n",
+        ["sherlock", "SHERLOCK", "She", "lock", "ck\n"[:2]])
+    lit("icase_tail", "y" * 100 + "sheSHERLOCK", ["Sherlock", "sherlock"])          # lossy tail, mixed case
+    lit("icase_tail_padded", "y" * 100 + "sheSHERLOCK" + "z" * 64, ["Sherlock"])
+    lit("icase_overlap", "aAaAaA\nAAAA aaa\n" * 4, ["aa", "AaA", "aaa"])
+    lit("icase_nonletters", "a-b A-B a_b [x] {X} @ `\n" * 3 + "\xc4\xe4 \xc3\x84\xc3\xa4\n", ["a-b", "[X]", "{x}", "@ `", "\xc4\xe4", "\xe4"[:1] + "\xc4"])
+    for i, n in enumerate([33, 64, 257, 4096]):
+        out.append({"name": f"aAbB_nl_{n}", "input": {"kind": "small_alphabet", "seed": 300 + i, "n": n, "alphabet": "aAbB\n",
+                                                      "terminate": bool(i & 1)}, "patterns": ["ab", "AB", "aBa", "bb", "ABAB"]})
+    out.append({"name": "text_64k_icase", "input": {"kind": "text_block", "seed": 9, "index": 0, "n": 65536, "needle_rate": 1e-3,
+                                                     "splice": [[1000, "SHERLOCK"], [30000, "sherLOCK holmes"], [-13, " sheSHERLOCK\n"]]},
+                "patterns": ["sherlock", "SHERLOCK", "Holmes", "THE", "detective STREET"]})
+    return out
+
+
 def main():
     orc = Oracle()
     ref = Reference()
@@ -138,10 +163,42 @@ def main():
             e["findNext"] = [[int(s), int(ref.find_next(p, data, s))] for s in probes]
             entry["expect"].append(e)
         doc["cases"].append(entry)
+    # ---- ignore_case: the same wrapper loops on a findNext made of the reference's strcasestr
+    import ctypes as C
+    FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t)
+
+    def find_next_icase(pat, plen, s, n, shift):  # simd::findNext (:289-295) with strcasestr for strstr
+        if shift > n:
+            return -1
+        r = ref.fn_strcasestr(s + shift, n - shift, C.cast(pat, C.c_char_p), plen)
+        return -1 if not r else r - s
+
+    cb = FN(find_next_icase)
+    orc.lib.xso_use_primitives(C.cast(cb, C.c_void_p), C.cast(ref.fn_findnl, C.c_void_p))
+    doc["icase_cases"] = []
+    for c in icase_cases():
+        data = make_input(c["input"])
+        entry = {"name": c["name"], "input": c["input"], "len": int(data.size),
+                 "sha256": hashlib.sha256(data.tobytes()).hexdigest(), "expect": []}
+        for pat in c["patterns"]:
+            p = pat.encode("latin-1")
+            assert len(p) >= 2 and b"\n" not in p
+            beg, ln = orc.lines_spans(data, p)
+            entry["expect"].append({
+                "pattern": pat,
+                "count_skip": int(orc.count(data, p, True)),
+                "count_noskip": int(orc.count(data, p, False)),
+                "byte_offsets_match": [int(x) for x in orc.byte_offsets_match(data, p)],
+                "byte_offsets_line": [int(x) for x in orc.byte_offsets_line(data, p)],
+                "lines_begin": [int(x) for x in beg],
+                "lines_len": [int(x) for x in ln],
+                "line_indices": [int(x) for x in orc.line_indices(data, p, 0)],
+            })
+        doc["icase_cases"].append(entry)
     orc.use_reference_primitives(None)
     out = Path(__file__).resolve().parent / "ref_generated_vectors.json"
     out.write_text(json.dumps(doc, separators=(",", ":")))
-    print("wrote", out, out.stat().st_size, "bytes;", len(doc["cases"]), "cases")
+    print("wrote", out, out.stat().st_size, "bytes;", len(doc["cases"]), "cases +", len(doc["icase_cases"]), "ignore_case cases")
 
 
 if __name__ == "__main__":

@@ -44,3 +44,15 @@ def generated_cases():
         assert hashlib.sha256(data.tobytes()).hexdigest() == c["sha256"], f"generator drift in {c['name']}"
         for e in c["expect"]:
             yield c["name"], data, e
+
+
+def generated_icase_cases():
+    """ignore_case vectors: expected values from the wrapper loops on the reference's simd::strcasestr
+    (tests/golden/gen_golden.py: icase_cases)."""
+    doc = load("ref_generated_vectors.json")
+    for c in doc["icase_cases"]:
+        data = make_input(c["input"])
+        assert data.size == c["len"], c["name"]
+        assert hashlib.sha256(data.tobytes()).hexdigest() == c["sha256"], f"generator drift in {c['name']}"
+        for e in c["expect"]:
+            yield c["name"], data, e

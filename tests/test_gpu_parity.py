@@ -83,6 +83,27 @@ def test_golden_vectors_from_the_reference_build(gs):
     assert n > 100
 
 
+def test_golden_ignore_case_vectors_from_the_reference_build(gs):
+    """The ignore_case part of ref_generated_vectors.json: expected values produced by the reference's own
+    simd::strcasestr under the wrapper loops; the GPU runs with XSG_FLAG_IGNORE_CASE on the original bytes."""
+    last, n = None, 0
+    for name, data, e in G.generated_icase_cases():
+        if name != last:
+            gs.bind([data])
+            last = name
+        r = gs.all_modes(_b(e["pattern"]), xsg.FLAG_IGNORE_CASE)
+        ctx = f"{name} pat={e['pattern']!r}"
+        assert r["count_matches"] == e["count_noskip"], ctx
+        assert r["count_lines"] == e["count_skip"], ctx
+        assert r["match_byte_offsets"] == e["byte_offsets_match"], ctx
+        assert r["line_byte_offsets"] == e["byte_offsets_line"], ctx
+        assert r["line_indices"] == e["line_indices"], ctx
+        assert r["lines_offsets"] == e["lines_begin"], ctx
+        assert r["lines"] == [data[b:b + l].tobytes() for b, l in zip(e["lines_begin"], e["lines_len"])], ctx  # original case
+        n += 1
+    assert n >= 40
+
+
 PATTERNS = [b"a", b"ab", b"aa", b"aba", b"abab", b"bab", b"abc ", b"ab ab", b"abcabca", b"abababab", b"ab ab ab a",
             b"a" * 17, b"b\na"]
 

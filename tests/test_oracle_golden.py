@@ -158,3 +158,22 @@ def test_ignore_case_semantics_equal_the_references_strcasestr(oracle, reference
         assert oracle.strstr(oracle.lower(data), oracle.lower(pat).tobytes()) == want
         n += got >= 0
     assert n > 1500
+
+
+def test_generated_ignore_case_vectors(oracle):
+    """The oracle's ignore_case convention (search on toLower(data), toLower(pattern)) against the vectors the
+    reference's own strcasestr produced."""
+    n = 0
+    for name, data, e in G.generated_icase_cases():
+        low = oracle.lower(data)
+        p = oracle.lower(e["pattern"].encode("latin-1")).tobytes()
+        ctx = f"{name} pat={e['pattern']!r}"
+        assert oracle.count(low, p, True) == e["count_skip"], ctx
+        assert oracle.count(low, p, False) == e["count_noskip"], ctx
+        assert oracle.byte_offsets_match(low, p).tolist() == e["byte_offsets_match"], ctx
+        assert oracle.byte_offsets_line(low, p).tolist() == e["byte_offsets_line"], ctx
+        beg, ln = oracle.lines_spans(low, p)
+        assert beg.tolist() == e["lines_begin"] and ln.tolist() == e["lines_len"], ctx
+        assert oracle.line_indices(low, p, 0).tolist() == e["line_indices"], ctx
+        n += 1
+    assert n >= 40
