@@ -12,6 +12,11 @@
  * (tests/test_oracle_golden.py), and the primitives are cross-checked against
  * oracle/_ref/libxsref.so, which is the reference's own
  * src/string_search/simd_search.cpp compiled unmodified (oracle/Makefile).
+ * ignore_case (toLower on both sides) equals that build's simd::strcasestr
+ * (tests/test_oracle_golden.py).  The regex wrappers are restated for
+ * fixed-length class sequences only: RE2 is an unpinned, absent submodule; that
+ * part is pinned by the known answers of search_wrappersTest.cpp:74-105 and
+ * cross-checked against CPython's `re` (tests/test_oracle_regex.py).
  *
  * Each function cites the reference file:line whose behaviour it restates.
  * All paths are relative to the reference tree.
