@@ -752,9 +752,17 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     HIP_TRY(launch_globalize(o, st));
   } else if (mode == XSG_LINE_INDICES) {
     XSG_TRY(s->d_tile_nl_off.ensure(8 * (ntiles + 1)));
+    XSG_TRY(s->d_line_len.ensure(8 * std::max<uint64_t>(total, 1)));
+    XSG_TRY(s->d_line_off.ensure(8 * (total + 1)));
+    XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(std::max<uint64_t>(total + 1, ntiles + 1))));
     HIP_TRY(launch_exclusive_scan_u32(a.tile_nl, s->d_tile_nl_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(),
                                       st));
     o.tile_nl_off = s->d_tile_nl_off.as<uint64_t>();
+    // per-entry newline differences -> prefix sums -> indices (k_line_nl_delta / k_line_indices)
+    o.line_len = s->d_line_len.as<uint64_t>();
+    o.line_out_off = s->d_line_off.as<uint64_t>();
+    HIP_TRY(launch_line_nl_delta(o, st));
+    HIP_TRY(launch_exclusive_scan_u64(o.line_len, s->d_line_off.as<uint64_t>(), total, s->d_scan_tmp.as<uint64_t>(), st));
     HIP_TRY(launch_line_indices(o, st));
     HIP_TRY(hipMemcpyAsync(&s->last_newlines, s->d_tile_nl_off.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, st));
   } else {  // XSG_LINES

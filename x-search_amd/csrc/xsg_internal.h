@@ -166,6 +166,7 @@ struct LineOutArgs {
   uint8_t* line_bytes;
 };
 hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s);
+hipError_t launch_line_nl_delta(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_indices(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_lengths(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s);

@@ -1182,29 +1182,101 @@ __global__ void k_globalize(const LineOutArgs A) {
 }
 
 // xs::line_indices: number of '\n' before the line start
-// = newlines in all tiles before the line's tile (exclusive scan of tile_nl)
-// + newlines between the tile start and the line start, counted 16 bytes a step.
+// = newlines in all tiles before the line's tile (exclusive scan of tile_nl) + newlines between the tile start
+// and the line start.  Counting from the tile start for every line would cost O(lines x tile) when most lines
+// match (66 M lines in 10 GiB: 90 ms); instead every list entry counts only the gap back to the previous entry
+// (the previous entry of the same tile, else both ends from their tile starts), and one prefix sum over the
+// entries turns the differences into counts: O(shard) whatever the density.
+__device__ __forceinline__ uint32_t unit_newlines(const uint8_t* p) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  return (uint32_t)__popc(nl_flags(v.x)) + (uint32_t)__popc(nl_flags(v.y)) + (uint32_t)__popc(nl_flags(v.z)) +
+         (uint32_t)__popc(nl_flags(v.w));
+}
+// newlines among bytes [lo, hi) of the aligned 16-byte unit at p
+__device__ __forceinline__ uint32_t unit_newlines_masked(const uint8_t* p, uint32_t lo, uint32_t hi) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  const uint32_t f[4] = {nl_flags(v.x), nl_flags(v.y), nl_flags(v.z), nl_flags(v.w)};
+  uint32_t n = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t b0 = 4u * q;
+    uint32_t keep = 0xffffffffu;
+    if (lo > b0) keep &= lo >= b0 + 4 ? 0u : 0xffffffffu << (8u * (lo - b0));
+    if (hi < b0 + 4) keep &= hi <= b0 ? 0u : 0xffffffffu >> (8u * (b0 + 4 - hi));
+    n += (uint32_t)__popc(f[q] & keep);
+  }
+  return n;
+}
+// Newlines in d[from, to) with aligned 16-byte loads only (a gap is ~30 bytes when most lines match: byte loads
+// would be 10x the memory operations); the units at both ends are masked.  Chunk buffers are padded to 16.
+// The interior runs four independent loads per step: a walk over a whole tile is latency-bound otherwise.
+__device__ __forceinline__ uint64_t count_newlines(const uint8_t* d, uint64_t from, uint64_t to) {
+  if (from >= to) return 0;
+  uint64_t n = 0;
+  uint64_t p = from & ~(uint64_t)15;
+  if (p < from) {  // leading partial unit
+    const uint64_t end = p + kUnit < to ? p + kUnit : to;
+    n += unit_newlines_masked(d + p, (uint32_t)(from - p), (uint32_t)(end - p));
+    p += kUnit;
+  }
+  for (; p + 4 * kUnit <= to; p += 4 * kUnit)
+    n += unit_newlines(d + p) + unit_newlines(d + p + kUnit) + unit_newlines(d + p + 2 * kUnit) +
+         unit_newlines(d + p + 3 * kUnit);
+  for (; p + kUnit <= to; p += kUnit) n += unit_newlines(d + p);
+  if (p < to) n += unit_newlines_masked(d + p, 0u, (uint32_t)(to - p));  // trailing partial unit
+  return n;
+}
+
+// shard-wide newline count before entry i's line start, from its tile's prefix (up to one tile of counting)
+__device__ __forceinline__ uint64_t newlines_before_entry(const LineOutArgs& A, uint64_t i) {
+  const uint32_t c = A.f_chunk[i];
+  const uint8_t* d = A.base + A.chunks[c].offset;
+  const uint64_t b = A.f_pos[i];
+  const uint32_t sh = 31u - (uint32_t)__clz(A.tile_bytes);  // tiles are a power of two
+  const uint64_t tl = b >> sh;
+  return A.tile_nl_off[A.chunk_tile0[c] + tl] + count_newlines(d, tl << sh, b);
+}
+
+// An entry is "near" if the previous entry is in the same chunk and at most a quarter tile back: its gap is
+// counted directly -- when most lines match the gaps are tens of bytes and no thread walks a tile while its wave
+// waits.  Farther apart, the entry counts from its tile start (at most 4x the bytes of its gap).
+__device__ __forceinline__ bool entry_is_near(const LineOutArgs& A, uint64_t i) {
+  return i > 0 && A.f_chunk[i - 1] == A.f_chunk[i] && A.f_pos[i] - A.f_pos[i - 1] <= A.tile_bytes / 4u;
+}
+
+// pass 1: the far entries get their absolute count (into out_u64, overwritten by k_line_indices later)
+__global__ void k_line_nl_abs(const LineOutArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.total) return;
+  if (!entry_is_near(A, i)) A.out_u64[i] = newlines_before_entry(A, i);
+}
+
+// pass 2: line_len[i] = (newlines before entry i) - (newlines before entry i-1); entry 0: its own count.
+__global__ void k_line_nl_delta(const LineOutArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.total) return;
+  uint64_t delta;
+  if (entry_is_near(A, i)) {
+    const uint8_t* d = A.base + A.chunks[A.f_chunk[i]].offset;
+    delta = count_newlines(d, A.f_pos[i - 1], A.f_pos[i]);  // line starts ascend inside a chunk
+  } else {
+    const uint64_t prev = i == 0 ? 0u : entry_is_near(A, i - 1) ? newlines_before_entry(A, i - 1) : A.out_u64[i - 1];
+    delta = A.out_u64[i] - prev;
+  }
+  A.line_len[i] = delta;
+}
+
+// line_out_off = exclusive prefix sums of the deltas (total + 1 entries): entry i's count is line_out_off[i + 1]
 __global__ void k_line_indices(const LineOutArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= A.total) return;
   const uint32_t c = A.f_chunk[i];
   const ChunkDev ch = A.chunks[c];
-  const uint8_t* d = A.base + ch.offset;
-  const uint64_t b = A.f_pos[i];
-  const uint64_t t0 = A.chunk_tile0[c];
-  const uint64_t t = t0 + b / A.tile_bytes;
-  uint64_t n = A.tile_nl_off[t];
-  uint64_t p = (b / A.tile_bytes) * A.tile_bytes;  // 16-byte aligned (chunk offsets and tiles are)
-  for (; p + kUnit <= b; p += kUnit) {
-    const uint4 v = *reinterpret_cast<const uint4*>(d + p);
-    n += (uint32_t)__popc(nl_flags(v.x)) + (uint32_t)__popc(nl_flags(v.y)) + (uint32_t)__popc(nl_flags(v.z)) +
-         (uint32_t)__popc(nl_flags(v.w));
-  }
-  for (; p < b; ++p) n += d[p] == '\n';
+  const uint64_t n = A.line_out_off[i + 1];
   if (ch.line_base == XSG_LINE_BASE_AUTO)
     A.out_u64[i] = A.shard_line_base + n;
   else
-    A.out_u64[i] = ch.line_base + (n - A.tile_nl_off[t0]);
+    A.out_u64[i] = ch.line_base + (n - A.tile_nl_off[A.chunk_tile0[c]]);
 }
 
 // xs::lines: [line start, next '\n' after the match); a line without '\n' is
@@ -1234,6 +1306,12 @@ __global__ __launch_bounds__(kBlock) void k_line_gather(const LineOutArgs A) {
 hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s) {
   if (!a.total) return hipSuccess;
   hipLaunchKernelGGL(k_globalize, grid_for(a.total), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_line_nl_delta(const LineOutArgs& a, hipStream_t s) {
+  if (!a.total) return hipSuccess;
+  hipLaunchKernelGGL(k_line_nl_abs, grid_for(a.total), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(k_line_nl_delta, grid_for(a.total), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_line_indices(const LineOutArgs& a, hipStream_t s) {
