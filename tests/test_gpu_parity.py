@@ -354,3 +354,30 @@ def test_long_patterns_with_a_shifted_filter_window(gs, oracle):
                 want = oracle_all_modes(oracle, blocks, p, exact, ignore_case=icase)
                 assert_same(got, want, f"shifted window pat={p!r} exact={exact} icase={icase}")
         assert oracle_all_modes(oracle, blocks, p, True)["count_matches"] > 15
+
+
+def test_half_a_gigabyte_without_a_newline(gs, oracle):
+    """One 512 MiB chunk that is a single unterminated line, needles at both ends and in the middle, then the
+    same with one newline in the middle: the line tags have to find a line start / line end half a gigabyte
+    away from the match.  A lane looks 4 KiB far on its own, then the whole wave finishes the search 4 KiB a step
+    (newline_query in xsg_kernels.hip): 2 s for all tags here; a byte loop in one thread took minutes."""
+    import time
+    n = 512 << 20
+    b = np.full(n, ord("x"), dtype=np.uint8)
+    b[::97] = 32
+    for pos in (5, n // 2 + 3, n - 4000):
+        b[pos:pos + 8] = np.frombuffer(b"Sherlock", dtype=np.uint8)
+    for with_nl in (False, True):
+        if with_nl:
+            b[n // 2 - 1000] = 10
+        gs.bind([b])
+        t0 = time.perf_counter()
+        got = gs.all_modes(b"Sherlock")
+        dt = time.perf_counter() - t0
+        want = oracle_all_modes(oracle, [b], b"Sherlock")
+        for k in ("count_matches", "count_lines", "match_byte_offsets", "line_byte_offsets", "line_indices", "lines_offsets"):
+            assert got[k] == want[k], (with_nl, k)
+        assert [len(x) for x in got["lines"]] == [len(x) for x in want["lines"]], with_nl
+        assert want["count_matches"] == 3 and want["count_lines"] == (2 if with_nl else 1)
+        assert dt < 10.0, f"single-line chunk took {dt:.1f} s"
+        print(f"512 MiB single line (newline in the middle: {with_nl}): all tags in {dt:.2f} s")

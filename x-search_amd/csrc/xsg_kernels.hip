@@ -134,6 +134,170 @@ __device__ __forceinline__ bool nl_any16(const uint32_t (&d)[8]) {
   return (acc & 0x80808080u) != 0;
 }
 
+// ---- newline searches over arbitrary distances (list kernels, walk_entry) -----------------------------
+// One thread, aligned 16-byte loads only (chunk buffers are padded to 16), 64 bytes per step while nothing is
+// found: a line of a few dozen bytes costs one or two loads, and a scan that has to cross megabytes of a
+// newline-less line moves 8-16x faster than a byte loop would.
+__device__ __forceinline__ uint32_t nl_mask_of_unit(const uint8_t* p) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  const uint32_t d[8] = {v.x, v.y, v.z, v.w, 0u, 0u, 0u, 0u};
+  return nl_mask16(d);
+}
+__device__ __forceinline__ uint32_t unit_has_nl(const uint8_t* p) {  // 0 / 1; combined with | so that the loads stay independent
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  const uint32_t d[8] = {v.x, v.y, v.z, v.w, 0u, 0u, 0u, 0u};
+  return nl_any16(d) ? 1u : 0u;
+}
+// does any of the 256 bytes at p (16-byte aligned) hold a newline?  Sixteen independent loads, one combined test.
+__device__ __forceinline__ bool block_has_nl(const uint8_t* p) {
+  uint32_t acc = 0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p + u * kUnit);
+    const uint32_t x0 = v.x ^ 0x0a0a0a0au, x1 = v.y ^ 0x0a0a0a0au, x2 = v.z ^ 0x0a0a0a0au, x3 = v.w ^ 0x0a0a0a0au;
+    acc |= ((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) | ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3);
+  }
+  return (acc & 0x80808080u) != 0;  // exact as an existence test
+}
+// offset of the first '\n' in d[lo, hi), or -1
+__device__ __forceinline__ int64_t first_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi) {
+  if (lo >= hi) return -1;
+  uint64_t p = lo & ~(uint64_t)15;
+  uint32_t range = 0xffffu << (uint32_t)(lo - p);  // first unit: positions >= lo
+  for (;;) {
+    if (range == 0xffffu) {  // past the first unit: skip 256, then 64 bytes at a time while they hold no newline
+      while (p + 16 * kUnit <= hi && !block_has_nl(d + p)) p += 16 * kUnit;
+      while (p + 4 * kUnit <= hi && !(unit_has_nl(d + p) | unit_has_nl(d + p + kUnit) | unit_has_nl(d + p + 2 * kUnit) |
+                                      unit_has_nl(d + p + 3 * kUnit)))
+        p += 4 * kUnit;
+    }
+    if (p >= hi) return -1;
+    uint32_t m = nl_mask_of_unit(d + p) & range & 0xffffu;
+    if (hi - p < kUnit) m &= (1u << (uint32_t)(hi - p)) - 1u;
+    if (m) return (int64_t)(p + (uint32_t)__ffs((int)m) - 1u);
+    p += kUnit;
+    range = 0xffffu;
+  }
+}
+// offset of the last '\n' in d[lo, hi), or -1
+__device__ __forceinline__ int64_t last_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi) {
+  if (lo >= hi) return -1;
+  uint64_t p = (hi - 1u) & ~(uint64_t)15;  // unit of the last byte of the range
+  uint32_t range = hi - p >= kUnit ? 0xffffu : (1u << (uint32_t)(hi - p)) - 1u;
+  const uint64_t lo_unit = lo & ~(uint64_t)15;
+  for (;;) {
+    if (range == 0xffffu) {
+      while (p >= lo_unit + 16 * kUnit && !block_has_nl(d + p - 15 * kUnit)) p -= 16 * kUnit;
+      while (p >= lo_unit + 4 * kUnit && !(unit_has_nl(d + p) | unit_has_nl(d + p - kUnit) | unit_has_nl(d + p - 2 * kUnit) |
+                                           unit_has_nl(d + p - 3 * kUnit)))
+        p -= 4 * kUnit;
+    }
+    uint32_t m = nl_mask_of_unit(d + p) & range;
+    if (p < lo) m &= 0xffffu << (uint32_t)(lo - p);  // only in the unit that holds lo
+    m &= 0xffffu;
+    if (m) return (int64_t)(p + 31u - (uint32_t)__clz(m));
+    if (p <= lo_unit) return -1;
+    p -= kUnit;
+    range = 0xffffu;
+  }
+}
+
+// ---- the same searches by a whole wave ---------------------------------------------------------------
+// One lane moves ~0.25 GB/s through a newline-less stretch however the loads are arranged; a line of hundreds of
+// megabytes (a minified file, a binary blob) would keep a list kernel busy for seconds per scan.  All 64 lanes
+// together read 4 KiB per step.  Every lane must call these with the SAME arguments (and all 64 must be active).
+__device__ __forceinline__ int64_t wave_first_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi, uint32_t lane) {
+  if (lo >= hi) return -1;
+  constexpr int U = 4;
+  for (uint64_t p = lo & ~(uint64_t)15; p < hi; p += (uint64_t)U * 64u * kUnit) {
+    uint32_t m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t a = p + ((uint64_t)u * 64u + lane) * kUnit;
+      uint32_t x = 0;
+      if (a < hi) {
+        x = nl_mask_of_unit(d + a) & 0xffffu;
+        if (a < lo) x &= 0xffffu << (uint32_t)(lo - a);  // the unit that holds lo
+        if (hi - a < kUnit) x &= (1u << (uint32_t)(hi - a)) - 1u;
+      }
+      m[u] = x;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long b = __ballot(m[u] != 0);
+      if (b) {
+        const int L = __builtin_ctzll(b);  // lowest address of the group
+        const uint32_t mm = (uint32_t)__shfl((int)m[u], L);
+        return (int64_t)(p + ((uint64_t)u * 64u + (uint64_t)L) * kUnit + (uint32_t)__ffs((int)mm) - 1u);
+      }
+    }
+  }
+  return -1;
+}
+__device__ __forceinline__ int64_t wave_last_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi, uint32_t lane) {
+  if (lo >= hi) return -1;
+  constexpr int U = 4;
+  const uint64_t top = (hi - 1u) & ~(uint64_t)15;               // unit of the last byte
+  const uint64_t K = (top - (lo & ~(uint64_t)15)) / kUnit;      // units are numbered downwards from the top: 0..K
+  for (uint64_t kb = 0; kb <= K; kb += (uint64_t)U * 64u) {
+    uint32_t m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = kb + (uint64_t)u * 64u + lane;
+      uint32_t x = 0;
+      if (k <= K) {
+        const uint64_t a = top - k * kUnit;
+        x = nl_mask_of_unit(d + a) & 0xffffu;
+        if (a < lo) x &= 0xffffu << (uint32_t)(lo - a);
+        if (hi - a < kUnit) x &= (1u << (uint32_t)(hi - a)) - 1u;
+      }
+      m[u] = x;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long b = __ballot(m[u] != 0);
+      if (b) {
+        const int L = __builtin_ctzll(b);  // smallest k = highest address of the group
+        const uint32_t mm = (uint32_t)__shfl((int)m[u], L);
+        const uint64_t a = top - (kb + (uint64_t)u * 64u + (uint64_t)L) * kUnit;
+        return (int64_t)(a + 31u - (uint32_t)__clz(mm));
+      }
+    }
+  }
+  return -1;
+}
+
+// A newline query per lane (live lanes only), FORWARD: first in [lo, hi), else last in [lo, hi).  Each lane looks
+// kSoloScan bytes far on its own -- that settles every ordinary line -- and the whole wave then finishes the
+// queries that are still open, one after the other.  All 64 lanes of the wave must call this together.
+constexpr uint64_t kSoloScan = 4096;
+template <bool FORWARD>
+__device__ __forceinline__ int64_t newline_query(bool live, const uint8_t* d, uint64_t lo, uint64_t hi, uint32_t lane) {
+  int64_t res = -1;
+  bool pending = false;
+  if (live && lo < hi) {
+    if (FORWARD) {
+      const uint64_t cut = hi - lo > kSoloScan ? lo + kSoloScan : hi;
+      res = first_newline_in(d, lo, cut);
+      if (res < 0 && cut < hi) pending = true, lo = cut;
+    } else {
+      const uint64_t cut = hi - lo > kSoloScan ? hi - kSoloScan : lo;
+      res = last_newline_in(d, cut, hi);
+      if (res < 0 && cut > lo) pending = true, hi = cut;
+    }
+  }
+  unsigned long long pend = __ballot(pending);
+  while (pend) {  // wave-uniform
+    const int L = __builtin_ctzll(pend);
+    const uint8_t* dd = reinterpret_cast<const uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)d, L));
+    const uint64_t l2 = (uint64_t)__shfl((long long)lo, L), h2 = (uint64_t)__shfl((long long)hi, L);
+    const int64_t r = FORWARD ? wave_first_newline_in(dd, l2, h2, lane) : wave_last_newline_in(dd, l2, h2, lane);
+    if ((int)lane == L) res = r;
+    pend &= pend - 1ull;
+  }
+  return res;
+}
+
 // w[b] = the 4 bytes starting at byte b of the lane's 32-byte view (own unit + neighbour's)
 // simd::toLower on 4 bytes at once (src/utils/string_utils.cpp:11-33): bytes in
 // 'A'..'Z' get bit 5 set, everything else (incl. bytes >= 0x80) is unchanged.
@@ -818,11 +982,14 @@ __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* sh) {
   return t;  // valid in thread 0
 }
 
-// where the reference walk stands when it reaches the tail zone of a chunk
-__device__ __forceinline__ uint64_t walk_entry(const uint8_t* d, uint64_t L, uint64_t last_end, bool skip_to_nl) {
+// where the reference walk stands when it reaches the tail zone of a chunk: after the last bulk match (match
+// modes), at the start of the line after the last bulk matching line (line modes; UINT64_MAX if that line has
+// no '\n': the walk ended).  Wave-uniform arguments, all lanes active.
+__device__ __forceinline__ uint64_t wave_walk_entry(const uint8_t* d, uint64_t L, uint64_t last_end, bool skip_to_nl,
+                                                   uint32_t lane) {
   if (last_end == 0) return 0;
   if (!skip_to_nl) return last_end;
-  const int64_t nl = next_newline(d, last_end, L);
+  const int64_t nl = wave_first_newline_in(d, last_end, L, lane);
   return nl < 0 ? UINT64_MAX : (uint64_t)nl + 1u;
 }
 
@@ -881,14 +1048,14 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
       }
     }
-    if (lane == 0) {
-      if (need_tail) {
+    if (need_tail) {
+      // the line-mode entry point may lie a whole huge line away: found by the wave, not by lane 0 alone
+      const uint64_t entry_lines = A.want_lines ? wave_walk_entry(d, ch.length, last_end, true, lane) : 0;
+      if (lane == 0) {
         if (A.want_matches)
-          cm += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, false), false,
-                          nullptr, 0, A.pat.icase != 0);
+          cm += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, last_end, false, nullptr, 0, A.pat.icase != 0);
         if (A.want_lines)
-          lines += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, walk_entry(d, ch.length, last_end, true), true,
-                             nullptr, 0, A.pat.icase != 0);
+          lines += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, entry_lines, true, nullptr, 0, A.pat.icase != 0);
       }
     }
   }
@@ -1068,35 +1235,44 @@ __global__ void k_greedy_keep(const ListArgs A) {
 // far as the previous match (the first match of a chunk: to the chunk start).  The
 // scans of one chunk are disjoint: O(chunk) bytes in total however long the lines
 // are (a walk back to the line start per match would be quadratic on one huge line).
-__global__ void k_line_starts_keep(const ListArgs A) {
+__global__ __launch_bounds__(kBlock) void k_line_starts_keep(const ListArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= A.M) return;
-  const uint32_t c = A.m_chunk[i];
+  const bool live = i < A.M;  // no early return: the wave finishes long scans together (newline_query)
+  const uint32_t c = live ? A.m_chunk[i] : 0u;
   const uint8_t* d = A.base + A.chunks[c].offset;
-  const bool first_in_chunk = i == 0 || A.m_chunk[i - 1] != c;
-  const uint64_t lo = first_in_chunk ? 0 : A.m_pos[i - 1];
-  uint64_t p = A.m_pos[i];
-  while (p > lo && d[p - 1] != '\n') --p;
-  const bool found_nl = p > lo;  // d[p-1] is the newline that opens the match's line
+  const bool first_in_chunk = live && (i == 0 || A.m_chunk[i - 1] != c);
+  const uint64_t lo = (!live || first_in_chunk) ? 0 : A.m_pos[i - 1];
+  const uint64_t hi = live ? A.m_pos[i] : 0;
+  // the newline that opens the match's line, if it lies in [lo, match)
+  const int64_t nl = newline_query<false>(live, d, lo, hi, threadIdx.x & 63u);
+  if (!live) return;
+  const bool found_nl = nl >= 0;
   A.keep[i] = (found_nl || first_in_chunk) ? 1u : 0u;
-  A.m_ls[i] = p;  // meaningful for kept matches only (p == 0 for a first match on the chunk's first line)
+  A.m_ls[i] = found_nl ? (uint64_t)nl + 1u : lo;  // meaningful for kept matches only (0 for a first match on the chunk's first line)
 }
 
 // per chunk: where the walk enters the tail zone, from the last kept bulk match
-__global__ void k_chunk_shift0(const ListArgs A) {
+__global__ __launch_bounds__(kBlock) void k_chunk_shift0(const ListArgs A) {
   const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (c >= A.nchunks) return;
-  const uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
+  const bool live = c < A.nchunks;
   uint64_t last_end = 0;
-  // last kept raw match of the chunk (kept ones are never far from the end of a chain)
-  for (uint64_t i = r1; i > r0; --i) {
-    if (A.keep[i - 1]) {
-      last_end = A.m_pos[i - 1] + A.pat.plen;
-      break;
+  ChunkDev ch{};
+  if (live) {
+    const uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
+    // last kept raw match of the chunk (kept ones are never far from the end of a chain)
+    for (uint64_t i = r1; i > r0; --i) {
+      if (A.keep[i - 1]) {
+        last_end = A.m_pos[i - 1] + A.pat.plen;
+        break;
+      }
     }
+    ch = A.chunks[c];
   }
-  const ChunkDev ch = A.chunks[c];
-  A.chunk_shift0[c] = walk_entry(A.base + ch.offset, ch.length, last_end, A.line_mode != 0);
+  // line modes: the walk continues at the start of the line after the last kept match (UINT64_MAX: no such line)
+  const bool need_nl = live && last_end != 0 && A.line_mode != 0;
+  const int64_t nl = newline_query<true>(need_nl, A.base + ch.offset, last_end, ch.length, threadIdx.x & 63u);
+  if (!live) return;
+  A.chunk_shift0[c] = last_end == 0 ? 0 : !A.line_mode ? last_end : nl < 0 ? UINT64_MAX : (uint64_t)nl + 1u;
 }
 
 __global__ void k_tail_list(const ListArgs A) {
@@ -1121,19 +1297,27 @@ __global__ void k_assemble(const ListArgs A) {
     A.f_match[dst] = A.m_pos[i];
     A.f_chunk[dst] = c;
   }
-  if (i < A.nchunks) {
-    const uint64_t c = i;
-    const uint32_t n = A.tail_cnt[c];
-    if (n) {
-      const uint64_t r1 = A.tile_off[A.chunk_tile0[c + 1]];
-      const uint64_t dst0 = A.keep_pre[r1] + A.tail_pre[c];
-      const uint8_t* d = A.base + A.chunks[c].offset;
-      for (uint32_t k = 0; k < n; ++k) {
-        const uint64_t m = A.tail_pos[c * A.tail_cap + k];
-        uint64_t p = m;
-        if (A.line_mode)
-          while (p > 0 && d[p - 1] != '\n') --p;
-        A.f_pos[dst0 + k] = p;
+  // the tail walk's matches, one thread per chunk; their line starts may lie a whole huge line back, so the
+  // loop runs wave-uniformly (up to the largest count in the wave) and the wave shares long scans
+  const bool has_chunk = i < A.nchunks;
+  const uint64_t c = has_chunk ? i : 0;
+  const uint32_t n = has_chunk ? A.tail_cnt[c] : 0u;
+  uint32_t nmax = n;
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)nmax, sft);
+    nmax = o > nmax ? o : nmax;
+  }
+  if (nmax) {
+    const uint64_t r1 = has_chunk ? A.tile_off[A.chunk_tile0[c + 1]] : 0;
+    const uint64_t dst0 = has_chunk ? A.keep_pre[r1] + A.tail_pre[c] : 0;
+    const uint8_t* d = A.base + A.chunks[c].offset;
+    for (uint32_t k = 0; k < nmax; ++k) {
+      const bool live = k < n;
+      const uint64_t m = live ? A.tail_pos[c * A.tail_cap + k] : 0;
+      const int64_t nl = newline_query<false>(live && A.line_mode != 0, d, 0, m, threadIdx.x & 63u);
+      if (live) {
+        A.f_pos[dst0 + k] = !A.line_mode ? m : nl < 0 ? 0u : (uint64_t)nl + 1u;
         A.f_match[dst0 + k] = m;
         A.f_chunk[dst0 + k] = (uint32_t)c;
       }
@@ -1281,12 +1465,13 @@ __global__ void k_line_indices(const LineOutArgs A) {
 
 // xs::lines: [line start, next '\n' after the match); a line without '\n' is
 // dropped (search_wrappers.h:199-202)
-__global__ void k_line_lengths(const LineOutArgs A) {
+__global__ __launch_bounds__(kBlock) void k_line_lengths(const LineOutArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= A.total) return;
-  const ChunkDev ch = A.chunks[A.f_chunk[i]];
+  const bool live = i < A.total;  // no early return: see newline_query
+  const ChunkDev ch = A.chunks[live ? A.f_chunk[i] : 0u];
   const uint8_t* d = A.base + ch.offset;
-  const int64_t e = next_newline(d, A.f_match[i] + A.pat.plen, ch.length);
+  const int64_t e = newline_query<true>(live, d, live ? A.f_match[i] + A.pat.plen : 0, ch.length, threadIdx.x & 63u);
+  if (!live) return;
   A.line_len[i] = e < 0 ? UINT64_MAX : (uint64_t)e - A.f_pos[i];
   A.out_u64[i] = ch.global_offset + A.f_pos[i];
 }
