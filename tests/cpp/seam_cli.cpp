@@ -1,10 +1,12 @@
 // seam_cli.cpp -- drives the reference-style searcher functors
 // (include/xsearch/tasks/gpu_searchers.h) the way Searcher::run_thread does
 // (include/xsearch/Searcher.h:100-120): N threads pull chunks (std::vector<char>,
-// the reference's xs::strtype) and call ONE shared const functor concurrently.
+// the reference's xs::strtype) from ONE shared reader functor (tasks/aligned_reader.h)
+// and call ONE shared const searcher functor concurrently.
 //
 // usage: seam_cli <index|line_index|line|count> <pattern> <file> <chunk_bytes> <threads>
 // prints: per chunk "C <chunk_index> <n>" then the chunk-local values, in chunk order.
+#include <xsearch/tasks/aligned_reader.h>
 #include <xsearch/tasks/gpu_searchers.h>
 
 #include <atomic>
@@ -17,39 +19,19 @@
 
 using strtype = std::vector<char>;
 
-static std::vector<strtype> newline_aligned_chunks(const std::string& path, size_t target) {
-  std::ifstream f(path, std::ios::binary);
-  std::vector<char> all((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-  std::vector<strtype> out;
-  size_t pos = 0;
-  while (pos < all.size()) {
-    size_t end = pos + target;
-    if (end >= all.size()) {
-      end = all.size();
-    } else {
-      size_t q = end - 1;
-      while (q < all.size() && all[q] != '\n') ++q;
-      end = q < all.size() ? q + 1 : all.size();
-    }
-    out.emplace_back(all.begin() + pos, all.begin() + end);
-    pos = end;
-  }
-  return out;
-}
-
+// Searcher::run_thread (Searcher.h:100-120): every worker calls the SHARED reader, then the SHARED searcher
 template <class Functor, class Printer>
-static void run(const Functor& fn, const std::vector<strtype>& chunks, int threads, Printer print) {
-  std::atomic<size_t> next{0};
+static void run(const Functor& fn, xs::AlignedFileReader<strtype>& reader, int threads, Printer print) {
   std::mutex mu;
   std::map<size_t, std::string> outs;
   auto worker = [&] {
     for (;;) {
-      const size_t i = next.fetch_add(1);
-      if (i >= chunks.size()) break;
-      auto r = fn(chunks[i]);  // shared const functor, concurrent calls
-      std::string s = print(i, r);
+      auto chunk = reader.next();  // operator()() plus the chunk's index, for the ordered printout
+      if (!chunk) break;
+      auto r = fn(chunk->data);  // shared const functor, concurrent calls
+      std::string s = print(chunk->index, r);
       std::lock_guard<std::mutex> g(mu);
-      outs[i] = std::move(s);
+      outs[chunk->index] = std::move(s);
     }
   };
   std::vector<std::thread> ts;
@@ -67,7 +49,7 @@ int main(int argc, char** argv) {
   const size_t target = std::stoull(argv[4]);
   const int threads = std::atoi(argv[5]);
   try {
-    auto chunks = newline_aligned_chunks(file, target);
+    xs::AlignedFileReader<strtype> chunks(file, target);  // the ReaderC-shaped reader of this repo
     auto print_u64 = [](size_t i, const std::optional<std::vector<uint64_t>>& r) {
       std::string s = "C " + std::to_string(i) + " " + std::to_string(r ? r->size() : 0) + "\n";
       if (r)

@@ -196,3 +196,29 @@ def test_builtin_lz4_writes_what_liblz4_reads(text_file, tmp_path):
     a, b = outs["lib"][0], outs["own"][0]
     assert len(a) == len(b) and (a["original_offset"] == b["original_offset"]).all() and (a["original_size"] == b["original_size"]).all()
     assert 0 < outs["own"][1] < data.size  # it does compress text
+
+
+def test_aligned_file_reader_functor(text_file, tmp_path):
+    """include/xsearch/tasks/aligned_reader.h: the ReaderC-shaped chunk reader (reference: tasks/readers.h:29-54,
+    concepts.h:24-27) hands out the newline-aligned plan, from 4 threads sharing one instance, with and without
+    a metafile (tests/cpp/reader_selftest.cpp)."""
+    import subprocess
+    exe = Path(__file__).resolve().parent / "cpp" / "build" / "reader_selftest"
+    if not exe.exists():
+        pytest.fail(f"{exe} not built (make -C tests/cpp)")
+    p, data = text_file
+    for target in (1 << 16, 1 << 19, 1 << 30):
+        r = subprocess.run([str(exe), str(p), str(target)], capture_output=True, timeout=120)
+        assert r.returncode == 0 and b"reader selftest ok" in r.stdout, (r.stdout + r.stderr).decode()
+    meta = tmp_path / "plain.meta"
+    xsg.meta_write(str(p), str(meta), None, xsg.COMPRESSION_NONE, 1 << 18, 500)
+    r = subprocess.run([str(exe), str(p), str(1 << 18), str(meta)], capture_output=True, timeout=120)
+    assert r.returncode == 0 and b"reader selftest ok" in r.stdout, (r.stdout + r.stderr).decode()
+    lz = tmp_path / "c.meta"
+    xsg.meta_write(str(p), str(lz), str(tmp_path / "c.xslz4"), xsg.COMPRESSION_LZ4, 1 << 18, 500)
+    r = subprocess.run([str(exe), str(tmp_path / "c.xslz4"), str(1 << 18), str(lz)], capture_output=True, timeout=120)
+    assert r.returncode == 1 and b"compressed" in r.stdout
+    empty = tmp_path / "empty.txt"
+    empty.write_bytes(b"")
+    r = subprocess.run([str(exe), str(empty), "65536"], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stdout.decode()
