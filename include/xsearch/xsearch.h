@@ -42,6 +42,7 @@
 #include <cstdlib>
 #include <iterator>
 #include <memory>
+#include <mutex>
 #include <regex>
 #include <stdexcept>
 #include <string>
@@ -214,6 +215,8 @@ struct JobSet {
   std::vector<xsg_job*> jobs;
   bool is_count = false;
   bool add_newline_base = false;  // xs::line_indices without a metafile
+  mutable std::mutex _mu;
+  mutable std::vector<uint64_t> _carry;
 
   // Finds the job that holds element i of the concatenated sequence; blocks until the element exists or every
   // job is closed.  Every job before the returned one is finished.
@@ -233,10 +236,14 @@ struct JobSet {
     }
     return false;
   }
-  // what the finished jobs before job k add to a value of job k
+  // what the finished jobs before job k add to a value of job k (constant once asked for: those jobs are closed)
   uint64_t carry(size_t k) const {
+    if (k == 0 || !(is_count || add_newline_base)) return 0;
+    std::lock_guard<std::mutex> g(_mu);
+    if (_carry.size() < jobs.size()) _carry.assign(jobs.size(), UINT64_MAX);
+    if (_carry[k] != UINT64_MAX) return _carry[k];
     uint64_t c = 0;
-    for (size_t h = 0; h < k && (is_count || add_newline_base); ++h) {
+    for (size_t h = 0; h < k; ++h) {
       if (is_count) {
         uint64_t t = 0;
         const int r = xsg_job_total(jobs[h], &t);
@@ -249,7 +256,7 @@ struct JobSet {
         c += st.newlines;
       }
     }
-    return c;
+    return _carry[k] = c;
   }
   template <class V>
   V get(size_t k, uint64_t local) const {
