@@ -25,12 +25,27 @@ _REF = HERE / "_ref" / "libxsref.so"
 _u64p = C.POINTER(C.c_uint64)
 
 
+def _stale() -> bool:
+    return not _LIB.exists() or _LIB.stat().st_mtime < (HERE / "xs_oracle.c").stat().st_mtime
+
+
 def build(force: bool = False) -> None:
-    """Compile the oracle (and oracle/_ref when /root/reference is mounted)."""
-    if force or not _LIB.exists() or _LIB.stat().st_mtime < (HERE / "xs_oracle.c").stat().st_mtime:
-        subprocess.check_call(["make", "-C", str(HERE), "--no-print-directory"], stdout=subprocess.DEVNULL)
-    elif not _REF.exists() and Path("/root/reference/src/string_search/simd_search.cpp").exists():
-        subprocess.check_call(["make", "-C", str(HERE), "--no-print-directory", "ref"], stdout=subprocess.DEVNULL)
+    """Compile the oracle (and oracle/_ref when /root/reference is mounted).  Several processes may get here at
+    once (bench.py under torch.distributed.run starts one per GPU): the build runs under a file lock and the
+    others find the library up to date when they get the lock."""
+    need_ref = not _REF.exists() and Path("/root/reference/src/string_search/simd_search.cpp").exists()
+    if not (force or _stale() or need_ref):
+        return
+    import fcntl
+    with open(HERE / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or _stale():
+                subprocess.check_call(["make", "-C", str(HERE), "--no-print-directory"], stdout=subprocess.DEVNULL)
+            elif not _REF.exists() and need_ref:
+                subprocess.check_call(["make", "-C", str(HERE), "--no-print-directory", "ref"], stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def host_has_avx2() -> bool:
