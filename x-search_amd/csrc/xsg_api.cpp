@@ -183,21 +183,38 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   c->pattern.assign(re, re + n);
   c->flags = flags;
   c->bordered = xsg::sequence_can_overlap(seq);
-  // the window with the most (and rarest) literal bytes; class positions inside it are don't-care bytes
+  // What the window compare can know about a position: the bits all members of its set agree on (a literal: all
+  // eight; [Ss]: seven; [0-9]: the upper four; [a-z]: the upper three).  (x & agree) == (member & agree) holds for
+  // every member x, so it is a superset filter at no cost -- the compare is masked per byte anyway -- and the
+  // exact decision against the sets follows for the rare candidate.
+  std::vector<uint8_t> agree(plen), value(plen);
+  for (size_t k = 0; k < plen; ++k) {
+    int first = -1;
+    uint32_t diff = 0;
+    for (uint32_t b = 0; b < 256; ++b)
+      if (xsg::set_has(seq[k], b)) {
+        if (first < 0) first = (int)b;
+        diff |= b ^ (uint32_t)first;
+      }
+    agree[k] = (uint8_t)~diff;
+    value[k] = (uint8_t)((uint32_t)first & ~diff);
+  }
+  // the window that pins the most bits (rarer literal bytes break ties)
   uint32_t koff = 0;
   int best = -1;
   for (size_t k = 0; k < plen; ++k) {
     int score = 0;
-    for (int i = 0; i < 8 && k + i < plen; ++i)
-      if (xsg::set_single(seq[k + i]) >= 0) score += 100 + byte_rarity(lit[k + i], i);
+    for (int i = 0; i < 8 && k + i < plen; ++i) {
+      score += 16 * __builtin_popcount(agree[k + i]);
+      if (agree[k + i] == 0xff) score += byte_rarity(value[k + i], i);
+    }
     if (score > best) best = score, koff = (uint32_t)k;
   }
   uint32_t pw[2] = {0, 0}, mw[2] = {0, 0};
-  for (int i = 0; i < 8 && koff + i < plen; ++i)
-    if (xsg::set_single(seq[koff + i]) >= 0) {
-      pw[i >> 2] |= (uint32_t)lit[koff + i] << (8 * (i & 3));
-      mw[i >> 2] |= 0xffu << (8 * (i & 3));
-    }
+  for (int i = 0; i < 8 && koff + i < plen; ++i) {
+    pw[i >> 2] |= (uint32_t)value[koff + i] << (8 * (i & 3));
+    mw[i >> 2] |= (uint32_t)agree[koff + i] << (8 * (i & 3));
+  }
   XSG_TRY(c->d_pat.ensure(XSG_MAX_PATTERN + 16));
   static_assert(xsg::kMaxClassSeq * sizeof(xsg::ByteSet) <= XSG_MAX_PATTERN, "sets must fit the pattern buffer");
   std::vector<uint8_t> padded(XSG_MAX_PATTERN + 16, 0);
