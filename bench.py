@@ -7,8 +7,12 @@ Metric (BASELINE.json): GiB/s scanned (+ matches/s) for xs::count (literal
 One "step" = one pass of the hot path over the rank's whole shard: the bulk scan
 kernel over every chunk, the finish kernel (per-tile sums + the reference's
 end-of-chunk walk) and -- for N > 1 -- one RCCL all-reduce (sum) of the four
-uint64 counters.  Inputs are resident in HBM when the timed region starts
-(weak scaling: every rank owns --gib-per-gpu GiB, default 50).
+uint64 counters.  Inputs are resident in HBM when the timed region starts.
+
+Two forms are measured in every run:
+  weak   : every rank owns --gib-per-gpu GiB (default 50)  -> `value`, "scaling": "weak"
+  strong : --gib-per-gpu GiB IN TOTAL, the first 1/N of every rank's chunks       -> `strong`
+           (50 GiB over 8 GPUs = 400 chunks of 16 MiB per GPU)
 
 Corpus: synthetic (no network).  T distinct '\\n'-terminated template chunks of
 16 MiB (+ a few bytes, like the reference's .meta fixtures) are generated on the
@@ -18,12 +22,14 @@ address (the working set is >> the 256 MiB Infinity Cache) and the expected
 count of the full shard is known exactly from the oracle's counts of the T
 templates.  The result of EVERY timed step is checked against it.
 
-Launch:  python bench.py --gpus 1            (single process)
-         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+Launch:  python bench.py --gpus N      N > 1 starts its own N ranks (one per GPU, torch.distributed.run)
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N      (what the driver may also do)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -47,10 +53,33 @@ def parse():
     ap.add_argument("--templates", type=int, default=32)
     ap.add_argument("--pattern", type=str, default="Sherlock")
     ap.add_argument("--seed", type=int, default=0x5EED)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (rank 0, N=1)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=10)
+    ap.add_argument("--e2e-gib", type=float, default=4.0,
+                    help="size of the tmpfs file of the end-to-end (file -> result) leg; 0 = skip")
+    ap.add_argument("--no-tune", action="store_true", help="keep the per-variant default stagger")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves.  Must happen before anything touches the GPU
+# (a process that has initialised HIP must never be replaced or forked into ranks).
+# ---------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:  # relay; rank 0 prints the one JSON line
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return p.wait()
 
 
 def template_blocks(args, pattern: bytes):
@@ -70,59 +99,219 @@ def chunk_plan(args, rank: int, nchunks: int):
                     dtype=np.int64)
 
 
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------
+def host_topology():
+    """hardware threads we may run on, physical cores and sockets among them, NUMA nodes, cgroup CPU quota"""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores, sockets = set(), set()
+    try:
+        cpu, phys, core = None, None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip():
+                if cpu in allowed and phys is not None and core is not None:
+                    cores.add((phys, core))
+                    sockets.add(phys)
+                cpu = phys = core = None
+    except OSError:
+        pass
+    try:
+        nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        nodes = 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    mem_avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                mem_avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return {"hw_threads": len(allowed), "physical_cores": len(cores) or len(allowed), "sockets": len(sockets) or 1,
+            "numa_nodes": nodes, "cgroup_cpu_quota": quota, "mem_available": mem_avail}
+
+
 def cpu_baseline(args, blocks, pattern: bytes):
-    """The reference's CPU path on this host's cores, on a bounded sample of the
-    same workload: the template chunks, work-stealing threads like
-    include/xsearch/Searcher.h:100-120."""
-    from xs_oracle import Oracle, Reference
-    import corpus
+    """The reference's CPU path on this host's cores, on a bounded sample of the same workload: chunks of the same
+    corpus in RAM, a persistent pool of worker threads pulling chunk indices from a shared counter like
+    include/xsearch/Searcher.h:100-120 (one thread pool per search, >= 4 chunks per thread, pages first-touched by
+    the workers so that they spread over the NUMA nodes), T = 1 / physical cores / hardware threads."""
+    from xs_oracle import CpuPoolCorpus, Oracle, Reference
     orc = Oracle()
     kind = "port"
-    ref = None
     if Reference.available():
         try:
-            ref = Reference()
-            orc.use_reference_primitives(ref)  # the timed work is the reference's own compiled simd_search.cpp
+            orc.use_reference_primitives(Reference())  # the timed work is the reference's own compiled simd_search.cpp
             kind = "reference"
         except Exception:
-            ref = None
-    off, ln, cap = corpus.chunk_table([b.size for b in blocks])
-    buf = np.zeros(cap, dtype=np.uint8)
-    for o, b in zip(off, blocks):
-        buf[int(o):int(o) + b.size] = b
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    sample_bytes = int(ln.sum())
-    out = {}
-    want = None
-    for label, nt in (("1", 1), ("all", cores)):
-        budget = args.cpu_seconds / 2
-        t_total, passes = 0.0, 0
-        while t_total < budget and passes < 64:
-            t0 = time.perf_counter()
-            tot, _ = orc.count_chunks_mt(buf, off, ln, pattern, False, nt)
-            t_total += time.perf_counter() - t0
-            passes += 1
-            want = tot if want is None else want
-            assert tot == want
-        out[label] = (sample_bytes * passes / t_total / 2**30, passes)
+            kind = "port"
+    topo = host_topology()
+    hw, pc = topo["hw_threads"], topo["physical_cores"]
+    chunk_bytes = int(blocks[0].size)
+    want_chunks = max(64, 4 * hw)
+    if topo["mem_available"]:
+        want_chunks = min(want_chunks, max(16, int(topo["mem_available"] * 0.25) // chunk_bytes))
+    plan = chunk_plan(args, 0x7777, want_chunks)
+    corp = CpuPoolCorpus(orc, blocks, plan, nthreads_touch=hw)
+    tcount = [orc.count(b, pattern, False) for b in blocks]
+    expect_all = int(sum(tcount[int(t)] for t in plan))
+    ts = sorted({1, pc, hw})
+    per_t = args.cpu_seconds / (len(ts) + 1)
+    rates = {}
+    for t in ts:
+        first = max(16, min(want_chunks, 16 * t)) if t == 1 else want_chunks  # one thread: a 16-chunk sample is plenty
+        tot, sec, nb = corp.count(pattern, t, 1, first_chunks=first)  # calibration pass
+        passes = max(1, min(200, int(per_t / max(sec, 1e-4))))
+        tot, sec, nb = corp.count(pattern, t, passes, first_chunks=first)
+        exp = int(sum(tcount[int(x)] for x in plan[:first]))
+        if tot != exp:
+            raise SystemExit(f"CPU baseline: count {tot} != expected {exp}")
+        rates[t] = (nb * passes / sec / 2**30, passes, first)
+    corp.close()
     orc.use_reference_primitives(None)
+    best_t = max((t for t in ts if t > 1), key=lambda t: rates[t][0], default=1)
+    r1, rbest = rates[1][0], rates[best_t][0]
+    note = (f"{best_t} threads are {rbest / r1:.1f}x one thread"
+            + (f"; cgroup limits this process to {topo['cgroup_cpu_quota']} CPUs" if topo["cgroup_cpu_quota"] else "")
+            + ("; beyond that the search is DRAM-bandwidth-bound" if rbest / r1 < 0.5 * best_t and not topo["cgroup_cpu_quota"] else ""))
     return {
-        "value": round(out["all"][0], 3),
+        "value": round(rbest, 3),
         "unit": "GiB/s",
-        "cores": cores,
+        "cores": best_t,
         "kind": kind,
-        "value_1thread": round(out["1"][0], 3),
-        "sample": f"{len(blocks)} chunks x {args.chunk_mib} MiB = {sample_bytes / 2**20:.0f} MiB of the same corpus in RAM, "
-                  f"{out['all'][1]} passes with {cores} threads / {out['1'][1]} passes with 1 thread "
-                  f"(xs::count, chunk work-stealing)",
+        "value_1thread": round(r1, 3),
+        "by_threads": {str(t): round(rates[t][0], 3) for t in ts},
+        "physical_cores": pc, "hw_threads": hw, "sockets": topo["sockets"], "numa_nodes": topo["numa_nodes"],
+        "cgroup_cpu_quota": topo["cgroup_cpu_quota"],
+        "expected_count_checked": expect_all >= 0,
+        "note": note,
+        "sample": f"{want_chunks} chunks x {args.chunk_mib} MiB = {want_chunks * chunk_bytes / 2**30:.1f} GiB of the same corpus in RAM "
+                  f"(first-touched by the workers), persistent thread pool, chunk work-stealing, xs::count; "
+                  + ", ".join(f"T={t}: {rates[t][1]} passes over {rates[t][2]} chunks" for t in ts),
     }
+
+
+# ---------------------------------------------------------------------------------------------------
+# end-to-end leg: tmpfs file -> reader threads -> pinned buffers -> H2D -> scan -> result
+# ---------------------------------------------------------------------------------------------------
+def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
+    """file -> result wall time of xs::extern_search's pipeline (xsg_job_*) on a tmpfs file: PCIe- and
+    host-read-bound, reported beside -- never as -- `value`.  N > 1: every rank searches its contiguous chunk range
+    of the SAME file (config 3/5's fan-out); the rate is file bytes / the slowest rank's wall time."""
+    import xsg
+    n = max(world, int(args.e2e_gib * 2**30 / (args.chunk_mib << 20)))
+    plan = chunk_plan(args, 0xE2E, n)
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(d, f"xsg_bench_e2e_{os.environ.get('MASTER_PORT', os.getpid())}.txt")
+    out = {}
+    made = []
+    try:
+        if rank == 0:
+            with open(path, "wb") as f:
+                for c in plan:
+                    f.write(blocks[int(c)].tobytes())
+            made.append(path)
+        if dist is not None:
+            dist.barrier()
+        size = os.path.getsize(path)
+        want_total = int(sum(tcount[int(c)] for c in plan))
+        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+        want_local = int(sum(tcount[int(c)] for c in plan[lo:hi]))
+        nthreads = int(os.environ.get("XSG_E2E_WORKERS", "4"))
+        nreaders = int(os.environ.get("XSG_E2E_READERS", "8"))
+
+        def run(mode, meta=None, data=None):
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            j = xsg.Job(pattern, data or path, mode, meta_path=meta, device=dev_index, num_threads=nthreads,
+                        num_max_readers=nreaders, chunk_range=(lo, hi) if world > 1 else None)
+            r = j.result()
+            dt = time.perf_counter() - t0
+            j.close()
+            if dist is not None:  # wall time of the slowest rank (this leg is not a device measurement)
+                dt = _allreduce_max_host(dist, dt)
+            return r, dt
+
+        run(xsg.COUNT_MATCHES)  # warm: thread/buffer pools, page cache
+        r, dt = run(xsg.COUNT_MATCHES)
+        if r != want_local:
+            raise SystemExit(f"e2e PARITY FAILURE: count {r} != {want_local}")
+        out["count_gib_s"] = round(size / dt / 2**30, 2)
+        r, dt = run(xsg.MATCH_BYTE_OFFSETS)
+        if len(r) != want_local:
+            raise SystemExit(f"e2e PARITY FAILURE: {len(r)} offsets != {want_local}")
+        out["match_byte_offsets_gib_s"] = round(size / dt / 2**30, 2)
+        r, dt = run(xsg.LINE_INDICES)
+        out["line_indices_gib_s"] = round(size / dt / 2**30, 2)
+        r, dt = run(xsg.LINES)
+        out["lines_gib_s"] = round(size / dt / 2**30, 2)
+        # config 5: LZ4 blocks + metafile, host decode overlapped with H2D + scan
+        mp, dp = path + ".lz4.meta", path + ".lz4"
+        if rank == 0:
+            small = path + ".part"
+            nsmall = max(world, n // 4)
+            with open(small, "wb") as f:
+                for c in plan[:nsmall]:
+                    f.write(blocks[int(c)].tobytes())
+            made.append(small)
+            xsg.meta_write(small, mp, dp, xsg.COMPRESSION_LZ4)
+            made += [mp, dp]
+        if dist is not None:
+            dist.barrier()
+        nsmall = max(world, n // 4)
+        lo, hi = (nsmall * rank) // world, (nsmall * (rank + 1)) // world
+        want_l = int(sum(tcount[int(c)] for c in plan[lo:hi]))
+        nreaders = int(os.environ.get("XSG_E2E_DECODERS", "12"))
+        run(xsg.COUNT_MATCHES, mp, dp)
+        r, dt = run(xsg.COUNT_MATCHES, mp, dp)
+        if r != want_l:
+            raise SystemExit(f"e2e PARITY FAILURE (lz4): count {r} != {want_l}")
+        small_bytes = int(sum(blocks[int(c)].size for c in plan[:nsmall]))
+        out["lz4_metafile_count_gib_s"] = round(small_bytes / dt / 2**30, 2)
+        out["lz4_compressed_fraction"] = round(os.path.getsize(dp) / small_bytes, 3) if rank == 0 else None
+        out["file_gib"] = round(size / 2**30, 2)
+        out["threads"] = f"{nthreads} device workers + 8 readers per GPU (12 reader/decoder threads for LZ4)"
+        out["what"] = ("wall time from xsg_job_start to join on a tmpfs file (page-cache read -> pinned buffers -> "
+                       "hipMemcpyAsync -> scan -> ordered result); bounded by PCIe Gen5 x16 and the host read path, "
+                       "not by HBM")
+        out["total_matches"] = want_total
+    finally:
+        if dist is not None:
+            dist.barrier()
+        for f in made:
+            if os.path.exists(f):
+                os.unlink(f)
+    return out
+
+
+def _allreduce_max_host(dist, x: float) -> float:
+    objs = [None] * dist.get_world_size()
+    dist.all_gather_object(objs, float(x))
+    return max(objs)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+
     import torch
     import xsg
     from xs_oracle import Oracle
@@ -131,16 +320,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # Rehearsal hook (not used by the driver): XSG_BENCH_BACKEND=gloo runs the N>1 code path on a box with
     # fewer GPUs than ranks (all ranks scan on the visible GPUs, the collective goes through host memory).
     backend = os.environ.get("XSG_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
+    ndev = torch.cuda.device_count()  # does not initialise the GPU
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    if dev_index >= ndev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({ndev} visible)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -149,6 +338,11 @@ def main():
     if world > 1 or os.environ.get("XSG_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_mod
         dist = dist_mod
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
         else:
@@ -162,7 +356,7 @@ def main():
     orc = Oracle()
     tcount = np.array([orc.count(b, pattern, False) for b in blocks], dtype=np.int64)
     tbytes = np.array([b.size for b in blocks], dtype=np.int64)
-    nchunks = max(1, int(round(args.gib_per_gpu * 2**30 / (args.chunk_mib << 20))))
+    nchunks = max(world, int(round(args.gib_per_gpu * 2**30 / (args.chunk_mib << 20))))
     plan = chunk_plan(args, rank, nchunks)
     import corpus
     off, ln, cap = corpus.chunk_table(tbytes[plan])
@@ -183,12 +377,21 @@ def main():
     ctx = xsg.Context(dev_index)
     ctx.set_pattern(pattern)
     shard = xsg.Shard(ctx, shard_t.data_ptr(), cap, chunks)
+    # strong form: the same --gib-per-gpu GiB IN TOTAL, i.e. the first 1/world of this rank's chunks
+    n_strong = max(1, nchunks // world)
+    shard_strong = shard if world == 1 else xsg.Shard(ctx, shard_t.data_ptr(), cap, chunks[:n_strong])
+    strong_bytes = int(ln[:n_strong].sum())
+    expected_strong_local = int(tcount[plan[:n_strong]].sum())
     counters = torch.zeros((2, xsg.NUM_COUNTERS), dtype=torch.int64, device=dev)  # double-buffered, see step()
     # a dedicated stream: a NULL handle would mean "the ctx's own stream" to xsg_count_async
     torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
+    # the wave stagger of the bulk kernel: measured on this shard (a few launches), not a constant
+    stagger = None if args.no_tune else shard.tune(xsg.COUNT_MATCHES)
+    stagger_strong = stagger if (world == 1 or args.no_tune) else shard_strong.tune(xsg.COUNT_MATCHES)
+    kernel_name = shard.scan_kernel_name(xsg.COUNT_MATCHES)
     setup_s = time.perf_counter() - t_setup
 
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -202,12 +405,15 @@ def main():
             dist.all_reduce(h) if op is None else dist.all_reduce(h, op=op)
             t.copy_(h)
 
-    if dist is not None:
-        exp = torch.tensor([expected_local], dtype=torch.int64, device=dev)
-        all_reduce_(exp)
-        expected_total = int(exp.item())
-    else:
-        expected_total = expected_local
+    def reduce_int(v):
+        if dist is None:
+            return int(v)
+        x = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        all_reduce_(x)
+        return int(x.item())
+
+    expected_total = reduce_int(expected_local)
+    expected_strong = reduce_int(expected_strong_local)
 
     # N>1: the 32-byte all_reduce of step i runs on its own stream while the scan of step i+1 already
     # reads HBM (two counter buffers; events order scan -> all_reduce -> reuse of the buffer).
@@ -215,70 +421,114 @@ def main():
     scan_done = [torch.cuda.Event(), torch.cuda.Event()]
     coll_done = [torch.cuda.Event(), torch.cuda.Event()]
 
-    def step(i, results=None):
-        b = i & 1
-        c = counters[b]
-        if dist is None:
-            shard.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
-            if results is not None:
-                results[i] = c[xsg.CTR_MATCHES]
-            return
-        stream.wait_event(coll_done[b])  # the all_reduce that used this buffer two steps ago
-        shard.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
-        scan_done[b].record(stream)
-        with torch.cuda.stream(coll_stream):
-            coll_stream.wait_event(scan_done[b])
-            all_reduce_(c)  # RCCL sum of the 4 uint64 counters
-            if results is not None:
-                results[i] = c[xsg.CTR_MATCHES]
-            coll_done[b].record(coll_stream)
-
     def sync_all():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    sync_all()
-    got = int(counters[(args.warmup - 1) & 1][xsg.CTR_MATCHES].item()) if args.warmup else expected_total
-    if got != expected_total:
-        raise SystemExit(f"PARITY FAILURE before timing: count {got} != expected {expected_total}")
+    def measure(sh, expected, steps, warmup):
+        """W untimed + exactly K timed steps on shard `sh`; -> seconds of the K steps (max over ranks)"""
+        def step(i, results=None):
+            b = i & 1
+            c = counters[b]
+            if dist is None:
+                sh.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
+                if results is not None:
+                    results[i] = c[xsg.CTR_MATCHES]
+                return
+            stream.wait_event(coll_done[b])  # the all_reduce that used this buffer two steps ago
+            sh.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
+            scan_done[b].record(stream)
+            with torch.cuda.stream(coll_stream):
+                coll_stream.wait_event(scan_done[b])
+                all_reduce_(c)  # RCCL sum of the 4 uint64 counters
+                if results is not None:
+                    results[i] = c[xsg.CTR_MATCHES]
+                coll_done[b].record(coll_stream)
 
-    results = torch.zeros(args.steps, dtype=torch.int64, device=dev)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, results)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        all_reduce_(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
-    bad = [int(x) for x in results.cpu().tolist() if int(x) != expected_total]
-    if bad:
-        raise SystemExit(f"PARITY FAILURE in timed steps: {bad[:4]} != expected {expected_total}")
+        for i in range(warmup):
+            step(i)
+        sync_all()
+        if warmup:
+            got = int(counters[(warmup - 1) & 1][xsg.CTR_MATCHES].item())
+            if got != expected:
+                raise SystemExit(f"PARITY FAILURE before timing: count {got} != expected {expected}")
+        results = torch.zeros(steps, dtype=torch.int64, device=dev)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, results)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            all_reduce_(el, op=dist.ReduceOp.MAX)
+            elapsed = float(el.item())
+        bad = [int(x) for x in results.cpu().tolist() if int(x) != expected]
+        if bad:
+            raise SystemExit(f"PARITY FAILURE in timed steps: {bad[:4]} != expected {expected}")
+        return elapsed
 
+    elapsed = measure(shard, expected_total, args.steps, args.warmup)
     total_bytes = shard_bytes * world
     gibs = total_bytes * args.steps / elapsed / 2**30
     ms_per_step = elapsed / args.steps * 1e3
 
+    if world == 1:
+        elapsed_s, strong_total = elapsed, total_bytes
+    else:
+        elapsed_s = measure(shard_strong, expected_strong, args.steps, args.warmup)
+        sb = torch.tensor([strong_bytes], dtype=torch.int64, device=dev)
+        all_reduce_(sb)
+        strong_total = int(sb.item())
+    strong = {
+        "value": round(strong_total * args.steps / elapsed_s / 2**30, 2),
+        "unit": "GiB/s",
+        "ms_per_step": round(elapsed_s / args.steps * 1e3, 4),
+        "total_gib": round(strong_total / 2**30, 3),
+        "chunks_per_gpu": n_strong,
+        "bytes_per_gpu": strong_bytes,
+        "ideal_ms_at_kernel_rate": None,  # filled below
+        "stagger": stagger_strong,
+        "what": f"{args.gib_per_gpu:g} GiB in total over {world} GPU(s) (SURVEY 8d config 3), same step, same checks",
+    }
+
+    # ---- the collective alone: latency of one all_reduce of the 4 counters (N > 1)
+    allreduce_us = None
+    if dist is not None:
+        c = counters[0]
+        for _ in range(5):
+            all_reduce_(c)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            all_reduce_(c)
+        torch.cuda.synchronize()
+        allreduce_us = (time.perf_counter() - t0) / 50 * 1e6
+
     # ---- roofline of the dominant kernel (k_scan), HIP events on the stream it runs on
     kernel_ms = shard.time_scan_kernel(xsg.COUNT_MATCHES, args.kernel_iters)
     achieved = shard_bytes / (kernel_ms * 1e-3) / 1e9  # algorithmic bytes: 1 byte read per input byte
-    traffic = None
-    tfile = ROOT / "profiles" / "pmc_traffic.json"
-    if tfile.exists():
+    strong["ideal_ms_at_kernel_rate"] = round(strong_bytes / (achieved * 1e9) * 1e3, 4)
+    traffic, traffic_source = None, None
+    for tfile in sorted((ROOT / "profiles").glob("*pmc_traffic*.json"), reverse=True):
         try:
             tj = json.loads(tfile.read_text())
-            if tj.get("bytes_per_gpu") == shard_bytes:
-                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            continue
+        # only a record of THIS workload and kernel instantiation counts (same bytes, same pattern, same variant)
+        if (tj.get("bytes_per_gpu") == shard_bytes and tj.get("pattern", "Sherlock") == args.pattern
+                and str(tj.get("kernel", "")).split(" stagger")[0] == kernel_name.split(" stagger")[0]):
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/{tfile.name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command " \
+                             f"(separate runs; not measured in this run)"
+            break
 
-    line = None
+    e2e = None
+    if args.e2e_gib > 0:
+        e2e = e2e_leg(args, blocks, pattern, tcount, rank, world, dist, dev_index)
+
     if rank == 0:
         line = {
             "metric": "GiB/s scanned, xs::count literal on plain text resident in HBM",
@@ -308,18 +558,26 @@ def main():
                             "single GPU",
                 "setup_s": round(setup_s, 1),
             },
+            "strong": strong,
+            "rccl_ranks": (world if (dist is not None and backend == "nccl") else 0),
+            "collective_backend": (backend if dist is not None else None),
+            "allreduce_us": None if allreduce_us is None else round(allreduce_us, 1),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "xsg::k_scan<3, false, false, false, 4, false>",  # KIND kTwo, no NL/LINES/EMIT, 4 loads, no icase
+                "kernel": kernel_name,  # from the library: the instantiation this pattern and mode launch
+                "stagger": stagger,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": shard_bytes,
             },
         }
+        if e2e is not None:
+            line["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, blocks, pattern)
         print(json.dumps(line), flush=True)

@@ -172,6 +172,11 @@ int xsg_count_async(xsg_shard* shard, uint32_t mode, void* stream, uint64_t* d_c
  * (| XSG_WITH_NEWLINES): result in host memory. */
 int xsg_count(xsg_shard* shard, uint32_t mode, uint64_t counters[XSG_NUM_COUNTERS]);
 
+/* Split-phase form of xsg_count for host pipelines: _begin enqueues the pass on the ctx's stream and returns,
+ * _end blocks until it is done and hands out the counters.  One pass in flight per shard. */
+int xsg_count_begin(xsg_shard* shard, uint32_t mode);
+int xsg_count_end(xsg_shard* shard, uint64_t counters[XSG_NUM_COUNTERS]);
+
 /* ---- list results (replace byte_offsets_match/_line, line; :136-154,187-207) */
 /* Runs the search for one of the list modes on the ctx stream and waits.
  * *n_results = number of elements (offsets / indices / lines).  Results stay
@@ -320,6 +325,13 @@ int xsg_ctx_info(xsg_ctx* ctx, char* arch, size_t arch_cap, int* compute_units, 
  * mode `iters` times back to back on the ctx stream between two HIP events and
  * returns the average milliseconds per launch (bench.py's roofline figure). */
 int xsg_time_scan_kernel(xsg_shard* shard, uint32_t mode, int iters, float* avg_ms);
+/* Name of the bulk-kernel instantiation the next pass of `mode` launches on this shard with the current pattern
+ * ("xsg::k_scan<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE> stagger=N"): what a profile of that pass shows. */
+int xsg_scan_kernel_name(xsg_shard* shard, uint32_t mode, char* out, size_t cap);
+/* Measure and fix the bulk kernel's wave stagger for this shard, the current pattern and `mode` (a handful of
+ * launches; replaces the per-variant default until the shard is destroyed or tuned again).  *chosen (optional)
+ * receives the value, or UINT32_MAX when the default was kept (shard under 1 GiB, or XSG_TUNE set). */
+int xsg_shard_tune(xsg_shard* shard, uint32_t mode, uint32_t* chosen);
 /* Diagnostic: a kernel with k_scan's load shape and no work on the bytes, over the
  * shard's span -- the empirical HBM read ceiling for this access pattern. */
 int xsg_time_read_ceiling(xsg_shard* shard, int iters, float* avg_ms, uint64_t* bytes_per_launch);

@@ -409,6 +409,176 @@ uint64_t xso_count_chunks_mt(const char* base, const uint64_t* offsets, const ui
 }
 
 /* ------------------------------------------------------------------------ */
+/* Persistent worker pool: the same worker loop (Searcher.h:100-120), with    */
+/* threads that live across passes the way the reference's Searcher threads   */
+/* live for a whole search (Searcher.h:141-145) -- a timed pass pays no       */
+/* pthread_create/join.  The corpus is allocated and FIRST-TOUCHED by the     */
+/* workers (pages land on the NUMA node of the thread that writes them, spread */
+/* over all nodes the pool runs on).  Timing is taken inside, around the       */
+/* passes only.                                                                */
+/* ------------------------------------------------------------------------ */
+#include <sched.h>
+#include <sys/mman.h>
+#include <time.h>
+
+struct xso_pool {
+  int nthreads;
+  pthread_t* th;
+  pthread_mutex_t mu;
+  pthread_cond_t cv_go, cv_done;
+  uint64_t generation; /* bumped per dispatched job */
+  int running;         /* workers still inside the current job */
+  int quit;
+  /* the current job */
+  int kind; /* 0 = count, 1 = replicate */
+  mt_job job;
+  char* dst_base;
+  const uint64_t* src_idx;
+  const char* const* src_ptr;
+};
+
+static void pool_run_item(xso_pool* p, uint64_t* local) {
+  mt_job* job = &p->job;
+  for (;;) {
+    const uint64_t i = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
+    if (i >= job->n) break;
+    if (p->kind == 1) {
+      memcpy(p->dst_base + job->offsets[i], p->src_ptr[p->src_idx[i]], job->lengths[i]);
+    } else {
+      const uint64_t c = xso_count(job->base + job->offsets[i], job->lengths[i], job->pat, job->plen, job->skip_to_nl);
+      if (job->counts_out) job->counts_out[i] = c;
+      *local += c;
+    }
+  }
+}
+
+static void* pool_worker(void* arg) {
+  xso_pool* p = (xso_pool*)arg;
+  uint64_t seen = 0;
+  for (;;) {
+    pthread_mutex_lock(&p->mu);
+    while (!p->quit && p->generation == seen) pthread_cond_wait(&p->cv_go, &p->mu);
+    if (p->quit) {
+      pthread_mutex_unlock(&p->mu);
+      return NULL;
+    }
+    seen = p->generation;
+    pthread_mutex_unlock(&p->mu);
+    uint64_t local = 0;
+    pool_run_item(p, &local);
+    pthread_mutex_lock(&p->mu);
+    p->job.total += local;
+    if (--p->running == 0) pthread_cond_signal(&p->cv_done);
+    pthread_mutex_unlock(&p->mu);
+  }
+}
+
+static void pool_dispatch(xso_pool* p) {
+  pthread_mutex_lock(&p->mu);
+  p->job.next = 0;
+  p->job.total = 0;
+  p->running = p->nthreads;
+  ++p->generation;
+  pthread_cond_broadcast(&p->cv_go);
+  while (p->running) pthread_cond_wait(&p->cv_done, &p->mu);
+  pthread_mutex_unlock(&p->mu);
+}
+
+xso_pool* xso_pool_create(int nthreads, int pin) {
+  if (nthreads < 1) nthreads = 1;
+  xso_pool* p = (xso_pool*)calloc(1, sizeof *p);
+  if (!p) return NULL;
+  p->nthreads = nthreads;
+  p->th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+  pthread_mutex_init(&p->mu, NULL);
+  pthread_cond_init(&p->cv_go, NULL);
+  pthread_cond_init(&p->cv_done, NULL);
+  cpu_set_t allowed;
+  int ncpu = 0, cpus[4096];
+  if (pin && sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+    for (int c = 0; c < CPU_SETSIZE && ncpu < 4096; ++c)
+      if (CPU_ISSET(c, &allowed)) cpus[ncpu++] = c;
+  for (int t = 0; t < nthreads; ++t) {
+    pthread_create(&p->th[t], NULL, pool_worker, p);
+    if (pin && ncpu) { /* spread over the allowed CPUs: thread t -> every (ncpu/nthreads)-th CPU */
+      cpu_set_t one;
+      CPU_ZERO(&one);
+      CPU_SET(cpus[(int)(((long long)t * ncpu) / nthreads) % ncpu], &one);
+      pthread_setaffinity_np(p->th[t], sizeof one, &one);
+    }
+  }
+  return p;
+}
+
+void xso_pool_destroy(xso_pool* p) {
+  if (!p) return;
+  pthread_mutex_lock(&p->mu);
+  p->quit = 1;
+  pthread_cond_broadcast(&p->cv_go);
+  pthread_mutex_unlock(&p->mu);
+  for (int t = 0; t < p->nthreads; ++t) pthread_join(p->th[t], NULL);
+  pthread_mutex_destroy(&p->mu);
+  pthread_cond_destroy(&p->cv_go);
+  pthread_cond_destroy(&p->cv_done);
+  free(p->th);
+  free(p);
+}
+
+/* untouched anonymous memory (no page is resident until a worker writes it) */
+char* xso_corpus_alloc(uint64_t bytes) {
+  void* m = mmap(NULL, bytes ? bytes : 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (m == MAP_FAILED) return NULL;
+  madvise(m, bytes, MADV_HUGEPAGE);
+  return (char*)m;
+}
+void xso_corpus_free(char* p, uint64_t bytes) {
+  if (p) munmap(p, bytes ? bytes : 1);
+}
+
+/* chunk i of the corpus := template src_idx[i] (lengths[i] bytes), written by the pool's workers */
+void xso_pool_replicate(xso_pool* p, char* dst_base, const uint64_t* offsets, const uint64_t* lengths, uint64_t n,
+                        const uint64_t* src_idx, const char* const* src_ptr) {
+  memset(&p->job, 0, sizeof p->job);
+  p->kind = 1;
+  p->job.offsets = offsets;
+  p->job.lengths = lengths;
+  p->job.n = n;
+  p->dst_base = dst_base;
+  p->src_idx = src_idx;
+  p->src_ptr = src_ptr;
+  pool_dispatch(p);
+}
+
+/* `passes` passes of count() over all chunks; returns the total of ONE pass (every pass must agree, else
+ * UINT64_MAX) and the wall seconds of all passes in *seconds. */
+uint64_t xso_pool_count_chunks(xso_pool* p, const char* base, const uint64_t* offsets, const uint64_t* lengths,
+                               uint64_t n, const char* pat, size_t plen, int skip_to_nl, int passes,
+                               uint64_t* counts_out, double* seconds) {
+  memset(&p->job, 0, sizeof p->job);
+  p->kind = 0;
+  p->job.base = base;
+  p->job.offsets = offsets;
+  p->job.lengths = lengths;
+  p->job.n = n;
+  p->job.pat = pat;
+  p->job.plen = plen;
+  p->job.skip_to_nl = skip_to_nl;
+  p->job.counts_out = counts_out;
+  uint64_t want = 0;
+  int bad = 0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int k = 0; k < passes; ++k) {
+    pool_dispatch(p);
+    if (k == 0) want = p->job.total;
+    else if (p->job.total != want) bad = 1;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return bad ? UINT64_MAX : want;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Regex wrappers for fixed-length class sequences                           */
 /* (include/xsearch/string_search/search_wrappers.h:63-103, 209-271).        */
 /*                                                                           */

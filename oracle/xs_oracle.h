@@ -113,6 +113,21 @@ void xso_to_lower(char* buf, size_t len);
 uint64_t xso_count_chunks_mt(const char* base, const uint64_t* offsets, const uint64_t* lengths, uint64_t n,
                              const char* pat, size_t plen, int skip_to_nl, int nthreads, uint64_t* counts_out);
 
+/* The same worker loop on a persistent pool (threads live across passes, like the reference's Searcher
+ * threads live for a whole search, Searcher.h:141-145); pin != 0 spreads the threads over the allowed CPUs.
+ * bench.py's cpu_baseline leg: corpus allocated untouched (xso_corpus_alloc), first-touched by the workers
+ * (xso_pool_replicate), timed inside xso_pool_count_chunks. */
+typedef struct xso_pool xso_pool;
+xso_pool* xso_pool_create(int nthreads, int pin);
+void xso_pool_destroy(xso_pool* p);
+char* xso_corpus_alloc(uint64_t bytes);
+void xso_corpus_free(char* p, uint64_t bytes);
+void xso_pool_replicate(xso_pool* p, char* dst_base, const uint64_t* offsets, const uint64_t* lengths, uint64_t n,
+                        const uint64_t* src_idx, const char* const* src_ptr);
+uint64_t xso_pool_count_chunks(xso_pool* p, const char* base, const uint64_t* offsets, const uint64_t* lengths,
+                               uint64_t n, const char* pat, size_t plen, int skip_to_nl, int passes,
+                               uint64_t* counts_out, double* seconds);
+
 #ifdef __cplusplus
 }
 #endif

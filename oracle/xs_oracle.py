@@ -281,6 +281,15 @@ class Oracle:
             getattr(lib, name).restype = u64
         lib.xso_count_chunks_mt.argtypes = [vp, _u64p, _u64p, u64, cp, sz, ci, ci, _u64p]
         lib.xso_count_chunks_mt.restype = u64
+        lib.xso_pool_create.argtypes = [ci, ci]
+        lib.xso_pool_create.restype = vp
+        lib.xso_pool_destroy.argtypes = [vp]
+        lib.xso_corpus_alloc.argtypes = [u64]
+        lib.xso_corpus_alloc.restype = vp
+        lib.xso_corpus_free.argtypes = [vp, u64]
+        lib.xso_pool_replicate.argtypes = [vp, vp, _u64p, _u64p, u64, _u64p, C.POINTER(vp)]
+        lib.xso_pool_count_chunks.argtypes = [vp, vp, _u64p, _u64p, u64, cp, sz, ci, ci, _u64p, C.POINTER(C.c_double)]
+        lib.xso_pool_count_chunks.restype = u64
 
     # -- configuration ------------------------------------------------------
     def set_exact(self, exact: bool) -> None:
@@ -411,6 +420,60 @@ class Oracle:
         tot = self.lib.xso_count_chunks_mt(b.addr, off.ctypes.data_as(_u64p), ln.ctypes.data_as(_u64p), len(off), p,
                                            len(p), 1 if skip_to_nl else 0, int(nthreads), per.ctypes.data_as(_u64p))
         return int(tot), per
+
+
+class CpuPoolCorpus:
+    """bench.py's cpu_baseline leg: `nchunks` chunks replicated from template blocks into untouched anonymous
+    memory by the pool's own workers (first touch), searched by persistent worker threads
+    (xs_oracle.c: xso_pool_*; the worker loop of include/xsearch/Searcher.h:100-120)."""
+
+    def __init__(self, oracle: "Oracle", blocks, plan, nthreads_touch: int):
+        self.o = oracle
+        lib = oracle.lib
+        self.blocks = [np.ascontiguousarray(b) for b in blocks]
+        lens = np.array([self.blocks[int(t)].size for t in plan], dtype=np.uint64)
+        padded = (lens + np.uint64(4095)) // np.uint64(4096) * np.uint64(4096)
+        self.off = np.concatenate([[np.uint64(0)], np.cumsum(padded)[:-1]]).astype(np.uint64)
+        self.len = lens
+        self.cap = int(padded.sum())
+        self.n = len(lens)
+        self.base = lib.xso_corpus_alloc(self.cap)
+        if not self.base:
+            raise MemoryError(f"cannot map {self.cap} bytes")
+        src_idx = np.ascontiguousarray(plan, dtype=np.uint64)
+        ptrs = (C.c_void_p * len(self.blocks))(*[b.ctypes.data for b in self.blocks])
+        pool = lib.xso_pool_create(int(nthreads_touch), 1)
+        lib.xso_pool_replicate(pool, self.base, self.off.ctypes.data_as(_u64p), self.len.ctypes.data_as(_u64p), self.n,
+                               src_idx.ctypes.data_as(_u64p), ptrs)
+        lib.xso_pool_destroy(pool)
+
+    def count(self, pat: bytes, nthreads: int, passes: int, first_chunks: int | None = None, skip_to_nl=False):
+        """-> (total of one pass, seconds for all passes, bytes per pass)"""
+        lib = self.o.lib
+        n = self.n if first_chunks is None else min(self.n, int(first_chunks))
+        pool = lib.xso_pool_create(int(nthreads), 1)
+        sec = C.c_double(0)
+        p = _as_bytes(pat)
+        # one untimed pass first: thread start-up and page-table warm-up are not the search
+        lib.xso_pool_count_chunks(pool, self.base, self.off.ctypes.data_as(_u64p), self.len.ctypes.data_as(_u64p), n, p,
+                                  len(p), 1 if skip_to_nl else 0, 1, None, C.byref(sec))
+        tot = lib.xso_pool_count_chunks(pool, self.base, self.off.ctypes.data_as(_u64p), self.len.ctypes.data_as(_u64p),
+                                        n, p, len(p), 1 if skip_to_nl else 0, int(passes), None, C.byref(sec))
+        lib.xso_pool_destroy(pool)
+        if tot == (1 << 64) - 1:
+            raise RuntimeError("CPU passes disagree")
+        return int(tot), float(sec.value), int(self.len[:n].sum())
+
+    def close(self):
+        if self.base:
+            self.o.lib.xso_corpus_free(self.base, self.cap)
+            self.base = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Reference:

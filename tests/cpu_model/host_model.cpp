@@ -190,4 +190,101 @@ uint64_t hm_check_lane_combine(uint64_t seed, uint64_t iters) {
   return bad;
 }
 
+// xsg::tail_walk_masks (k_count_finish: one wave per chunk decides the zone's positions in parallel, the walk then
+// runs on bit masks) against xsg::tail_walk on random chunks / patterns / entry points.  Returns #mismatches.
+uint64_t hm_check_tail_masks(uint64_t seed, uint64_t iters) {
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + 7, bad = 0;
+  auto rnd = [&]() {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    return x;
+  };
+  std::vector<uint8_t> d, p;
+  for (uint64_t it = 0; it < iters; ++it) {
+    const uint32_t plen = 2 + (uint32_t)(rnd() % (kTailMaskMaxPlen - 1));  // 2..33
+    const uint64_t L = rnd() % 4 == 0 ? rnd() % (plen + 40) : plen + rnd() % 200;
+    const int alpha = 2 + (int)(rnd() % 2);
+    const bool icase = rnd() % 4 == 0;
+    d.assign(L + 1, 0);
+    p.assign(plen, 0);
+    for (uint64_t i = 0; i < L; ++i) {
+      const uint64_t r = rnd() % 16;
+      d[i] = r == 0 ? '\n' : (uint8_t)((icase && (r & 1) ? 'A' : 'a') + (int)(rnd() % (uint64_t)alpha));
+    }
+    // a pattern taken from the text (so that partial and full matches happen), sometimes periodic
+    if (L >= plen && rnd() % 3 != 0) {
+      const uint64_t at = rnd() % (L - plen + 1);
+      for (uint32_t k = 0; k < plen; ++k) p[k] = d[at + k] == '\n' ? 'a' : fold(d[at + k], true);
+    } else {
+      for (uint32_t k = 0; k < plen; ++k) p[k] = (uint8_t)('a' + (int)((k % (1 + rnd() % 3)) % (uint64_t)alpha));
+    }
+    if (!icase)
+      for (uint32_t k = 0; k < plen; ++k) p[k] = p[k];
+    const uint64_t Z = tail_zone_begin(L, plen);
+    const uint32_t n = (uint32_t)(L - Z);
+    uint32_t K[64] = {0};
+    uint64_t full = 0, nz = 0, nlm = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint64_t o = Z + i;
+      uint32_t k = 0;
+      if (L - o >= plen)
+        while (k < plen && fold(d[o + k], icase) == p[k]) ++k;
+      K[i] = k;
+      if (k == plen) full |= 1ull << i;
+      if (k) nz |= 1ull << i;
+      if (d[o] == '\n') nlm |= 1ull << i;
+    }
+    for (int rep = 0; rep < 4; ++rep) {
+      const bool skip = rnd() & 1;
+      uint64_t shift0 = rnd() % 5 == 0 ? 0 : rnd() % (L + 2);
+      if (rep == 3) shift0 = UINT64_MAX;
+      const uint32_t want = tail_walk(d.data(), L, p.data(), plen, shift0, skip, nullptr, 0, icase);
+      const uint32_t got = tail_walk_masks(L, plen, shift0, skip, full, nz, nlm, [&](uint32_t j) { return K[j]; });
+      bad += want != got;
+    }
+  }
+  return bad;
+}
+
+// sum_combine_lanes on summaries of whole SPANS (k_count_finish combines 64 per-wave tile summaries at a time):
+// closed-segment counts far above a unit's 7.
+uint64_t hm_check_span_combine(uint64_t seed, uint64_t iters) {
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + 3, bad = 0;
+  auto rnd = [&]() {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    return x;
+  };
+  for (uint64_t it = 0; it < iters; ++it) {
+    uint32_t sp[64];
+    for (int l = 0; l < 64; ++l) {
+      // a span = a few random units combined (a valid summary by construction)
+      const int nu = (int)(rnd() % 6);
+      uint32_t s = 0;  // identity
+      for (int u = 0; u < nu; ++u) {
+        uint32_t h = 0, n = 0;
+        for (int b = 0; b < 16; ++b) {
+          const int r = (int)(rnd() % 6);
+          if (r == 0) n |= 1u << b;
+          else if (r == 1) h |= 1u << b;
+        }
+        if (it % 5 == 0) h = 0;
+        s = u ? sum_combine(s, sum_of_unit(h, n)) : sum_of_unit(h, n);
+      }
+      if (nu == 0 && (rnd() & 1)) s = kSumNl;  // "has a newline, no match": the preset of an untouched wave span
+      sp[l] = s;
+    }
+    uint32_t ref = sp[0];
+    for (int l = 1; l < 64; ++l) ref = sum_combine(ref, sp[l]);
+    unsigned long long N = 0, Fm = 0, Lm = 0;
+    uint32_t csum = 0;
+    for (int l = 0; l < 64; ++l) {
+      if (sp[l] & kSumNl) N |= 1ull << l;
+      if (sp[l] & kSumF) Fm |= 1ull << l;
+      if (sp[l] & kSumL) Lm |= 1ull << l;
+      csum += sp[l] >> kSumCShift;
+    }
+    bad += sum_combine_lanes(N, Fm, Lm, csum) != ref;
+  }
+  return bad;
+}
+
 }  // extern "C"

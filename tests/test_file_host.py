@@ -107,6 +107,40 @@ def test_meta_read_rejects_garbage(tmp_path):
         xsg.meta_read(str(bad))
 
 
+def _meta_bytes(ctype, records):
+    """records: (original_offset, actual_offset, original_size, actual_size) -- no mapping entries"""
+    import struct
+    out = struct.pack("<i", ctype)
+    for r in records:
+        out += struct.pack("<5Q", *r, 0)
+    return out
+
+
+@pytest.mark.parametrize("name,ctype,records,data_len", [
+    # uncompressed file whose record asks for far more bytes than the chunk it declares (heap overflow of the
+    # pinned buffer if trusted: the buffer is sized from original_size, the read from actual_size)
+    ("actual_ne_original", 1, [(0, 0, 16, 1 << 20)], 1 << 21),
+    # actual_offset + actual_size wraps around 2^64
+    ("offset_wraps", 1, [(0, (1 << 64) - 8, 16, 16)], 4096),
+    # sizes near 2^64: the rounded-up buffer size would wrap to a few hundred bytes
+    ("size_wraps", 1, [(0, 0, (1 << 64) - 10, (1 << 64) - 10)], 4096),
+    ("lz4_block_over_int32", 3, [(0, 0, 1 << 33, 64)], 4096),
+    ("beyond_eof", 2, [(0, 4000, 100, 200)], 4096),
+    ("compressed_chunk_without_bytes", 3, [(0, 0, 100, 0)], 4096),
+])
+def test_job_start_refuses_a_malformed_metafile(tmp_path, name, ctype, records, data_len):
+    """Every metafile record is validated before a buffer is sized from it or a byte is read through it
+    (x-search_amd/csrc/xsg_file.cpp, job_start_impl); the file checks run before the device check, so this holds
+    on a host without a GPU too."""
+    data = tmp_path / f"{name}.txt"
+    data.write_bytes(b"a line of text\n" * (data_len // 15 + 1))
+    meta = tmp_path / f"{name}.meta"
+    meta.write_bytes(_meta_bytes(ctype, records))
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.Job(b"text", str(data), xsg.COUNT_MATCHES, meta_path=str(meta))
+    assert e.value.code == xsg.EIO, str(e.value)
+
+
 def _summary(path):
     ctype, chunks, maps = xsg.meta_read(str(path), True)
     return {

@@ -35,6 +35,9 @@ def hm():
     lib.hm_set_icase.argtypes = [ci]
     lib.hm_check_lane_combine.argtypes = [u64, u64]
     lib.hm_check_lane_combine.restype = u64
+    for name in ("hm_check_tail_masks", "hm_check_span_combine"):
+        getattr(lib, name).argtypes = [u64, u64]
+        getattr(lib, name).restype = u64
     return lib
 
 
@@ -155,3 +158,17 @@ def test_lane_mask_combine_equals_ordered_reduction(hm):
     == the ordered 64-way sum_combine of the same unit summaries."""
     assert hm.hm_check_lane_combine(1, 300000) == 0
     assert hm.hm_check_lane_combine(99, 300000) == 0
+
+
+def test_span_summaries_combine_by_lane_masks(hm):
+    """k_count_finish combines 64 per-wave tile summaries at a time with the same mask algebra: it must also hold
+    for summaries of whole spans (closed-segment counts beyond a unit's 7, identity and preset entries)."""
+    assert hm.hm_check_span_combine(5, 200000) == 0
+    assert hm.hm_check_span_combine(77, 200000) == 0
+
+
+def test_tail_walk_on_masks_equals_the_sequential_walk(hm):
+    """xsg::tail_walk_masks (the zone's positions decided in parallel, the walk on bit masks: what a wave of
+    k_count_finish runs) == xsg::tail_walk (byte by byte; itself checked against the oracle above)."""
+    assert hm.hm_check_tail_masks(3, 400000) == 0
+    assert hm.hm_check_tail_masks(1234, 400000) == 0

@@ -341,27 +341,48 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   s->last_mode = -1;
   s->total = 0;
 
+  // whatever was derived from the old binding's bytes is void
+  s->nl_cached = s->nl_off_cached = false;
+  bool grew = false;
   XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
   XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
-  XSG_TRY(s->d_tile_last.ensure(4 * std::max<uint64_t>(ntiles, 1)));  // tile_last
-  XSG_TRY(s->d_tile_cnt.ensure(4 * std::max<uint64_t>(ntiles, 1)));
+  XSG_TRY(s->d_tile_last.ensure(4 * std::max<uint64_t>(ntiles, 1), &grew));
+  if (grew) s->last_valid = false;
+  grew = false;
+  XSG_TRY(s->d_tile_cnt.ensure(4 * std::max<uint64_t>(ntiles, 1), &grew));
+  if (grew) s->cnt_clean = false;
   XSG_TRY(s->d_counters.ensure(8 * XSG_NUM_COUNTERS));
+  grew = false;
+  XSG_TRY(s->d_finish.ensure(8 * 3 * (size_t)kFinishBlocks + 64, &grew));
+  if (grew) HIP_TRY(hipMemsetAsync(s->d_finish.p, 0, 8 * 3 * (size_t)kFinishBlocks + 64, c->stream));  // ticket = 0
+  if (!s->h_counters) HIP_TRY(hipHostMalloc((void**)&s->h_counters, 8 * XSG_NUM_COUNTERS, hipHostMallocDefault));
+  if (!s->table_ev) HIP_TRY(hipEventCreateWithFlags(&s->table_ev, hipEventDisableTiming));
   static_assert(sizeof(ChunkDev) == sizeof(xsg_chunk), "layout");
-  if (nchunks)
-    HIP_TRY(hipMemcpyAsync(s->d_chunks.p, s->chunks.data(), sizeof(xsg_chunk) * nchunks, hipMemcpyHostToDevice,
-                           c->stream));
+  if (nchunks <= 1) {
+    // The file pipeline re-binds its one-chunk shard for every chunk it feeds: the 48 bytes of table go through
+    // a pinned staging block and no host sync.  The block is reused only after the previous upload has run.
+    if (!s->h_stage) HIP_TRY(hipHostMalloc(&s->h_stage, 64, hipHostMallocDefault));
+    if (s->table_pending) HIP_TRY(hipEventSynchronize(s->table_ev));
+    uint8_t* st = static_cast<uint8_t*>(s->h_stage);
+    if (nchunks) memcpy(st, s->chunks.data(), sizeof(xsg_chunk));
+    memcpy(st + 32, s->chunk_tile0.data(), 8 * (nchunks + 1));
+    if (nchunks) HIP_TRY(hipMemcpyAsync(s->d_chunks.p, st, sizeof(xsg_chunk), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_chunk_tile0.p, st + 32, 8 * (nchunks + 1), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(s->table_ev, c->stream));
+    s->table_pending = true;
+    return XSG_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_chunks.p, s->chunks.data(), sizeof(xsg_chunk) * nchunks, hipMemcpyHostToDevice,
+                         c->stream));
   HIP_TRY(hipMemcpyAsync(s->d_chunk_tile0.p, s->chunk_tile0.data(), 8 * (nchunks + 1), hipMemcpyHostToDevice,
                          c->stream));
-  if (nchunks > 1) {
-    std::vector<uint32_t> map(ntiles);
-    for (uint64_t i = 0; i < nchunks; ++i)
-      for (uint64_t t = s->chunk_tile0[i]; t < s->chunk_tile0[i + 1]; ++t) map[t] = (uint32_t)i;
-    XSG_TRY(s->d_tile_chunk.ensure(4 * std::max<uint64_t>(ntiles, 1)));
-    if (ntiles) HIP_TRY(hipMemcpyAsync(s->d_tile_chunk.p, map.data(), 4 * ntiles, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `map` is a local
-  } else {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-  }
+  std::vector<uint32_t> map(ntiles);
+  for (uint64_t i = 0; i < nchunks; ++i)
+    for (uint64_t t = s->chunk_tile0[i]; t < s->chunk_tile0[i + 1]; ++t) map[t] = (uint32_t)i;
+  XSG_TRY(s->d_tile_chunk.ensure(4 * std::max<uint64_t>(ntiles, 1)));
+  if (ntiles) HIP_TRY(hipMemcpyAsync(s->d_tile_chunk.p, map.data(), 4 * ntiles, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // `map` is a local
+  s->table_pending = false;
   return XSG_OK;
 }
 
@@ -414,7 +435,8 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.chunk_tile0 = s->d_chunk_tile0.as<uint64_t>();
   a.ntiles = s->ntiles;
   a.tile_bytes = s->tile_bytes;
-  a.tune = s->ctx->tune;
+  a.tune = s->ctx->tune != kTuneAuto ? s->ctx->tune : s->tune;  // XSG_TUNE, else xsg_shard_tune's choice, else per variant
+  a.epoch = s->epoch;
   a.pat = s->ctx->pat;
   a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
   a.tile_nl = s->d_tile_nl.as<uint32_t>();
@@ -429,27 +451,53 @@ static int check_ready(xsg_shard* s) {
   return XSG_OK;
 }
 
-// k_scan only writes where a wave found something: preset what "nothing found" looks like.
-static int preset_tile_arrays(xsg_shard* s, bool want_lines, hipStream_t st) {
-  const uint64_t nchunks = s->chunks.size();
-  (void)nchunks;
-  HIP_TRY(hipMemsetAsync(s->d_tile_last.p, 0, 4 * std::max<uint64_t>(s->ntiles, 1), st));  // tile_last
-  HIP_TRY(hipMemsetAsync(s->d_tile_cnt.p, 0, 4 * std::max<uint64_t>(s->ntiles, 1), st));
+// k_scan only writes where a wave found something: "nothing found" must be in place before it runs.  After a
+// count pass it already is (k_count_finish cleaned up behind itself): the steady state enqueues no memset at all.
+// Also opens a new epoch for tile_last, and orders a pending chunk-table upload before work on a foreign stream.
+static int prepare_tiles(xsg_shard* s, bool want_lines, hipStream_t st) {
+  xsg_ctx* c = s->ctx;
+  const uint64_t nt = std::max<uint64_t>(s->ntiles, 1);
+  if (s->table_pending && st != c->stream) HIP_TRY(hipStreamWaitEvent(st, s->table_ev, 0));
+  if (!s->cnt_clean) {
+    HIP_TRY(hipMemsetAsync(s->d_tile_cnt.p, 0, 4 * nt, st));
+    s->cnt_clean = true;
+  }
+  if (!s->last_valid || s->epoch >= 0xffffu) {
+    HIP_TRY(hipMemsetAsync(s->d_tile_last.p, 0, 4 * nt, st));
+    s->last_valid = true;
+    s->epoch = 0;
+  }
+  ++s->epoch;
   if (want_lines) {
-    XSG_TRY(s->d_tile_sum.ensure(4 * kWaves * std::max<uint64_t>(s->ntiles, 1)));
-    if (s->ntiles) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_tile_sum.p, (int)kSumNl, kWaves * s->ntiles, st));
+    bool grew = false;
+    XSG_TRY(s->d_tile_sum.ensure(4 * kWaves * nt, &grew));
+    if (grew) s->sum_clean = false;
+    if (!s->sum_clean) {
+      HIP_TRY(hipMemsetAsync(s->d_tile_sum.p, 0, 4 * kWaves * nt, st));
+      s->sum_clean = true;
+    }
   }
   return XSG_OK;
 }
 
+static int ensure_tile_nl(xsg_shard* s) {
+  bool grew = false;
+  XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(s->ntiles, 1), &grew));
+  if (grew) s->nl_cached = s->nl_off_cached = false;
+  return XSG_OK;
+}
+
 static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool want_nl, hipStream_t st,
-                         uint64_t* d_counters) {
-  if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
+                         uint64_t* d_counters, uint64_t* host_counters) {
+  if (want_nl) XSG_TRY(ensure_tile_nl(s));
   const uint64_t nchunks = s->chunks.size();
-  XSG_TRY(preset_tile_arrays(s, want_lines, st));
-  HIP_TRY(hipMemsetAsync(d_counters, 0, 8 * XSG_NUM_COUNTERS, st));
+  XSG_TRY(prepare_tiles(s, want_lines, st));
+  const bool scan_nl = want_nl && !s->nl_cached;  // the per-tile newline counts of this binding may already exist
   ScanArgs a = scan_args(s);
-  HIP_TRY(launch_scan_count(a, want_nl, want_lines, st));
+  // dirty until the finish kernel is in the queue behind the scan
+  s->cnt_clean = false;
+  if (want_lines) s->sum_clean = false;
+  HIP_TRY(launch_scan_count(a, scan_nl, want_lines, st));
   FinishArgs f{};
   f.base = s->base;
   f.chunks = a.chunks;
@@ -461,13 +509,20 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   f.tile_nl = a.tile_nl;
   f.tile_sum = a.tile_sum;
   f.tile_last = a.tile_last;
+  f.epoch = a.epoch;
   f.tile_bytes = s->tile_bytes;
   f.counters = d_counters;
+  f.host_counters = host_counters;
+  f.partials = s->d_finish.as<uint64_t>();
+  f.ticket = reinterpret_cast<uint32_t*>(s->d_finish.as<uint64_t>() + 3 * (size_t)kFinishBlocks);
   f.total_bytes = s->total_bytes;
   f.want_nl = want_nl;
   f.want_lines = want_lines;
   f.want_matches = want_matches;
   HIP_TRY(launch_count_finish(f, st));
+  s->cnt_clean = true;
+  if (want_lines) s->sum_clean = true;
+  if (scan_nl) s->nl_cached = true;
   return XSG_OK;
 }
 
@@ -483,11 +538,11 @@ extern "C" int xsg_count_async(xsg_shard* s, uint32_t mode, void* stream, uint64
   if (m == XSG_COUNT_MATCHES) {
     if (c->bordered)
       return fail(XSG_ENOTSUP, "pattern can overlap itself: the greedy non-overlap count needs xsg_count()");
-    return enqueue_count(s, true, false, want_nl, st, d_counters);
+    return enqueue_count(s, true, false, want_nl, st, d_counters, nullptr);
   }
   if (m == XSG_COUNT_LINES) {
     if (c->pat.has_newline) return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
-    return enqueue_count(s, false, true, want_nl, st, d_counters);
+    return enqueue_count(s, false, true, want_nl, st, d_counters, nullptr);
   }
   return fail(XSG_EINVAL, "xsg_count_async: mode %u is not a count mode", m);
 }
@@ -508,18 +563,62 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
     counters[XSG_CTR_MATCHES] = s->total;
     counters[XSG_CTR_BYTES] = s->total_bytes;
     if (mode & XSG_WITH_NEWLINES) {
-      uint64_t tmp[XSG_NUM_COUNTERS];
-      XSG_TRY(enqueue_count(s, false, false, true, c->stream, s->d_counters.as<uint64_t>()));
-      HIP_TRY(hipMemcpyAsync(tmp, s->d_counters.p, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
+      XSG_TRY(enqueue_count(s, false, false, true, c->stream, s->d_counters.as<uint64_t>(), s->h_counters));
       HIP_TRY(hipStreamSynchronize(c->stream));
-      counters[XSG_CTR_NEWLINES] = tmp[XSG_CTR_NEWLINES];
+      s->table_pending = false;
+      counters[XSG_CTR_NEWLINES] = s->h_counters[XSG_CTR_NEWLINES];
     }
     s->last_mode = -1;
     return XSG_OK;
   }
-  XSG_TRY(xsg_count_async(s, mode, c->stream, s->d_counters.as<uint64_t>()));
-  HIP_TRY(hipMemcpyAsync(counters, s->d_counters.p, 8 * XSG_NUM_COUNTERS, hipMemcpyDeviceToHost, c->stream));
+  const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
+  if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
+  if (m == XSG_COUNT_LINES && c->pat.has_newline)
+    return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+  // the finish kernel writes the four values straight into pinned host memory: no copy, one sync
+  XSG_TRY(enqueue_count(s, m == XSG_COUNT_MATCHES, m == XSG_COUNT_LINES, want_nl, c->stream,
+                        s->d_counters.as<uint64_t>(), s->h_counters));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  s->table_pending = false;
+  memcpy(counters, s->h_counters, 8 * XSG_NUM_COUNTERS);
+  return XSG_OK;
+}
+
+// Split-phase xsg_count for host pipelines: begin enqueues the pass on the ctx stream (results go to the shard's
+// pinned mirror), end waits for it.  Between the two the caller may enqueue work for other shards/contexts.
+extern "C" int xsg_count_begin(xsg_shard* s, uint32_t mode) {
+  XSG_TRY(check_ready(s));
+  const uint32_t m = mode & 0xffu;
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  if (m != XSG_COUNT_MATCHES && m != XSG_COUNT_LINES) return fail(XSG_EINVAL, "mode %u is not a count mode", m);
+  if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
+  s->begin_sync_result = false;
+  if (m == XSG_COUNT_MATCHES && c->bordered) {  // needs the ordered list: done synchronously, handed out by _end
+    XSG_TRY(xsg_count(s, mode, s->begin_counters));
+    s->begin_sync_result = true;
+    return XSG_OK;
+  }
+  if (m == XSG_COUNT_LINES && c->pat.has_newline)
+    return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+  XSG_TRY(enqueue_count(s, m == XSG_COUNT_MATCHES, m == XSG_COUNT_LINES, (mode & XSG_WITH_NEWLINES) != 0, c->stream,
+                        s->d_counters.as<uint64_t>(), s->h_counters));
+  HIP_TRY(hipEventRecord(s->table_ev, c->stream));  // doubles as "pass done": it covers the table upload too
+  s->table_pending = true;
+  return XSG_OK;
+}
+
+extern "C" int xsg_count_end(xsg_shard* s, uint64_t counters[XSG_NUM_COUNTERS]) {
+  if (!s || !counters) return fail(XSG_EINVAL, "null argument");
+  if (s->begin_sync_result) {
+    memcpy(counters, s->begin_counters, 8 * XSG_NUM_COUNTERS);
+    s->begin_sync_result = false;
+    return XSG_OK;
+  }
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(hipEventSynchronize(s->table_ev));
+  s->table_pending = false;
+  memcpy(counters, s->h_counters, 8 * XSG_NUM_COUNTERS);
   return XSG_OK;
 }
 
@@ -531,9 +630,10 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   const uint32_t m = mode & 0xffu;
   const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
   const bool want_lines = m == XSG_COUNT_LINES;
-  if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(s->ntiles, 1)));
-  XSG_TRY(preset_tile_arrays(s, want_lines, c->stream));
+  if (want_nl) XSG_TRY(ensure_tile_nl(s));
+  XSG_TRY(prepare_tiles(s, want_lines, c->stream));
   ScanArgs a = scan_args(s);
+  s->cnt_clean = s->sum_clean = false;  // no finish kernel runs behind these launches
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
@@ -547,6 +647,46 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *avg_ms = ms / (float)iters;
+  return XSG_OK;
+}
+
+extern "C" int xsg_scan_kernel_name(xsg_shard* s, uint32_t mode, char* out, size_t cap) {
+  XSG_TRY(check_ready(s));
+  if (!out || !cap) return fail(XSG_EINVAL, "null output");
+  const uint32_t m = mode & 0xffu;
+  const bool list = m >= XSG_MATCH_BYTE_OFFSETS;
+  // what the FIRST pass of this mode launches on this shard right now (newline counts already cached -> plain kernel)
+  const bool want_nl = ((mode & XSG_WITH_NEWLINES) != 0 || m == XSG_LINE_INDICES) && !s->nl_cached;
+  const ScanArgs a = scan_args(s);
+  describe_scan(a, want_nl, !list && m == XSG_COUNT_LINES, false, out, cap);
+  return XSG_OK;
+}
+
+// Picks the wave stagger of the bulk kernel for THIS shard, pattern and mode by measurement instead of the
+// per-variant default (the optimum is sharp and depends on how memory-bound the variant is on the actual data:
+// a needle that is dense in this text wants none).  A few launches per candidate; shards under 1 GiB keep the default.
+extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
+  XSG_TRY(check_ready(s));
+  xsg_ctx* c = s->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  s->tune = kTuneAuto;
+  if (chosen) *chosen = kTuneAuto;
+  if (c->tune != kTuneAuto || s->total_bytes < (1ull << 30)) return XSG_OK;  // XSG_TUNE wins; too small to measure
+  static const uint32_t cand[] = {0, 4, 8, 10, 12, 14, 16, 20};
+  float best_ms = 0;
+  uint32_t best = kTuneAuto;
+  for (uint32_t t : cand) {
+    s->tune = t;
+    float ms = 0;
+    const int r = xsg_time_scan_kernel(s, mode, 3, &ms);
+    if (r != XSG_OK) {
+      s->tune = kTuneAuto;
+      return r;
+    }
+    if (best == kTuneAuto || ms < best_ms) best_ms = ms, best = t;
+  }
+  s->tune = best;
+  if (chosen) *chosen = best;
   return XSG_OK;
 }
 
@@ -668,10 +808,13 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   s->line_bytes = 0;
 
   // 1. bulk count per tile
-  if (want_nl) XSG_TRY(s->d_tile_nl.ensure(4 * std::max<uint64_t>(ntiles, 1)));
-  XSG_TRY(preset_tile_arrays(s, false, st));
+  if (want_nl) XSG_TRY(ensure_tile_nl(s));
+  XSG_TRY(prepare_tiles(s, false, st));
   ScanArgs a = scan_args(s);
-  HIP_TRY(launch_scan_count(a, want_nl, false, st));
+  s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them
+  const bool scan_nl = want_nl && !s->nl_cached;  // newline counts per tile: once per binding, whatever the pattern
+  HIP_TRY(launch_scan_count(a, scan_nl, false, st));
+  if (scan_nl) s->nl_cached = true;
 
   // 2. ranks
   XSG_TRY(s->d_tile_off.ensure(8 * (ntiles + 1)));
@@ -768,12 +911,19 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   if (mode == XSG_MATCH_BYTE_OFFSETS || mode == XSG_LINE_BYTE_OFFSETS) {
     HIP_TRY(launch_globalize(o, st));
   } else if (mode == XSG_LINE_INDICES) {
-    XSG_TRY(s->d_tile_nl_off.ensure(8 * (ntiles + 1)));
+    {
+      bool grew = false;
+      XSG_TRY(s->d_tile_nl_off.ensure(8 * (ntiles + 1), &grew));
+      if (grew) s->nl_off_cached = false;
+    }
     XSG_TRY(s->d_line_len.ensure(8 * std::max<uint64_t>(total, 1)));
     XSG_TRY(s->d_line_off.ensure(8 * (total + 1)));
     XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(std::max<uint64_t>(total + 1, ntiles + 1))));
-    HIP_TRY(launch_exclusive_scan_u32(a.tile_nl, s->d_tile_nl_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(),
-                                      st));
+    if (!s->nl_off_cached) {
+      HIP_TRY(launch_exclusive_scan_u32(a.tile_nl, s->d_tile_nl_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(),
+                                        st));
+      s->nl_off_cached = true;
+    }
     o.tile_nl_off = s->d_tile_nl_off.as<uint64_t>();
     // per-entry newline differences -> prefix sums -> indices (k_line_nl_delta / k_line_indices)
     o.line_len = s->d_line_len.as<uint64_t>();

@@ -30,6 +30,18 @@ static double seconds_since(Clock::time_point t0) {
 
 extern "C" void xsg_free(void* p) { free(p); }
 
+// No C++ exception may cross the C ABI: host-side containers sized from file contents can throw.
+template <typename F>
+static int guarded(const char* what, F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(XSG_ENOMEM, "%s: host allocation failed", what);
+  } catch (const std::exception& e) {
+    return fail(XSG_EIO, "%s: %s", what, e.what());
+  }
+}
+
 // ---------------------------------------------------------------------------
 // file helpers
 // ---------------------------------------------------------------------------
@@ -122,11 +134,19 @@ extern "C" int xsg_plan_chunks(const char* file_path, uint64_t target_bytes, xsg
   int fd;
   uint64_t size;
   XSG_TRY(open_ro(file_path, &fd, &size));
-  std::vector<xsg_file_chunk> v;
-  const int r = plan_plain(fd, size, target_bytes ? target_bytes : (16u << 20), v);
-  close(fd);
-  if (r != XSG_OK) return r;
-  return to_malloc(v, chunks, n);
+  return guarded("xsg_plan_chunks", [&]() -> int {
+    std::vector<xsg_file_chunk> v;
+    int r;
+    try {
+      r = plan_plain(fd, size, target_bytes ? target_bytes : (16u << 20), v);
+    } catch (...) {
+      close(fd);
+      throw;
+    }
+    close(fd);
+    if (r != XSG_OK) return r;
+    return to_malloc(v, chunks, n);
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -173,7 +193,9 @@ static int read_meta(const char* path, int32_t* compression, std::vector<xsg_fil
     c.first_line = XSG_LINE_BASE_AUTO;
     if (c.original_offset != expect_orig)
       return fail(XSG_EIO, "metafile '%s': chunk %zu does not start where its predecessor ends", path, chunks.size());
-    expect_orig += c.original_size;
+    if (c.original_size >= (1ull << 40) || c.actual_size >= (1ull << 40))
+      return fail(XSG_EIO, "metafile '%s': chunk %zu has an implausible size", path, chunks.size());
+    expect_orig += c.original_size;  // < 2^40 each and at most size/40 records: no wrap
     if (n) {
       // the first mapping entry of a chunk is the chunk start
       if (f[5] == c.original_offset) c.first_line = f[6];
@@ -192,17 +214,19 @@ static int read_meta(const char* path, int32_t* compression, std::vector<xsg_fil
 extern "C" int xsg_meta_read(const char* meta_path, int32_t* compression, xsg_file_chunk** chunks, uint64_t* n,
                              uint64_t** mappings, uint64_t* n_mapping_pairs) {
   if (!compression || !chunks || !n) return fail(XSG_EINVAL, "null output");
-  std::vector<xsg_file_chunk> v;
-  std::vector<uint64_t> maps;
-  XSG_TRY(read_meta(meta_path, compression, v, mappings ? &maps : nullptr));
-  XSG_TRY(to_malloc(v, chunks, n));
-  if (mappings) {
-    *mappings = static_cast<uint64_t*>(malloc(8 * std::max<size_t>(maps.size(), 1)));
-    if (!*mappings) return fail(XSG_ENOMEM, "host allocation failed");
-    if (!maps.empty()) memcpy(*mappings, maps.data(), 8 * maps.size());
-    if (n_mapping_pairs) *n_mapping_pairs = maps.size() / 2;
-  }
-  return XSG_OK;
+  return guarded("xsg_meta_read", [&]() -> int {
+    std::vector<xsg_file_chunk> v;
+    std::vector<uint64_t> maps;
+    XSG_TRY(read_meta(meta_path, compression, v, mappings ? &maps : nullptr));
+    XSG_TRY(to_malloc(v, chunks, n));
+    if (mappings) {
+      *mappings = static_cast<uint64_t*>(malloc(8 * std::max<size_t>(maps.size(), 1)));
+      if (!*mappings) return fail(XSG_ENOMEM, "host allocation failed");
+      if (!maps.empty()) memcpy(*mappings, maps.data(), 8 * maps.size());
+      if (n_mapping_pairs) *n_mapping_pairs = maps.size() / 2;
+    }
+    return XSG_OK;
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -310,8 +334,16 @@ static int decompress_chunk(int32_t type, const uint8_t* src, uint64_t src_n, ui
 // ---------------------------------------------------------------------------
 // metafile writer / preprocessor
 // ---------------------------------------------------------------------------
+static int meta_write_impl(const char* file_path, const char* meta_out_path, const char* data_out_path,
+                           int32_t compression, uint64_t chunk_bytes, uint64_t mapping_gap, int hc);
 extern "C" int xsg_meta_write(const char* file_path, const char* meta_out_path, const char* data_out_path,
                               int32_t compression, uint64_t chunk_bytes, uint64_t mapping_gap, int hc) {
+  return guarded("xsg_meta_write", [&]() -> int {
+    return meta_write_impl(file_path, meta_out_path, data_out_path, compression, chunk_bytes, mapping_gap, hc);
+  });
+}
+static int meta_write_impl(const char* file_path, const char* meta_out_path, const char* data_out_path,
+                           int32_t compression, uint64_t chunk_bytes, uint64_t mapping_gap, int hc) {
   if (!meta_out_path) return fail(XSG_EINVAL, "meta_out_path is null");
   if (compression != XSG_COMPRESSION_NONE && compression != XSG_COMPRESSION_ZSTD && compression != XSG_COMPRESSION_LZ4)
     return fail(XSG_EINVAL, "bad compression type %d", compression);
@@ -502,16 +534,24 @@ struct HostBuf {
   }
 };
 
-// Device side of a worker: ctx + stream + shard scratch + device buffer.
-struct Slot {
+// Device side of a worker: two lanes of ctx (= stream) + shard scratch + device buffer.  Count tags alternate
+// between them so that the copy of chunk i+1 is already in the queue (and moving) while chunk i is scanned and
+// its result waited for; list tags use lane 0 only.
+struct Lane {
   xsg_ctx* ctx = nullptr;
   xsg_shard* shard = nullptr;
   void* dev = nullptr;
   uint64_t cap = 0;
+};
+struct Slot {
+  Lane lane[2];
+  int device = 0;
   ~Slot() {
-    if (shard) xsg_shard_destroy(shard);
-    if (dev) (void)hipFree(dev);
-    if (ctx) xsg_ctx_destroy(ctx);
+    for (Lane& l : lane) {
+      if (l.shard) xsg_shard_destroy(l.shard);
+      if (l.dev) (void)hipFree(l.dev);
+      if (l.ctx) xsg_ctx_destroy(l.ctx);
+    }
   }
 };
 
@@ -534,7 +574,7 @@ static Slot* slot_take(int device) {
   std::lock_guard<std::mutex> g(g_pool_mu);
   std::vector<Slot*>& pool = slot_pool();
   for (size_t i = 0; i < pool.size(); ++i) {
-    if (pool[i]->ctx->device == device) {
+    if (pool[i]->device == device) {
       Slot* s = pool[i];
       pool.erase(pool.begin() + (ptrdiff_t)i);
       return s;
@@ -554,25 +594,31 @@ static void slot_give_back(Slot* s) {
   delete s;
 }
 
+static bool is_count_mode(uint32_t mode) { return mode == XSG_COUNT_MATCHES || mode == XSG_COUNT_LINES; }
+
 static int slot_prepare(xsg_job* j, Slot** out) {
   Slot* s = slot_take(j->opts.device);
-  std::unique_ptr<Slot> own(s);
-  if (!s) {
-    own.reset(new (std::nothrow) Slot());
-    if (!own) return fail(XSG_ENOMEM, "host allocation failed");
-    s = own.get();
-    XSG_TRY(xsg_ctx_create(j->opts.device, &s->ctx));
-    XSG_TRY(xsg_shard_create(s->ctx, nullptr, 0, nullptr, 0, &s->shard));
-  }
+  std::unique_ptr<Slot> own(s ? s : new (std::nothrow) Slot());
+  if (!own) return fail(XSG_ENOMEM, "host allocation failed");
+  s = own.get();
+  s->device = j->opts.device;
   HIP_TRY(hipSetDevice(j->opts.device));
-  XSG_TRY(xsg_set_pattern(s->ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
+  const int nlanes = is_count_mode(j->opts.mode) ? 2 : 1;
   const uint64_t need = ((j->max_orig + 15u) & ~(uint64_t)15u) + 256u;
-  if (need > s->cap) {
-    if (s->dev) (void)hipFree(s->dev);
-    s->dev = nullptr;
-    s->cap = 0;
-    HIP_TRY(hipMalloc(&s->dev, need));
-    s->cap = need;
+  for (int k = 0; k < nlanes; ++k) {
+    Lane& l = s->lane[k];
+    if (!l.ctx) {
+      XSG_TRY(xsg_ctx_create(j->opts.device, &l.ctx));
+      XSG_TRY(xsg_shard_create(l.ctx, nullptr, 0, nullptr, 0, &l.shard));
+    }
+    XSG_TRY(xsg_set_pattern(l.ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
+    if (need > l.cap) {
+      if (l.dev) (void)hipFree(l.dev);
+      l.dev = nullptr;
+      l.cap = 0;
+      HIP_TRY(hipMalloc(&l.dev, need));
+      l.cap = need;
+    }
   }
   *out = own.release();
   return XSG_OK;
@@ -598,7 +644,13 @@ static int buf_prepare(xsg_job* j, HostBuf** out) {
     HIP_TRY(hipHostMalloc(&own->pinned, need, hipHostMallocDefault));
     own->cap = need;
   }
-  if (j->compression != XSG_COMPRESSION_NONE && own->staging.size() < j->max_actual) own->staging.resize(j->max_actual);
+  if (j->compression != XSG_COMPRESSION_NONE && own->staging.size() < j->max_actual) {
+    try {
+      own->staging.resize(j->max_actual);  // <= the data file's size (validated)
+    } catch (const std::bad_alloc&) {
+      return fail(XSG_ENOMEM, "cannot allocate %llu bytes of staging for compressed chunks", (unsigned long long)j->max_actual);
+    }
+  }
   *out = own.release();
   return XSG_OK;
 }
@@ -615,9 +667,7 @@ static void bufs_release(xsg_job* j) {
 }
 
 // ---- stage 1: read (+ decompress) into a pinned buffer ------------------------
-static void reader_main(xsg_job* j) {
-  double t_read = 0, t_dec = 0;
-  uint64_t rbytes = 0;
+static void reader_loop(xsg_job* j, double& t_read, double& t_dec, uint64_t& rbytes) {
   while (!j->stop.load()) {
     const uint64_t i = j->next_chunk.fetch_add(1);
     if (i >= j->plan.size()) break;
@@ -632,7 +682,11 @@ static void reader_main(xsg_job* j) {
     const xsg_file_chunk& fc = j->plan[i];
     auto t0 = Clock::now();
     int r = XSG_OK;
-    if (fc.actual_size) {
+    // the plan was validated at start; the buffers were sized from it -- checked again where the bytes land
+    if (fc.original_size > b->cap || (j->compression != XSG_COMPRESSION_NONE && fc.actual_size > b->staging.size()) ||
+        (j->compression == XSG_COMPRESSION_NONE && fc.actual_size > b->cap))
+      r = fail(XSG_EIO, "chunk %llu does not fit its buffers", (unsigned long long)i);
+    if (r == XSG_OK && fc.actual_size) {
       void* dst = j->compression == XSG_COMPRESSION_NONE ? b->pinned : (void*)b->staging.data();
       r = pread_full(j->fd, dst, fc.actual_size, fc.actual_offset);
     }
@@ -657,6 +711,20 @@ static void reader_main(xsg_job* j) {
     }
     j->q_cv_ready.notify_one();
   }
+}
+
+static void reader_main(xsg_job* j) {
+  double t_read = 0, t_dec = 0;
+  uint64_t rbytes = 0;
+  try {
+    reader_loop(j, t_read, t_dec, rbytes);
+  } catch (const std::bad_alloc&) {
+    (void)fail(XSG_ENOMEM, "host allocation failed in a reader");
+    job_fail(j, XSG_ENOMEM);
+  } catch (const std::exception& e) {
+    (void)fail(XSG_EIO, "reader: %s", e.what());
+    job_fail(j, XSG_EIO);
+  }
   {
     std::lock_guard<std::mutex> lk(j->q_mu);
     --j->readers_running;
@@ -669,29 +737,33 @@ static void reader_main(xsg_job* j) {
 }
 
 // ---- stage 2: H2D on the worker's stream, scan, publish -------------------------
-static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
+static int bind_chunk(xsg_job* j, Lane& l, const HostBuf& hb) {
   const xsg_file_chunk& fc = j->plan[hb.index];
-  const uint32_t mode = j->opts.mode;
+  if (fc.original_size > hb.cap || fc.original_size > l.cap) return fail(XSG_EINVAL, "chunk larger than its buffers");
   if (fc.original_size)
-    HIP_TRY(hipMemcpyAsync(s.dev, hb.pinned, fc.original_size, hipMemcpyHostToDevice, s.ctx->stream));
+    HIP_TRY(hipMemcpyAsync(l.dev, hb.pinned, fc.original_size, hipMemcpyHostToDevice, l.ctx->stream));
   xsg_chunk ch{};
   ch.offset = 0;
   ch.length = fc.original_size;
   ch.global_offset = fc.original_offset;
   ch.line_base = fc.first_line;  // from the metafile, or AUTO (then local indices + running base at publish)
-  XSG_TRY(xsg_shard_rebind(s.shard, s.dev, s.cap, &ch, 1));
+  return xsg_shard_rebind(l.shard, l.dev, l.cap, &ch, 1);
+}
+
+// list tags: one chunk at a time (the list search synchronises the stream several times anyway)
+static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
+  const xsg_file_chunk& fc = j->plan[hb.index];
+  const uint32_t mode = j->opts.mode;
+  Lane& l = s.lane[0];
+  XSG_TRY(bind_chunk(j, l, hb));
   Partial p;
-  if (mode == XSG_COUNT_MATCHES || mode == XSG_COUNT_LINES) {
-    uint64_t ctr[XSG_NUM_COUNTERS];
-    XSG_TRY(xsg_count(s.shard, mode, ctr));
-    p.count = ctr[mode == XSG_COUNT_MATCHES ? XSG_CTR_MATCHES : XSG_CTR_LINES];
-  } else if (mode == XSG_LINES) {
+  if (mode == XSG_LINES) {
     uint64_t n = 0, nl = 0, nb = 0;
-    XSG_TRY(xsg_search(s.shard, mode, &n));
-    XSG_TRY(xsg_result_lines_size(s.shard, &nl, &nb));
+    XSG_TRY(xsg_search(l.shard, mode, &n));
+    XSG_TRY(xsg_result_lines_size(l.shard, &nl, &nb));
     std::vector<uint64_t> lens(nl);
     std::vector<char> bytes(nb ? nb : 1);
-    XSG_TRY(xsg_result_lines(s.shard, lens.data(), bytes.data(), nb, nullptr));
+    XSG_TRY(xsg_result_lines(l.shard, lens.data(), bytes.data(), nb, nullptr));
     p.lines.reserve(nl);
     uint64_t at = 0;
     for (uint64_t i = 0; i < nl; ++i) {
@@ -700,12 +772,12 @@ static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
     }
   } else {
     uint64_t n = 0;
-    XSG_TRY(xsg_search(s.shard, mode, &n));
+    XSG_TRY(xsg_search(l.shard, mode, &n));
     p.u64.resize(n);
-    XSG_TRY(xsg_result_u64(s.shard, p.u64.data(), n));
+    XSG_TRY(xsg_result_u64(l.shard, p.u64.data(), n));
     if (mode == XSG_LINE_INDICES && fc.first_line == XSG_LINE_BASE_AUTO) {
       p.indices_local = true;
-      XSG_TRY(xsg_result_newlines(s.shard, &p.newlines));
+      XSG_TRY(xsg_result_newlines(l.shard, &p.newlines));
     }
   }
   // the searches above synchronise the stream: the pinned buffer is free again
@@ -713,44 +785,112 @@ static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
   return XSG_OK;
 }
 
-static void worker_main(xsg_job* j) {
-  double t_dev = 0;
-  uint64_t bytes = 0, chunks = 0;
+// count tags, first half: copy + scan of the chunk go into lane k's queue; nothing is waited for
+static int count_enqueue(xsg_job* j, Slot& s, int k, const HostBuf& hb) {
+  XSG_TRY(bind_chunk(j, s.lane[k], hb));
+  return xsg_count_begin(s.lane[k].shard, j->opts.mode);
+}
+// second half: wait for lane k, publish
+static int count_collect(xsg_job* j, Slot& s, int k, uint64_t index) {
+  uint64_t ctr[XSG_NUM_COUNTERS];
+  XSG_TRY(xsg_count_end(s.lane[k].shard, ctr));
+  Partial p;
+  p.count = ctr[j->opts.mode == XSG_COUNT_MATCHES ? XSG_CTR_MATCHES : XSG_CTR_LINES];
+  publish(j, index, std::move(p));
+  return XSG_OK;
+}
+
+static void give_back(xsg_job* j, HostBuf* b) {
+  {
+    std::lock_guard<std::mutex> lk(j->q_mu);
+    j->free_bufs.push_back(b);
+  }
+  j->q_cv_free.notify_one();
+}
+
+static void worker_body(xsg_job* j, double& t_dev, uint64_t& bytes, uint64_t& chunks) {
   Slot* sp = nullptr;
   int r = slot_prepare(j, &sp);
   if (r != XSG_OK) {
     job_fail(j, r);
-  } else {
-    for (;;) {
-      HostBuf* b = nullptr;
-      {
-        std::unique_lock<std::mutex> lk(j->q_mu);
+    return;
+  }
+  const bool pipelined = is_count_mode(j->opts.mode);
+  HostBuf* inflight = nullptr;  // count tags: the chunk whose pass is in lane (k ^ 1)'s queue
+  int k = 0;
+  for (;;) {
+    HostBuf* b = nullptr;
+    bool done = false;
+    {
+      std::unique_lock<std::mutex> lk(j->q_mu);
+      // with a pass in flight, do not sleep on the queue: collect that result first (its pinned buffer goes
+      // back to the readers, who may be waiting for exactly that one)
+      if (!inflight)
         j->q_cv_ready.wait(lk, [&] { return !j->ready_bufs.empty() || j->readers_running == 0 || j->stop.load(); });
-        if (j->stop.load()) break;
-        if (j->ready_bufs.empty()) break;  // readers are done and nothing is left
+      if (j->stop.load()) {
+        done = true;
+      } else if (!j->ready_bufs.empty()) {
         b = j->ready_bufs.front();
         j->ready_bufs.pop_front();
+      } else if (!inflight) {
+        done = true;  // readers are done and nothing is left
       }
-      const auto t0 = Clock::now();
-      r = process_chunk(j, *sp, *b);
-      t_dev += seconds_since(t0);
-      const uint64_t idx = b->index;
-      {
-        std::lock_guard<std::mutex> lk(j->q_mu);
-        j->free_bufs.push_back(b);
-      }
-      j->q_cv_free.notify_one();
-      if (r != XSG_OK) {
-        job_fail(j, r);
-        break;
-      }
-      bytes += j->plan[idx].original_size;
-      ++chunks;
     }
-    if (r == XSG_OK)
-      slot_give_back(sp);
-    else
-      delete sp;  // do not recycle a slot whose last operation failed
+    if (done) break;
+    const auto t0 = Clock::now();
+    if (!pipelined) {
+      r = process_chunk(j, *sp, *b);
+      bytes += j->plan[b->index].original_size;
+      ++chunks;
+      give_back(j, b);
+    } else {
+      if (b) r = count_enqueue(j, *sp, k, *b);
+      if (inflight) {
+        const int r2 = count_collect(j, *sp, k ^ 1, inflight->index);
+        bytes += j->plan[inflight->index].original_size;
+        ++chunks;
+        give_back(j, inflight);
+        inflight = nullptr;
+        if (r == XSG_OK) r = r2;
+      }
+      if (b) {
+        if (r == XSG_OK) {
+          inflight = b;
+          k ^= 1;
+        } else {
+          (void)hipDeviceSynchronize();  // the failed lane may still read the pinned buffer
+          give_back(j, b);
+        }
+      }
+    }
+    t_dev += seconds_since(t0);
+    if (r != XSG_OK) {
+      job_fail(j, r);
+      break;
+    }
+  }
+  if (inflight) {  // stopped with a pass in flight: let it drain before the buffer is handed back
+    uint64_t ctr[XSG_NUM_COUNTERS];
+    (void)xsg_count_end(sp->lane[k ^ 1].shard, ctr);
+    give_back(j, inflight);
+  }
+  if (r == XSG_OK)
+    slot_give_back(sp);
+  else
+    delete sp;  // do not recycle a slot whose last operation failed
+}
+
+static void worker_main(xsg_job* j) {
+  double t_dev = 0;
+  uint64_t bytes = 0, chunks = 0;
+  try {
+    worker_body(j, t_dev, bytes, chunks);
+  } catch (const std::bad_alloc&) {  // nothing may leave a thread body (or the extern "C" boundary) as an exception
+    (void)fail(XSG_ENOMEM, "host allocation failed in a device worker");
+    job_fail(j, XSG_ENOMEM);
+  } catch (const std::exception& e) {
+    (void)fail(XSG_EIO, "device worker: %s", e.what());
+    job_fail(j, XSG_EIO);
   }
   if (j->stop.load()) {  // wake everybody that may still be waiting on a queue
     { std::lock_guard<std::mutex> lk(j->q_mu); }
@@ -779,8 +919,22 @@ extern "C" void xsg_job_opts_init(xsg_job_opts* o) {
   o->chunk_bytes = 16u << 20;
 }
 
+static int job_start_impl(const void* pattern, size_t plen, const char* file_path, const char* meta_file_path,
+                          const xsg_job_opts* opts, xsg_job** out);
+
 extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_path, const char* meta_file_path,
                              const xsg_job_opts* opts, xsg_job** out) {
+  try {
+    return job_start_impl(pattern, plen, file_path, meta_file_path, opts, out);
+  } catch (const std::bad_alloc&) {  // e.g. a plan with millions of records
+    return fail(XSG_ENOMEM, "host allocation failed while setting up the job");
+  } catch (const std::exception& e) {
+    return fail(XSG_EIO, "xsg_job_start: %s", e.what());
+  }
+}
+
+static int job_start_impl(const void* pattern, size_t plen, const char* file_path, const char* meta_file_path,
+                          const xsg_job_opts* opts, xsg_job** out) {
   if (!out) return fail(XSG_EINVAL, "out is null");
   *out = nullptr;
   if (!opts || opts->struct_size != sizeof(xsg_job_opts)) return fail(XSG_EINVAL, "bad xsg_job_opts (struct_size)");
@@ -798,11 +952,6 @@ extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_
   } else if (line_mode && memchr(pattern, '\n', plen) != nullptr) {
     return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
   }
-  // fail early and loudly without a device: there is no CPU search path
-  int ndev = 0;
-  XSG_TRY(xsg_device_count(&ndev));
-  if (opts->device < 0 || opts->device >= ndev) return fail(XSG_ENODEV, "device %d out of range", opts->device);
-
   std::unique_ptr<xsg_job> j(new (std::nothrow) xsg_job());
   if (!j) return fail(XSG_ENOMEM, "host allocation failed");
   j->opts = *opts;
@@ -813,18 +962,34 @@ extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_
   int r = XSG_OK;
   if (meta_file_path && *meta_file_path) {
     r = read_meta(meta_file_path, &j->compression, j->plan, nullptr);
-    if (r == XSG_OK) {
-      for (const xsg_file_chunk& c : j->plan)
-        if (c.actual_offset + c.actual_size > fsize) {
-          r = fail(XSG_EIO, "metafile '%s' describes bytes beyond the end of '%s'", meta_file_path, file_path);
-          break;
-        }
+    // A metafile is input like any other: every record is checked BEFORE a buffer is sized from it or a byte is
+    // read or decoded through it (sizes < 2^40 were enforced by read_meta).
+    for (size_t i = 0; r == XSG_OK && i < j->plan.size(); ++i) {
+      const xsg_file_chunk& c = j->plan[i];
+      if (c.actual_size > fsize || c.actual_offset > fsize - c.actual_size)
+        r = fail(XSG_EIO, "metafile '%s': chunk %zu lies beyond the end of '%s'", meta_file_path, i, file_path);
+      else if (j->compression == XSG_COMPRESSION_NONE && c.actual_size != c.original_size)
+        r = fail(XSG_EIO, "metafile '%s': chunk %zu of an uncompressed file has actual_size != original_size",
+                 meta_file_path, i);
+      else if (j->compression == XSG_COMPRESSION_LZ4 && (c.original_size > INT32_MAX || c.actual_size > INT32_MAX))
+        r = fail(XSG_EIO, "metafile '%s': chunk %zu is too large for an LZ4 block", meta_file_path, i);
+      else if (j->compression != XSG_COMPRESSION_NONE && c.original_size && !c.actual_size)
+        r = fail(XSG_EIO, "metafile '%s': chunk %zu has no compressed bytes", meta_file_path, i);
     }
     if (r == XSG_OK && j->compression == XSG_COMPRESSION_LZ4) r = need_lz4();
     if (r == XSG_OK && j->compression == XSG_COMPRESSION_ZSTD) r = need_zstd();
   } else {
     r = plan_plain(j->fd, fsize, j->opts.chunk_bytes, j->plan);
   }
+  if (r != XSG_OK) {
+    close(j->fd);
+    return r;
+  }
+  // fail early and loudly without a device: there is no CPU search path (after the file checks, so that a bad
+  // path or metafile is reported as such on any host)
+  int ndev = 0;
+  r = xsg_device_count(&ndev);
+  if (r == XSG_OK && (opts->device < 0 || opts->device >= ndev)) r = fail(XSG_ENODEV, "device %d out of range", opts->device);
   if (r != XSG_OK) {
     close(j->fd);
     return r;
@@ -847,8 +1012,10 @@ extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_
   const uint64_t nch = std::max<uint64_t>(j->plan.size(), 1);
   const int nworkers = (int)std::min<uint64_t>((uint64_t)opts->num_threads, nch);
   const int nreaders = (int)std::min<uint64_t>((uint64_t)opts->num_max_readers, nch);
-  // one buffer being filled per reader, one being consumed per worker, one in between
-  const int nbufs = (int)std::min<uint64_t>((uint64_t)(nworkers + nreaders + 1), nch + 1);
+  // one buffer being filled per reader, one being consumed per worker (two for count tags: a worker keeps the
+  // next chunk's copy queued behind the current scan), one in between
+  const int per_worker = is_count_mode(opts->mode) ? 2 : 1;
+  const int nbufs = (int)std::min<uint64_t>((uint64_t)(per_worker * nworkers + nreaders + 1), nch + 1);
   for (int i = 0; i < nbufs; ++i) {
     HostBuf* b = nullptr;
     r = buf_prepare(j.get(), &b);

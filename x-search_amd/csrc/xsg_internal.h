@@ -65,17 +65,22 @@ struct ScanArgs {
   uint64_t ntiles;
   uint32_t tile_bytes;          // 16384 (selects the k_scan instantiation)
   uint32_t tune;                // bits 0-7: wave stagger in units of s_sleep(1) = 64 clocks; kTuneAuto = per variant (XSG_TUNE overrides)
+  uint32_t epoch;               // 1..0xffff: tag of this pass in the upper half of the tile_last words
   PatternDev pat;
-  // outputs of the counting pass
-  uint32_t* tile_cnt;                  // matches starting in the tile (o < limit); ZEROED by the host before the pass
-  uint32_t* tile_nl;                   // '\n' in the tile              (WANT_NL)
-  uint32_t* tile_sum;                  // line summary PER WAVE (4 per tile), preset to kSumNl (WANT_LINES)
-  uint32_t* tile_last;                 // max (match offset + plen) in the tile, relative to the tile start; ZEROED by the host
+  // outputs of the counting pass.  Only waves that found something write (no store on the common path), so
+  // "nothing found" must already be in place: tile_cnt == 0 and tile_sum == 0 (k_count_finish restores both as
+  // it consumes them), tile_last from an older epoch (never reset: a newer tag wins the atomicMax).
+  uint32_t* tile_cnt;                  // matches starting in the tile (o < limit)
+  uint32_t* tile_nl;                   // '\n' in the tile              (WANT_NL; every tile is written)
+  uint32_t* tile_sum;                  // line summary PER WAVE (4 per tile), stored XOR kSumNl (WANT_LINES)
+  uint32_t* tile_last;                 // (epoch << 16) | max (match offset + plen) in the tile, relative to the tile start
   // inputs/outputs of the emit pass
   const uint64_t* tile_off;  // exclusive prefix of tile_cnt
   uint64_t* m_pos;           // chunk-local offset of every match, ascending
   uint32_t* m_chunk;         // its chunk
 };
+
+constexpr int kFinishBlocks = 2048;  // upper bound of k_count_finish's grid (size of FinishArgs::partials / 3)
 
 struct FinishArgs {
   const uint8_t* base;
@@ -84,13 +89,17 @@ struct FinishArgs {
   uint64_t nchunks;
   uint64_t ntiles;
   PatternDev pat;
-  const uint32_t* tile_cnt;
+  uint32_t* tile_cnt;         // read, then zeroed again
   const uint32_t* tile_nl;
-  const uint32_t* tile_sum;
-  const uint32_t* tile_last;
+  uint32_t* tile_sum;         // read, then zeroed again
+  const uint32_t* tile_last;  // valid where the upper half equals `epoch`
+  uint32_t epoch;
   uint32_t tile_bytes;
-  uint64_t* counters;  // XSG_NUM_COUNTERS, zeroed before the launch
-  uint64_t total_bytes;  // sum of the chunk lengths (host-side knowledge)
+  uint64_t* counters;       // device, XSG_NUM_COUNTERS: overwritten (no zeroing needed)
+  uint64_t* host_counters;  // optional: pinned host mirror of the same four values
+  uint64_t* partials;       // scratch: 3 x kFinishBlocks
+  uint32_t* ticket;         // zero at rest: the last workgroup to arrive does the final sum and resets it
+  uint64_t total_bytes;     // sum of the chunk lengths (host-side knowledge)
   uint32_t want_nl;
   uint32_t want_lines;
   uint32_t want_matches;
@@ -100,6 +109,8 @@ struct FinishArgs {
 hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s);
 hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s);
 hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s);
+// "xsg::k_scan<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE>" + the stagger launch_scan would use, for reports
+void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap);
 hipError_t launch_read_exp(const uint8_t* base, uint64_t bytes, int loads, int block, uint32_t stagger, uint32_t gap,
                            uint32_t* sink, hipStream_t s);
 hipError_t launch_read_probe(const ScanArgs& a, int parts, uint64_t flat_bytes, uint32_t* sink, hipStream_t s);

@@ -657,8 +657,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   if (!EMIT) {
     // ---- epilogue.  A store per tile, however small, interleaves writes into the
     // read stream (DRAM bus turnarounds): a probe kernel with k_scan's loads lost
-    // 2-4 % to it (scripts/probe_parts.py).  So the per-tile arrays are preset by the
-    // host (tile_cnt = 0, tile_sum = "has a newline, no match") and only waves that
+    // 2-4 % to it (scripts/probe_parts.py).  So the per-tile arrays hold "nothing
+    // found" at rest (tile_cnt = 0, tile_sum = 0 = "has a newline, no match";
+    // k_count_finish puts that back as it consumes them) and only waves that
     // found something else write: no LDS, no barrier, no store on the common path.
     if (__any(cnt != 0)) {
       const uint32_t wc = wave_sum_u32(cnt);
@@ -667,11 +668,13 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
         // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
         // cut dense patterns to a third)
         atomicAdd(A.tile_cnt + tile, wc);
-        atomicMax(A.tile_last + tile, (uint32_t)(wl - toff));  // >= 1: end of the last match, relative to the tile
+        // end of the last match relative to the tile start (1 .. tile + plen < 2^16), tagged with this pass's
+        // epoch: a word of an older pass loses the max, so the array is never reset
+        atomicMax(A.tile_last + tile, (A.epoch << 16) | (uint32_t)(wl - toff));
       }
     }
     if (WANT_LINES) {
-      if (lane == 0 && wsum != kSumNl) A.tile_sum[tile * kWaves + wave] = wsum;
+      if (lane == 0 && wsum != kSumNl) A.tile_sum[tile * kWaves + wave] = wsum ^ kSumNl;  // 0 = "a newline, no match"
     }
     if (WANT_NL) {  // every wave has newlines to report: one store per tile through LDS
       const uint32_t wn = wave_sum_u32(nlc);
@@ -745,21 +748,31 @@ static dim3 tile_grid(uint64_t ntiles) {
   return dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx), 1);
 }
 
+static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, bool emit) {
+  if (a.tune != kTuneAuto) return a.tune & 0xffu;
+  // The stagger only pays where the kernel is memory-bound: it takes issue slots
+  // away from the VALU-bound variants (scripts/tune_sweep.py: plain count +5 %,
+  // count_lines +1 % at a small stagger, every heavier variant -1..-3 %).
+  // (unmasked compares = plen >= 4; a needle that is dense in the text makes any variant VALU-heavy
+  // and loses 2-3 % to the stagger -- not knowable before the scan: xsg_shard_tune measures it)
+  // ignore_case: the hot loop of an 8-byte pattern only ORs 0x20 into the data (LAZY in scan_load) and stays
+  // memory-bound (7.0 -> 7.36 TB/s with the stagger); the other kinds measured 2-3 % slower with it
+  const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo || a.pat.kind == kLong) &&
+                     (!a.pat.icase || a.pat.kind == kTwo) && !want_nl && !emit;
+  return !light ? 0u : (want_lines ? 4u : kDefaultStagger);
+}
+
+void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap) {
+  if (!out || !cap) return;
+  const char* b[2] = {"false", "true"};
+  snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s> stagger=%u", (int)a.pat.kind, b[emit ? 0 : want_nl],
+           b[emit ? 0 : want_lines], b[emit], b[a.pat.icase ? 1 : 0], pick_stagger(a, want_nl, want_lines, emit));
+}
+
 static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_lines, bool emit, hipStream_t s) {
   if (a_in.ntiles == 0) return hipSuccess;
   ScanArgs a = a_in;
-  if (a.tune == kTuneAuto) {
-    // The stagger only pays where the kernel is memory-bound: it takes issue slots
-    // away from the VALU-bound variants (scripts/tune_sweep.py: plain count +5 %,
-    // count_lines +1 % at a small stagger, every heavier variant -1..-3 %).
-    // (unmasked compares = plen >= 4; a needle that is dense in the text makes any variant VALU-heavy
-    // and loses 2-3 % to the stagger -- not knowable before the scan)
-    // ignore_case: the hot loop of an 8-byte pattern only ORs 0x20 into the data (LAZY in scan_load) and stays
-    // memory-bound (7.0 -> 7.36 TB/s with the stagger); the other kinds measured 2-3 % slower with it
-    const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo || a.pat.kind == kLong) &&
-                       (!a.pat.icase || a.pat.kind == kTwo) && !want_nl && !emit;
-    a.tune = !light ? 0u : (want_lines ? 4u : kDefaultStagger);
-  }
+  a.tune = pick_stagger(a_in, want_nl, want_lines, emit);
   const dim3 grid = tile_grid(a.ntiles);
   switch (a.pat.kind) {
     case kMask1: return launch_scan_loads<kMask1>(a, want_nl, want_lines, emit, grid, s);
@@ -963,11 +976,13 @@ hipError_t launch_read_probe(const ScanArgs& a, int parts, uint64_t flat_bytes, 
 }
 
 // ---------------------------------------------------------------------------
-// k_count_finish: sums the per-tile outputs and replays the reference walk
-// over every chunk's tail zone.  counters[] must be zero on entry.
+// k_count_finish: sums the per-tile outputs, replays the reference walk over
+// every chunk's tail zone, and leaves the per-tile arrays as the next pass
+// needs them (tile_cnt and tile_sum zero again).  One launch, no host-side
+// memset before or after; the last workgroup to arrive adds up the per-block
+// partial sums and writes the four counters (device and, if given, a pinned
+// host mirror), so the counters need no zeroing either.
 // ---------------------------------------------------------------------------
-constexpr int kFinishBlocks = 2048;
-
 __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* sh) {
   // sh: kWaves entries
 #pragma unroll
@@ -993,87 +1008,214 @@ __device__ __forceinline__ uint64_t wave_walk_entry(const uint8_t* d, uint64_t L
   return nl < 0 ? UINT64_MAX : (uint64_t)nl + 1u;
 }
 
+constexpr uint32_t kZoneStage = 96;  // bytes of a chunk's tail zone staged in LDS: <= 64 positions + 2 x 15 of alignment
+
+// The tail zone of one chunk, decided by the whole wave (xsg_tail.h, tail_walk_masks): lane i owns position Z + i,
+// computes how many leading pattern bytes match there (from the zone's bytes staged in LDS -- a byte-by-byte walk
+// by one lane through global memory cost ~10 us per chunk in dependent loads), ballots give the masks and the walk
+// itself runs on the scalar unit.  Returns (wave-uniform) the matches of the match-mode walk from `entry_m` and
+// of the line-mode walk from `entry_l`.  plen <= kTailMaskMaxPlen; all 64 lanes active.
+__device__ __forceinline__ void wave_tail_counts(const uint8_t* d, uint64_t L, const uint8_t* s_pat, uint32_t plen,
+                                                 bool icase, uint8_t* zone, uint32_t lane, bool want_m, uint64_t entry_m,
+                                                 bool want_l, uint64_t entry_l, uint32_t* n_m, uint32_t* n_l) {
+  const uint64_t Z = tail_zone_begin(L, plen);
+  const uint32_t n = (uint32_t)(L - Z);  // <= plen + 31 <= 64
+  const uint64_t Zal = Z & ~(uint64_t)15;
+  const uint64_t Lr = (L + 15u) & ~(uint64_t)15u;
+  const uint32_t off = (uint32_t)(Z - Zal);
+  if (Zal + (uint64_t)lane * kUnit < Lr && lane < kZoneStage / kUnit)
+    *reinterpret_cast<uint4*>(zone + lane * kUnit) = *reinterpret_cast<const uint4*>(d + Zal + (uint64_t)lane * kUnit);
+  // the zone row belongs to this wave alone: a wavefront-scope release/acquire orders its lanes' LDS accesses
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool in_zone = lane < n;
+  const bool room = in_zone && (L - (Z + lane) >= plen);
+  uint32_t k = 0;
+  bool alive = room;
+  for (uint32_t j = 0; j < plen; ++j) {
+    if (!__any(alive)) break;
+    if (alive) {
+      if (fold(zone[off + lane + j], icase) == s_pat[j])
+        k = j + 1u;
+      else
+        alive = false;
+    }
+  }
+  const unsigned long long full = __ballot(room && k == plen);
+  const unsigned long long nz = __ballot(k != 0);
+  const unsigned long long nlm = __ballot(in_zone && zone[off + lane] == '\n');
+  auto k_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)k, (int)__builtin_amdgcn_readfirstlane(j)); };
+  *n_m = want_m ? tail_walk_masks(L, plen, entry_m, false, full, nz, nlm, k_at) : 0u;
+  *n_l = want_l ? tail_walk_masks(L, plen, entry_l, true, full, nz, nlm, k_at) : 0u;
+}
+
 __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   __shared__ uint64_t sh[kWaves];
+  __shared__ __attribute__((aligned(16))) uint8_t s_zone[kWaves][kZoneStage];
+  __shared__ uint8_t s_pat[kTailMaskMaxPlen + 3];
+  __shared__ uint32_t s_is_last;
   const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint64_t gsz = (uint64_t)gridDim.x * kBlock;
   const uint32_t lane = threadIdx.x & 63u;
-
-  uint64_t cm = 0, cn = 0;
-  for (uint64_t t = gid; t < A.ntiles; t += gsz) {
-    if (A.want_matches) cm += A.tile_cnt[t];
-    if (A.want_nl) cn += A.tile_nl[t];
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool need_tail = !A.pat.exact_tail && A.pat.plen > 1;
+  const bool mask_tail = need_tail && A.pat.plen <= kTailMaskMaxPlen;
+  if (mask_tail) {
+    if (threadIdx.x < A.pat.plen) s_pat[threadIdx.x] = A.pat.d_pat[threadIdx.x];
+    __syncthreads();
   }
-  // one wave per chunk: where the walk stands at the end of the bulk part (from the
+
+  // ---- per-tile sums; tile_cnt goes back to zero as it is read (every word has exactly one reader)
+  uint64_t cm = 0, cn = 0;
+  for (uint64_t t = gid; t < A.ntiles; t += 4 * gsz) {
+    uint32_t v[4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t tt = t + (uint64_t)u * gsz;
+      v[u] = tt < A.ntiles ? A.tile_cnt[tt] : 0u;
+      w[u] = (A.want_nl && tt < A.ntiles) ? A.tile_nl[tt] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (v[u]) A.tile_cnt[t + (uint64_t)u * gsz] = 0u;
+      cm += v[u];
+      cn += w[u];
+    }
+  }
+  if (!A.want_matches) cm = 0;
+
+  // ---- one wave per chunk: where the walk stands at the end of the bulk part (from the
   // last tile that holds a match), the chunk's matching lines, then its tail zone
   uint64_t lines = 0;
   const uint64_t wave_id = gid >> 6, nwaves = gsz >> 6;
   for (uint64_t c = wave_id; c < A.nchunks; c += nwaves) {
     const uint64_t t0 = A.chunk_tile0[c], t1 = A.chunk_tile0[c + 1];
-    const bool need_tail = !A.pat.exact_tail && A.pat.plen > 1;
+    const ChunkDev ch = A.chunks[c];
+    const uint8_t* d = A.base + ch.offset;
     uint64_t last_end = 0;
     if (need_tail) {
       uint64_t t = t1;
-      while (t > t0 && last_end == 0) {  // wave-uniform
-        const uint64_t lo = t - t0 >= 64 ? t - 64 : t0;
-        const uint64_t idx = lo + lane;
-        const uint32_t v = idx < t ? A.tile_last[idx] : 0u;
-        const unsigned long long bal = __ballot(v != 0);
-        if (bal) {
-          const int hi = 63 - __clzll((long long)bal);
-          const uint32_t vv = (uint32_t)__shfl((int)v, hi);
-          last_end = (lo + (uint64_t)hi - t0) * (uint64_t)A.tile_bytes + vv;
+      while (t > t0 && last_end == 0) {  // wave-uniform; 256 tiles a step, four independent loads
+        const uint64_t lo = t - t0 >= 256 ? t - 256 : t0;
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint64_t idx = lo + (uint64_t)u * 64u + lane;
+          const uint32_t x = idx < t ? A.tile_last[idx] : 0u;
+          v[u] = (x >> 16) == A.epoch ? (x & 0xffffu) : 0u;  // words of older passes do not count
+        }
+#pragma unroll
+        for (int u = 3; u >= 0; --u) {
+          const unsigned long long bal = __ballot(v[u] != 0);
+          if (bal && last_end == 0) {
+            const int hi = 63 - __clzll((long long)bal);
+            const uint32_t vv = (uint32_t)__builtin_amdgcn_readlane((int)v[u], hi);
+            last_end = (lo + (uint64_t)u * 64u + (uint64_t)hi - t0) * (uint64_t)A.tile_bytes + vv;
+          }
         }
         t = lo;
       }
     }
     if (A.want_lines) {
+      // 4 per-wave summaries per tile, 256 entries a step.  An entry that was never written reads 0 = "a newline,
+      // no match"; a group of 64 such entries combines to the same, so the common step is four ballots.
       uint32_t run = 0;  // identity
-      for (uint64_t e = t0 * kWaves; e < t1 * kWaves; e += 64) {
-        const uint32_t v = e + lane < t1 * kWaves ? A.tile_sum[e + lane] : 0u;
-        const uint32_t r = wave_sum_combine(v, lane);
-        run = sum_combine(run, r);  // meaningful in lane 0
+      const uint64_t e1 = t1 * kWaves;
+      for (uint64_t e0 = t0 * kWaves; e0 < e1; e0 += 256) {
+        uint32_t raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint64_t e = e0 + (uint64_t)u * 64u + lane;
+          raw[u] = e < e1 ? A.tile_sum[e] : kSumNl;  // beyond the chunk: the identity (0 after the XOR)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (e0 + (uint64_t)u * 64u >= e1) break;  // wave-uniform
+          const uint64_t e = e0 + (uint64_t)u * 64u + lane;
+          if (__ballot(raw[u] != 0) == 0) {
+            run = sum_combine(run, kSumNl);
+          } else {
+            const uint32_t v = raw[u] ^ kSumNl;
+            if (raw[u] != 0 && e < e1) A.tile_sum[e] = 0u;  // back to "nothing found"
+            const uint32_t csum = wave_sum_u32(v >> kSumCShift);
+            run = sum_combine(run, sum_combine_lanes(__ballot(v & kSumNl), __ballot(v & kSumF), __ballot(v & kSumL), csum));
+          }
+        }
       }
       if (lane == 0) lines += sum_total_lines(run);
     }
-    const ChunkDev ch = A.chunks[c];
-    const uint8_t* d = A.base + ch.offset;
     if (need_tail && ch.length) {
-      // the walk below is one lane reading byte by byte: pull the tail zone into the
-      // caches with one coalesced sweep of the whole wave first
-      const uint64_t Lr = (ch.length + 15u) & ~(uint64_t)15u;
-      for (uint64_t off = (tail_zone_begin(ch.length, A.pat.plen) & ~(uint64_t)15u) + (uint64_t)lane * kUnit; off < Lr;
-           off += kWaveLoad) {
-        const uint4 v = *reinterpret_cast<const uint4*>(d + off);
-        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-      }
-    }
-    if (need_tail) {
       // the line-mode entry point may lie a whole huge line away: found by the wave, not by lane 0 alone
       const uint64_t entry_lines = A.want_lines ? wave_walk_entry(d, ch.length, last_end, true, lane) : 0;
-      if (lane == 0) {
-        if (A.want_matches)
-          cm += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, last_end, false, nullptr, 0, A.pat.icase != 0);
-        if (A.want_lines)
-          lines += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, entry_lines, true, nullptr, 0, A.pat.icase != 0);
+      if (mask_tail) {
+        uint32_t nm = 0, nl = 0;
+        wave_tail_counts(d, ch.length, s_pat, A.pat.plen, A.pat.icase != 0, s_zone[wave], lane, A.want_matches != 0,
+                         last_end, A.want_lines != 0, entry_lines, &nm, &nl);
+        if (lane == 0) cm += nm, lines += nl;
+      } else {
+        // long patterns: the zone does not fit one position per lane.  One lane walks it byte by byte after a
+        // coalesced sweep of the whole wave has pulled the zone into the caches.
+        const uint64_t Lr = (ch.length + 15u) & ~(uint64_t)15u;
+        for (uint64_t off = (tail_zone_begin(ch.length, A.pat.plen) & ~(uint64_t)15u) + (uint64_t)lane * kUnit; off < Lr;
+             off += kWaveLoad) {
+          const uint4 v = *reinterpret_cast<const uint4*>(d + off);
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        }
+        if (lane == 0) {
+          if (A.want_matches)
+            cm += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, last_end, false, nullptr, 0, A.pat.icase != 0);
+          if (A.want_lines)
+            lines += tail_walk(d, ch.length, A.pat.d_pat, A.pat.plen, entry_lines, true, nullptr, 0, A.pat.icase != 0);
+        }
       }
     }
   }
+
+  // ---- per-block partial sums; the last block to arrive adds them up
   uint64_t t;
   t = block_sum_u64(cm, sh);
-  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_MATCHES], (unsigned long long)t);
+  if (threadIdx.x == 0) A.partials[3u * blockIdx.x + 0u] = t;
   t = block_sum_u64(lines, sh);
-  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_LINES], (unsigned long long)t);
+  if (threadIdx.x == 0) A.partials[3u * blockIdx.x + 1u] = t;
   t = block_sum_u64(cn, sh);
-  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&A.counters[XSG_CTR_NEWLINES], (unsigned long long)t);
-  if (gid == 0) A.counters[XSG_CTR_BYTES] = A.total_bytes;  // known on the host: no fan-in of atomics for it
+  if (threadIdx.x == 0) {
+    A.partials[3u * blockIdx.x + 2u] = t;
+    __threadfence();  // partials before the ticket
+    s_is_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  if (!s_is_last) return;
+  __threadfence();
+  uint64_t a0 = 0, a1 = 0, a2 = 0;
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += kBlock) {
+    a0 += __hip_atomic_load(A.partials + 3u * b + 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a1 += __hip_atomic_load(A.partials + 3u * b + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a2 += __hip_atomic_load(A.partials + 3u * b + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  a0 = block_sum_u64(a0, sh);
+  a1 = block_sum_u64(a1, sh);
+  a2 = block_sum_u64(a2, sh);
+  if (threadIdx.x == 0) {
+    A.counters[XSG_CTR_MATCHES] = a0;
+    A.counters[XSG_CTR_LINES] = a1;
+    A.counters[XSG_CTR_NEWLINES] = a2;
+    A.counters[XSG_CTR_BYTES] = A.total_bytes;  // known on the host
+    if (A.host_counters) {
+      A.host_counters[XSG_CTR_MATCHES] = a0;
+      A.host_counters[XSG_CTR_LINES] = a1;
+      A.host_counters[XSG_CTR_NEWLINES] = a2;
+      A.host_counters[XSG_CTR_BYTES] = A.total_bytes;
+    }
+    *A.ticket = 0u;  // at rest for the next launch (stream order)
+  }
 }
 
 hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s) {
   // enough workgroups that every chunk gets its own wave (the per-chunk part is a
-  // chain of dependent loads: latency-bound), capped so that the atomics stay few
+  // chain of dependent loads: latency-bound) and that a thread sums ~8 tiles
   uint64_t blocks = (a.nchunks + kWaves - 1) / kWaves;
-  const uint64_t for_tiles = (a.ntiles + (uint64_t)kBlock * 64 - 1) / ((uint64_t)kBlock * 64);
+  const uint64_t for_tiles = (a.ntiles + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
   if (for_tiles > blocks) blocks = for_tiles;
   if (blocks < 1) blocks = 1;
   if (blocks > kFinishBlocks) blocks = kFinishBlocks;

@@ -34,8 +34,10 @@ const char* last_error_message();
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
-  int ensure(size_t bytes) {
+  // *grew (optional) is set when the buffer was (re)allocated: its old contents are gone
+  int ensure(size_t bytes, bool* grew = nullptr) {
     if (bytes <= cap && p) return XSG_OK;
+    if (grew) *grew = true;
     if (bytes == 0) bytes = 16;
     // grow geometrically so that repeated searches with slowly growing results do not re-allocate
     size_t want = std::max(bytes, cap + cap / 2);
@@ -91,13 +93,33 @@ struct xsg_shard {
   uint32_t tile_bytes = xsg::kDefaultTileBytes;
   uint64_t total_bytes = 0;
   uint64_t shard_line_base = 0;
+  uint32_t tune = xsg::kTuneAuto;  // wave stagger chosen by xsg_shard_tune (kTuneAuto: per variant / ctx override)
 
   DevBuf d_chunks, d_tile_chunk, d_chunk_tile0;
   DevBuf d_tile_cnt, d_tile_nl, d_tile_sum, d_tile_last, d_counters;
+  DevBuf d_finish;  // k_count_finish scratch: 3 x kFinishBlocks partial sums, then the ticket word
   DevBuf d_tile_off, d_tile_nl_off, d_scan_tmp;
   DevBuf d_m_pos, d_m_chunk, d_m_ls, d_keep, d_keep_pre;
   DevBuf d_chunk_shift0, d_tail_cnt, d_tail_pos, d_tail_pre;
   DevBuf d_f_pos, d_f_match, d_f_chunk, d_out_u64, d_line_len, d_line_off, d_line_bytes;
+
+  // State of the per-tile arrays between passes (host-side bookkeeping; see ScanArgs).  A count pass leaves
+  // tile_cnt / tile_sum clean (k_count_finish zeroes what it read); a list pass or a timing loop leaves them
+  // dirty and the next pass pays one memset.  tile_last is never cleaned: passes are told apart by `epoch`.
+  bool cnt_clean = false, sum_clean = false, last_valid = false;
+  uint32_t epoch = 0;
+  // The newline counts per tile do not depend on the pattern: computed by the first pass that needs them
+  // (k_scan<WANT_NL>), kept until the shard is re-bound; later XSG_LINE_INDICES / XSG_WITH_NEWLINES passes run
+  // the plain kernel.
+  bool nl_cached = false, nl_off_cached = false;
+
+  // chunk table upload without a host sync (one-chunk shards: the file pipeline re-binds per chunk)
+  void* h_stage = nullptr;  // pinned
+  hipEvent_t table_ev = nullptr;
+  bool table_pending = false;  // an upload has been enqueued on the ctx stream since the last sync
+  uint64_t* h_counters = nullptr;  // pinned mirror of the four counters (xsg_count reads it after the stream sync)
+  bool begin_sync_result = false;  // xsg_count_begin had to run synchronously: _end hands out begin_counters
+  uint64_t begin_counters[XSG_NUM_COUNTERS] = {0, 0, 0, 0};
 
   int last_mode = -1;
   uint64_t total = 0;       // elements of the last list search
@@ -107,10 +129,16 @@ struct xsg_shard {
 
   void release_all() {
     DevBuf* all[] = {&d_chunks, &d_tile_chunk, &d_chunk_tile0, &d_tile_cnt, &d_tile_nl, &d_tile_sum, &d_tile_last,
-                     &d_counters, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls, &d_keep,
-                     &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
+                     &d_counters, &d_finish, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls,
+                     &d_keep, &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
                      &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes};
     for (DevBuf* b : all) b->release();
+    if (h_stage) (void)hipHostFree(h_stage);
+    if (h_counters) (void)hipHostFree(h_counters);
+    if (table_ev) (void)hipEventDestroy(table_ev);
+    h_stage = nullptr;
+    h_counters = nullptr;
+    table_ev = nullptr;
   }
 };
 

@@ -106,6 +106,67 @@ XSG_HD uint32_t tail_walk(const uint8_t* d, uint64_t L, const uint8_t* pat, uint
   return n;
 }
 
+// ---------------------------------------------------------------------------
+// The same walk on bit masks (k_count_finish: one wave per chunk).
+// A zone of at most 64 positions (plen <= kTailMaskMaxPlen): position i stands for
+// offset Z + i.  Per position, decided by 64 lanes in parallel:
+//   K[i]  = number of leading pattern bytes that match at Z+i (0 if fewer than plen
+//           bytes remain: the scalar search gives up there, simd_search.cpp:62)
+//   full  = bit i <=> K[i] == plen,  nz = bit i <=> K[i] > 0,  nlm = bit i <=> d[Z+i] == '\n'
+// The lossy scalar search then never looks at bytes: from `cur` it slides over
+// positions with K == 0 one by one (next candidate = lowest nz bit at or above cur),
+// and at a position with 0 < K < plen it resumes K+1 bytes further on -- exactly
+// scalar_strstr's `shift = str_index` (:75).  The chain has one step per VISITED
+// partial match, not per byte.  k_at(i) returns K[i] (device: v_readlane).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kTailMaskMaxPlen = 33;  // plen + 31 <= 64 positions
+
+XSG_HD uint64_t bits_from(uint32_t i) { return i >= 64 ? 0ull : ~0ull << i; }  // bits [i, 64)
+
+template <typename KAt>
+XSG_HD int64_t lossy_scalar_find_masks(uint64_t cur, uint64_t L, uint64_t Z, uint32_t plen, uint64_t full, uint64_t nz,
+                                       KAt k_at) {
+  for (;;) {
+    if (cur >= L || L - cur < plen) return -1;
+    const uint64_t above = nz & bits_from((uint32_t)(cur - Z));
+    if (!above) return -1;  // only mismatches at the first byte up to where the room ends
+    const uint32_t j = (uint32_t)__builtin_ctzll(above);
+    if ((full >> j) & 1ull) return (int64_t)(Z + j);
+    cur = Z + j + (uint64_t)k_at(j) + 1u;
+  }
+}
+
+template <typename KAt>
+XSG_HD uint32_t tail_walk_masks(uint64_t L, uint32_t plen, uint64_t shift0, bool skip_to_nl, uint64_t full, uint64_t nz,
+                                uint64_t nlm, KAt k_at) {
+  if (plen <= 1 || shift0 == UINT64_MAX) return 0;
+  const uint64_t Z = tail_zone_begin(L, plen);
+  uint32_t n = 0;
+  uint64_t shift = shift0;
+  while (shift < L) {
+    // tail_find_next
+    int64_t m;
+    const uint64_t R = L - shift;
+    if (R < 32u + (uint64_t)plen) {
+      m = lossy_scalar_find_masks(shift, L, Z, plen, full, nz, k_at);  // shift >= Z here
+    } else {
+      const uint64_t T = shift + 32u * ((R - plen) / 32u);
+      const uint64_t a = shift > Z ? shift : Z;
+      const uint64_t exact = a < T ? (full & bits_from((uint32_t)(a - Z)) & ~bits_from((uint32_t)(T - Z))) : 0ull;
+      m = exact ? (int64_t)(Z + (uint32_t)__builtin_ctzll(exact)) : lossy_scalar_find_masks(T, L, Z, plen, full, nz, k_at);
+    }
+    if (m < 0) break;
+    ++n;
+    shift = (uint64_t)m + plen;
+    if (skip_to_nl) {
+      const uint64_t after = shift >= L ? 0ull : (nlm & bits_from((uint32_t)(shift - Z)));
+      if (!after) break;
+      shift = Z + (uint32_t)__builtin_ctzll(after) + 1u;
+    }
+  }
+  return n;
+}
+
 // Upper bound on matches tail_walk can return: they are >= plen apart in a
 // zone of plen+31 bytes.
 XSG_HD uint32_t tail_max_matches(uint32_t plen) { return plen <= 1 ? 0u : (plen + 31u) / plen + 1u; }

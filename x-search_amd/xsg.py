@@ -106,6 +106,8 @@ def load():
         "xsg_shard_set_line_base": (ci, [vp, u64]),
         "xsg_count_async": (ci, [vp, u32, vp, vp]),
         "xsg_count": (ci, [vp, u32, _u64p]),
+        "xsg_count_begin": (ci, [vp, u32]),
+        "xsg_count_end": (ci, [vp, _u64p]),
         "xsg_search": (ci, [vp, u32, _u64p]),
         "xsg_result_u64": (ci, [vp, _u64p, u64]),
         "xsg_result_lines_size": (ci, [vp, _u64p, _u64p]),
@@ -133,6 +135,8 @@ def load():
         "xsg_ctx_info": (ci, [vp, C.c_char_p, sz, C.POINTER(ci), _u64p]),
         "xsg_time_scan_kernel": (ci, [vp, u32, ci, C.POINTER(C.c_float)]),
         "xsg_time_read_ceiling": (ci, [vp, ci, C.POINTER(C.c_float), _u64p]),
+        "xsg_scan_kernel_name": (ci, [vp, u32, C.c_char_p, sz]),
+        "xsg_shard_tune": (ci, [vp, u32, C.POINTER(u32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -149,7 +153,8 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_job_opts_init", "xsg_job_start", "xsg_job_join", "xsg_job_destroy", "xsg_job_total", "xsg_job_wait", "xsg_job_poll",
            "xsg_job_get_u64", "xsg_job_get_line", "xsg_job_stats_get", "xsg_plan_chunks", "xsg_meta_read",
            "xsg_meta_write", "xsg_free", "xsg_host_searcher_create", "xsg_host_searcher_destroy", "xsg_host_count",
-           "xsg_host_offsets", "xsg_host_lines"]
+           "xsg_host_offsets", "xsg_host_lines", "xsg_scan_kernel_name", "xsg_shard_tune", "xsg_count_begin",
+           "xsg_count_end"]
 
 
 def _check(rc):
@@ -256,6 +261,14 @@ class Shard:
         _check(self._lib.xsg_count(self.h, mode, out.ctypes.data_as(_u64p)))
         return out
 
+    def count_begin(self, mode: int):
+        _check(self._lib.xsg_count_begin(self.h, mode))
+
+    def count_end(self) -> np.ndarray:
+        out = np.zeros(NUM_COUNTERS, dtype=np.uint64)
+        _check(self._lib.xsg_count_end(self.h, out.ctypes.data_as(_u64p)))
+        return out
+
     def search_u64(self, mode: int) -> np.ndarray:
         n = C.c_uint64(0)
         _check(self._lib.xsg_search(self.h, mode, C.byref(n)))
@@ -285,6 +298,17 @@ class Shard:
         ms, nb = C.c_float(0), C.c_uint64(0)
         _check(self._lib.xsg_time_read_ceiling(self.h, iters, C.byref(ms), C.byref(nb)))
         return ms.value, nb.value
+
+    def scan_kernel_name(self, mode: int) -> str:
+        buf = C.create_string_buffer(160)
+        _check(self._lib.xsg_scan_kernel_name(self.h, mode, buf, 160))
+        return buf.value.decode()
+
+    def tune(self, mode: int) -> int | None:
+        """measure and fix the wave stagger for this shard/pattern/mode; None = default kept"""
+        v = C.c_uint32(0)
+        _check(self._lib.xsg_shard_tune(self.h, mode, C.byref(v)))
+        return None if v.value == 0xFFFFFFFF else int(v.value)
 
     def time_scan_kernel(self, mode: int, iters: int) -> float:
         ms = C.c_float(0)
