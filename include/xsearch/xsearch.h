@@ -215,6 +215,9 @@ struct JobSet {
   std::vector<xsg_job*> jobs;
   bool is_count = false;
   bool add_newline_base = false;  // xs::line_indices without a metafile
+  bool reduced = false;           // count tags, several devices, after join(): reduced_total is the exchanged sum
+  bool reduced_via_rccl = false;
+  uint64_t reduced_total = 0;
   mutable std::mutex _mu;
   mutable std::vector<uint64_t> _carry;
 
@@ -340,6 +343,7 @@ class Result {
   // count tags: the count (so far; final after join()).  Vector tags: number of
   // elements available so far.  (test/src/xsearchTest.cpp:346)
   size_t size() const {
+    if (_set->reduced) return static_cast<size_t>(_set->reduced_total);
     uint64_t sum = 0;
     for (xsg_job* j : _set->jobs) {
       uint64_t t = 0;
@@ -444,7 +448,20 @@ class ExternSearcher {
     }
     if (first != XSG_OK)
       throw std::runtime_error(std::string("xs::ExternSearcher::join: ") + xsg_strerror(first) + " (" + msg + ")");
+    // several devices: the count is the one thing they exchange -- an RCCL all-reduce of the per-device totals
+    // (xsg_jobs_reduce_total; host addition when there is no librccl or a device is listed twice)
+    if (_set.is_count && _set.jobs.size() > 1 && !_set.reduced) {
+      uint64_t total = 0;
+      int via = 0;
+      const int r = xsg_jobs_reduce_total(_set.jobs.data(), (int)_set.jobs.size(), &total, &via);
+      if (r != XSG_OK) detail::throw_last("xs::ExternSearcher::join", r);
+      _set.reduced_total = total;
+      _set.reduced_via_rccl = via != 0;
+      _set.reduced = true;
+    }
   }
+  // after join(): did the devices' counts meet over RCCL (true) or were they added on the host (false)?
+  bool reduced_over_rccl() const { return _set.reduced && _set.reduced_via_rccl; }
   ResultT* getResult() { return _result.get(); }
   bool running() const { return !_result->is_closed(); }
   size_t num_devices() const { return _set.jobs.size(); }

@@ -318,6 +318,45 @@ int xsg_meta_write(const char* file_path, const char* meta_out_path, const char*
                    uint64_t chunk_bytes, uint64_t mapping_gap, int hc);
 void xsg_free(void* p);
 
+/* ======================================================================== */
+/* Multi-GPU: the one exchange step, RCCL over xGMI                           */
+/* ======================================================================== */
+/* The reference's only parallelism is N threads over chunks (include/xsearch/Searcher.h:141-145).  Across GPUs
+ * the chunk list is cut into contiguous ranges (xsg_job_opts.chunk_begin/_end, or one shard per device) and
+ * searched with no data-path collective; what is exchanged once per search is
+ *   - the counter vector (xs::count / xs::count_lines): ncclAllReduce(sum) of XSG_NUM_COUNTERS uint64
+ *   - one uint64 per device, its '\n' total (xs::line_indices without a metafile): ncclAllGather
+ * 8-32 byte messages: latency-bound.  librccl is bound at run time (the copy the process already carries --
+ * e.g. PyTorch-ROCm's -- else the system's); without one the create calls return XSG_ENOTSUP and the caller sums
+ * on the host instead (include/xsearch/xsearch.h does exactly that). */
+typedef struct xsg_comm xsg_comm;
+#define XSG_COMM_ID_BYTES 128
+/* rank form (one process per GPU): rank 0 makes an id, hands it to the others by any means (file, socket,
+ * torch.distributed store), every rank then creates its end. */
+int xsg_comm_unique_id(void* id, size_t cap);
+int xsg_comm_create_rank(xsg_ctx* ctx, int nranks, int rank, const void* id, xsg_comm** out);
+/* local form (one process, n GPUs): one communicator over the devices of ctxs[0..n), all distinct. */
+int xsg_comm_create_local(xsg_ctx* const* ctxs, int n, xsg_comm** out);
+void xsg_comm_destroy(xsg_comm* comm);
+int xsg_comm_size(xsg_comm* comm, int* nranks, int* rank /* -1 in the local form */);
+/* path of the librccl in use ("" if none) */
+const char* xsg_comm_library(void);
+/* rank form: in-place sum over the ranks of k uint64 device words (e.g. what xsg_count_async wrote), enqueued
+ * on `stream` (a hipStream_t; NULL = the ctx's own) -- stream-ordered behind the count that produced them. */
+int xsg_reduce_counts_async(xsg_comm* comm, uint64_t* d_counters, int k, void* stream);
+/* either form, blocking: totals[0..k) = the sums; the device vectors are left summed in place.
+ * rank form: d_counters[0] is this rank's vector; local form: d_counters[i] lives on ctxs[i]'s device. */
+int xsg_reduce_counts(xsg_comm* comm, uint64_t* const* d_counters, int k, uint64_t* totals);
+/* either form, blocking: out[0..nranks) = every rank's / device's value in rank order (mine[0], or mine[i] for
+ * ctxs[i]); the exclusive prefix -- the line-index base of each range -- is the caller's to take. */
+int xsg_allgather_u64(xsg_comm* comm, const uint64_t* mine, uint64_t* out);
+
+/* The count of a search that fanned out over several devices (one job each, contiguous chunk ranges): the sum of
+ * the jobs' totals, exchanged over RCCL (one ncclAllReduce of one uint64 over a per-process communicator of the
+ * jobs' devices, created at first use).  *via_rccl (optional) = 1 if it went that way, 0 if the sum was taken on
+ * the host instead: no librccl, a device listed twice, a single job, or XS_REDUCE=host.  Call after the joins. */
+int xsg_jobs_reduce_total(xsg_job* const* jobs, int n, uint64_t* total, int* via_rccl);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 /* Name of the device the ctx is bound to (e.g. "gfx950..."), CU count. */
 int xsg_ctx_info(xsg_ctx* ctx, char* arch, size_t arch_cap, int* compute_units, uint64_t* hbm_bytes);

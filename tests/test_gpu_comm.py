@@ -1,0 +1,110 @@
+"""The library's own RCCL step (include/xsg.h, "Multi-GPU"; x-search_amd/csrc/xsg_comm.cpp): the counter vector of a
+count pass summed over the devices by ncclAllReduce, newline totals gathered by ncclAllGather.  On the one-GPU test
+box the clique has one member (RCCL still initialises, launches and completes its kernels); with two or more visible
+devices the same calls run over a real clique.  The reference has no distributed backend to compare with:
+the check is the arithmetic -- the exchanged sum equals the sum of the per-device results, which equal the oracle's."""
+import numpy as np
+import pytest
+
+import corpus
+import xsg
+
+pytestmark = pytest.mark.gpu
+
+
+def _shard_on(dev, blocks):
+    import torch
+    lengths = [int(b.size) for b in blocks]
+    off, ln, cap = corpus.chunk_table(lengths)
+    host = np.zeros(max(cap, 256), dtype=np.uint8)
+    for o, b in zip(off, blocks):
+        host[int(o):int(o) + b.size] = b
+    t = torch.from_numpy(host).to(f"cuda:{dev}")
+    ctx = xsg.Context(dev)
+    ctx.set_pattern(b"Sherlock")
+    sh = xsg.Shard(ctx, t.data_ptr(), t.numel(), xsg.make_chunks(off, ln))
+    return t, ctx, sh
+
+
+@pytest.fixture(scope="module")
+def blocks():
+    return [corpus.text_block(77, i, 300_000 + 17 * i, needle_rate=2e-4) for i in range(6)]
+
+
+def test_rccl_is_found():
+    assert "rccl" in xsg.comm_library()
+    assert len(xsg.comm_unique_id()) == xsg.COMM_ID_BYTES
+
+
+def test_local_clique_sums_the_counter_vectors(blocks, oracle):
+    import torch
+    ndev = min(xsg.device_count(), 4)
+    per = [blocks[d::ndev] for d in range(ndev)]  # device d's chunk range (any split: the sum is what matters)
+    keep, ctxs, shards, ctrs = [], [], [], []
+    for d in range(ndev):
+        t, ctx, sh = _shard_on(d, per[d])
+        keep.append(t)
+        ctxs.append(ctx)
+        shards.append(sh)
+        ctrs.append(torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device=f"cuda:{d}"))
+    comm = xsg.Comm.local(ctxs)
+    assert comm.size() == (ndev, -1)
+    local = []
+    for d in range(ndev):
+        shards[d].count_async(xsg.COUNT_MATCHES | xsg.WITH_NEWLINES, 0, ctrs[d].data_ptr())  # NULL stream = the ctx's own
+    for d in range(ndev):
+        torch.cuda.synchronize(d)
+        local.append(ctrs[d].cpu().numpy().astype(np.uint64))
+    totals = comm.reduce_counts([c.data_ptr() for c in ctrs])
+    want_m = sum(oracle.count(b, b"Sherlock", False) for b in blocks)
+    want_nl = sum(int((b == 10).sum()) for b in blocks)
+    assert int(totals[xsg.CTR_MATCHES]) == want_m == int(sum(int(x[xsg.CTR_MATCHES]) for x in local))
+    assert int(totals[xsg.CTR_NEWLINES]) == want_nl
+    assert int(totals[xsg.CTR_BYTES]) == sum(b.size for b in blocks)
+    # newline totals per device -> line-index bases
+    mine = [int(x[xsg.CTR_NEWLINES]) for x in local]
+    assert comm.allgather_u64(mine).tolist() == mine
+    comm.close()
+
+
+def test_rank_form_single_rank(blocks, oracle):
+    import torch
+    t, ctx, sh = _shard_on(0, blocks)
+    comm = xsg.Comm.rank(ctx, 1, 0, xsg.comm_unique_id())
+    assert comm.size() == (1, 0)
+    c = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    s = torch.cuda.Stream()
+    sh.count_async(xsg.COUNT_MATCHES, s.cuda_stream, c.data_ptr())
+    comm.reduce_counts_async(c.data_ptr(), xsg.NUM_COUNTERS, s.cuda_stream)  # stream-ordered behind the count
+    s.synchronize()
+    assert int(c[xsg.CTR_MATCHES]) == sum(oracle.count(b, b"Sherlock", False) for b in blocks)
+    comm.close()
+
+
+def test_one_rank_per_gpu_is_enforced(blocks):
+    _, ctx, _ = _shard_on(0, blocks[:1])
+    ctx2 = xsg.Context(0)
+    with pytest.raises(xsg.XsgError) as e:
+        xsg.Comm.local([ctx, ctx2])
+    assert e.value.code == xsg.ENOTSUP
+
+
+def test_jobs_total_over_rccl_or_host(tmp_path, blocks, oracle):
+    """xs::extern_search over XS_DEVICES ends in xsg_jobs_reduce_total: over RCCL with >= 2 distinct devices,
+    on the host (and saying so) when a device is listed twice."""
+    p = tmp_path / "c.txt"
+    data = np.concatenate(blocks)
+    data.tofile(p)
+    want = sum(oracle.count(b, b"Sherlock", False) for b in blocks)
+    n = len(xsg.plan_chunks(str(p), 1 << 18))
+    ndev = xsg.device_count()
+    devs = [0, 1] if ndev >= 2 else [0, 0]
+    jobs = [xsg.Job(b"Sherlock", str(p), xsg.COUNT_MATCHES, device=d, chunk_bytes=1 << 18,
+                    chunk_range=(n * g // 2, n * (g + 1) // 2)) for g, d in enumerate(devs)]
+    for j in jobs:
+        j.join()
+    total, via = xsg.jobs_reduce_total(jobs)
+    assert total == want
+    assert via == (ndev >= 2)
+    for j in jobs:
+        j.close()

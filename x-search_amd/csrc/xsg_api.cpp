@@ -458,12 +458,14 @@ static int prepare_tiles(xsg_shard* s, bool want_lines, hipStream_t st) {
   xsg_ctx* c = s->ctx;
   const uint64_t nt = std::max<uint64_t>(s->ntiles, 1);
   if (s->table_pending && st != c->stream) HIP_TRY(hipStreamWaitEvent(st, s->table_ev, 0));
+  // A clean-up always covers the WHOLE allocation (the buffers grow geometrically): a later binding with more
+  // tiles that still fits must find the words beyond today's ntiles clean as well.
   if (!s->cnt_clean) {
-    HIP_TRY(hipMemsetAsync(s->d_tile_cnt.p, 0, 4 * nt, st));
+    HIP_TRY(hipMemsetAsync(s->d_tile_cnt.p, 0, s->d_tile_cnt.cap, st));
     s->cnt_clean = true;
   }
   if (!s->last_valid || s->epoch >= 0xffffu) {
-    HIP_TRY(hipMemsetAsync(s->d_tile_last.p, 0, 4 * nt, st));
+    HIP_TRY(hipMemsetAsync(s->d_tile_last.p, 0, s->d_tile_last.cap, st));
     s->last_valid = true;
     s->epoch = 0;
   }
@@ -473,7 +475,7 @@ static int prepare_tiles(xsg_shard* s, bool want_lines, hipStream_t st) {
     XSG_TRY(s->d_tile_sum.ensure(4 * kWaves * nt, &grew));
     if (grew) s->sum_clean = false;
     if (!s->sum_clean) {
-      HIP_TRY(hipMemsetAsync(s->d_tile_sum.p, 0, 4 * kWaves * nt, st));
+      HIP_TRY(hipMemsetAsync(s->d_tile_sum.p, 0, s->d_tile_sum.cap, st));
       s->sum_clean = true;
     }
   }

@@ -1117,6 +1117,100 @@ extern "C" int xsg_job_stats_get(xsg_job* j, xsg_job_stats* stats) {
 
 
 // ---------------------------------------------------------------------------
+// several jobs of one search (one per device): the count is the sum of their totals.  That sum is the search's one
+// exchange step and goes over RCCL: every job's total is put into a word on its own GPU, one ncclAllReduce over a
+// per-process communicator of those devices (ncclCommInitAll, kept for the life of the process: creating one costs
+// far more than the 8-byte exchange), and the result is read back from the first device.  Falls back to adding on
+// the host -- and says so through *via_rccl -- when there is no librccl, when a device is listed twice (RCCL
+// wants one rank per GPU), or when XS_REDUCE=host.
+// ---------------------------------------------------------------------------
+namespace {
+struct LocalClique {
+  std::vector<int> devices;
+  std::vector<xsg_ctx*> ctxs;
+  std::vector<uint64_t*> d_word;
+  xsg_comm* comm = nullptr;
+};
+std::mutex g_clique_mu;
+std::vector<LocalClique*>& cliques() {
+  static std::vector<LocalClique*>* v = new std::vector<LocalClique*>();  // never torn down (see slot_pool)
+  return *v;
+}
+
+int clique_for(const std::vector<int>& devices, LocalClique** out) {
+  for (LocalClique* c : cliques())
+    if (c->devices == devices) {
+      *out = c;
+      return XSG_OK;
+    }
+  std::unique_ptr<LocalClique> c(new LocalClique());
+  c->devices = devices;
+  int r = XSG_OK;
+  for (int d : devices) {
+    xsg_ctx* x = nullptr;
+    r = xsg_ctx_create(d, &x);
+    if (r != XSG_OK) break;
+    c->ctxs.push_back(x);
+    void* p = nullptr;
+    if (hipSetDevice(d) != hipSuccess || hipMalloc(&p, 64) != hipSuccess) {
+      r = fail(XSG_ENOMEM, "hipMalloc on device %d failed", d);
+      break;
+    }
+    c->d_word.push_back(static_cast<uint64_t*>(p));
+  }
+  if (r == XSG_OK) r = xsg_comm_create_local(c->ctxs.data(), (int)c->ctxs.size(), &c->comm);
+  if (r != XSG_OK) {
+    for (size_t i = 0; i < c->d_word.size(); ++i) {
+      (void)hipSetDevice(devices[i]);
+      (void)hipFree(c->d_word[i]);
+    }
+    for (xsg_ctx* x : c->ctxs) xsg_ctx_destroy(x);
+    return r;
+  }
+  cliques().push_back(c.get());
+  *out = c.release();
+  return XSG_OK;
+}
+}  // namespace
+
+extern "C" int xsg_jobs_reduce_total(xsg_job* const* jobs, int n, uint64_t* total, int* via_rccl) {
+  if (!jobs || n < 1 || !total) return fail(XSG_EINVAL, "bad argument");
+  return guarded("xsg_jobs_reduce_total", [&]() -> int {
+    if (via_rccl) *via_rccl = 0;
+    uint64_t host_sum = 0;
+    std::vector<int> devices;
+    std::vector<uint64_t> totals;
+    bool distinct = true;
+    for (int i = 0; i < n; ++i) {
+      if (!jobs[i]) return fail(XSG_EINVAL, "job %d is null", i);
+      uint64_t t = 0;
+      XSG_TRY(xsg_job_total(jobs[i], &t));
+      host_sum += t;
+      totals.push_back(t);
+      for (int d : devices) distinct &= d != jobs[i]->opts.device;
+      devices.push_back(jobs[i]->opts.device);
+    }
+    *total = host_sum;
+    const char* how = getenv("XS_REDUCE");
+    if (n < 2 || !distinct || (how && strcmp(how, "host") == 0)) return XSG_OK;
+    std::lock_guard<std::mutex> g(g_clique_mu);
+    LocalClique* c = nullptr;
+    if (clique_for(devices, &c) != XSG_OK) return XSG_OK;  // no librccl / init refused: the host sum stands
+    for (int i = 0; i < n; ++i) {
+      HIP_TRY(hipSetDevice(devices[i]));
+      HIP_TRY(hipMemcpyAsync(c->d_word[i], &totals[i], 8, hipMemcpyHostToDevice, c->ctxs[i]->stream));
+    }
+    uint64_t sum = 0;
+    XSG_TRY(xsg_reduce_counts(c->comm, c->d_word.data(), 1, &sum));
+    if (sum != host_sum)
+      return fail(XSG_EHIP, "RCCL sum %llu differs from the host sum %llu", (unsigned long long)sum,
+                  (unsigned long long)host_sum);
+    if (via_rccl) *via_rccl = 1;
+    return XSG_OK;
+  });
+}
+
+// ---------------------------------------------------------------------------
 // the lower seam: chunks in host memory (reference-style searcher functors)
 // ---------------------------------------------------------------------------
 struct HostSlot {

@@ -135,6 +135,16 @@ def load():
         "xsg_ctx_info": (ci, [vp, C.c_char_p, sz, C.POINTER(ci), _u64p]),
         "xsg_time_scan_kernel": (ci, [vp, u32, ci, C.POINTER(C.c_float)]),
         "xsg_time_read_ceiling": (ci, [vp, ci, C.POINTER(C.c_float), _u64p]),
+        "xsg_comm_unique_id": (ci, [vp, sz]),
+        "xsg_comm_create_rank": (ci, [vp, ci, ci, vp, C.POINTER(vp)]),
+        "xsg_comm_create_local": (ci, [C.POINTER(vp), ci, C.POINTER(vp)]),
+        "xsg_comm_destroy": (None, [vp]),
+        "xsg_comm_size": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
+        "xsg_comm_library": (C.c_char_p, []),
+        "xsg_reduce_counts_async": (ci, [vp, vp, ci, vp]),
+        "xsg_reduce_counts": (ci, [vp, C.POINTER(vp), ci, _u64p]),
+        "xsg_allgather_u64": (ci, [vp, _u64p, _u64p]),
+        "xsg_jobs_reduce_total": (ci, [C.POINTER(vp), ci, _u64p, C.POINTER(ci)]),
         "xsg_scan_kernel_name": (ci, [vp, u32, C.c_char_p, sz]),
         "xsg_shard_tune": (ci, [vp, u32, C.POINTER(u32)]),
     }
@@ -154,7 +164,9 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_job_get_u64", "xsg_job_get_line", "xsg_job_stats_get", "xsg_plan_chunks", "xsg_meta_read",
            "xsg_meta_write", "xsg_free", "xsg_host_searcher_create", "xsg_host_searcher_destroy", "xsg_host_count",
            "xsg_host_offsets", "xsg_host_lines", "xsg_scan_kernel_name", "xsg_shard_tune", "xsg_count_begin",
-           "xsg_count_end"]
+           "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
+           "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
+           "xsg_jobs_reduce_total"]
 
 
 def _check(rc):
@@ -314,6 +326,85 @@ class Shard:
         ms = C.c_float(0)
         _check(self._lib.xsg_time_scan_kernel(self.h, mode, iters, C.byref(ms)))
         return ms.value
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().xsg_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+def comm_library() -> str:
+    return load().xsg_comm_library().decode()
+
+
+def jobs_reduce_total(jobs) -> tuple[int, bool]:
+    """-> (sum of the count jobs' totals, whether it was exchanged over RCCL)"""
+    lib = load()
+    arr = (C.c_void_p * len(jobs))(*[j.h for j in jobs])
+    tot, via = C.c_uint64(0), C.c_int(0)
+    _check(lib.xsg_jobs_reduce_total(arr, len(jobs), C.byref(tot), C.byref(via)))
+    return tot.value, bool(via.value)
+
+
+class Comm:
+    """RCCL communicator of the library (include/xsg.h, 'Multi-GPU').  Rank form: Comm.rank(ctx, nranks, rank, id);
+    local form: Comm.local([ctx0, ctx1, ...])."""
+
+    def __init__(self, h, ctxs, lib):
+        self.h, self.ctxs, self._lib = h, ctxs, lib
+
+    @classmethod
+    def rank(cls, ctx: "Context", nranks: int, rank: int, uid: bytes):
+        lib = load()
+        h = C.c_void_p()
+        _check(lib.xsg_comm_create_rank(ctx.h, nranks, rank, uid, C.byref(h)))
+        return cls(h, [ctx], lib)
+
+    @classmethod
+    def local(cls, ctxs):
+        lib = load()
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        h = C.c_void_p()
+        _check(lib.xsg_comm_create_local(arr, len(ctxs), C.byref(h)))
+        return cls(h, list(ctxs), lib)
+
+    def size(self):
+        n, r = C.c_int(0), C.c_int(0)
+        _check(self._lib.xsg_comm_size(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def reduce_counts_async(self, d_counters: int, k: int, stream: int):
+        _check(self._lib.xsg_reduce_counts_async(self.h, C.c_void_p(d_counters), k, C.c_void_p(stream)))
+
+    def reduce_counts(self, d_counters, k: int = NUM_COUNTERS) -> np.ndarray:
+        """d_counters: device address (rank form) or one per local device"""
+        ptrs = [d_counters] if isinstance(d_counters, int) else list(d_counters)
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        out = np.zeros(k, dtype=np.uint64)
+        _check(self._lib.xsg_reduce_counts(self.h, arr, k, out.ctypes.data_as(_u64p)))
+        return out
+
+    def allgather_u64(self, mine) -> np.ndarray:
+        mine = np.ascontiguousarray(np.atleast_1d(mine), dtype=np.uint64)
+        n, _ = self.size()
+        out = np.zeros(n, dtype=np.uint64)
+        _check(self._lib.xsg_allgather_u64(self.h, mine.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p)))
+        return out
+
+    def close(self):
+        if self.h:
+            self._lib.xsg_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---------------------------------------------------------------------------
