@@ -351,6 +351,11 @@ int xsg_reduce_counts(xsg_comm* comm, uint64_t* const* d_counters, int k, uint64
  * ctxs[i]); the exclusive prefix -- the line-index base of each range -- is the caller's to take. */
 int xsg_allgather_u64(xsg_comm* comm, const uint64_t* mine, uint64_t* out);
 
+/* NUMA placement of a device: its node (-1 if the platform does not say) and the CPUs next to it (the PCI device's
+ * local_cpulist, e.g. "0-63,128-191").  The reader and device-worker threads of a job are bound to those CPUs
+ * (XSG_NUMA=0 switches that off); its pinned buffers are allocated on that node by hipHostMalloc. */
+int xsg_device_numa(int device, int* node, char* cpulist, size_t cap);
+
 /* The count of a search that fanned out over several devices (one job each, contiguous chunk ranges): the sum of
  * the jobs' totals, exchanged over RCCL (one ncclAllReduce of one uint64 over a per-process communicator of the
  * jobs' devices, created at first use).  *via_rccl (optional) = 1 if it went that way, 0 if the sum was taken on

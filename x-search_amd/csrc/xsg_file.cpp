@@ -3,8 +3,11 @@
 // reference's pipeline is C++: include/xsearch/Searcher.h, tasks/readers.h,
 // ResultTypes.h); the scan itself always runs on the GPU through the shard API
 // of xsg_api.cpp -- there is no CPU search path in here.
+#include <ctype.h>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -666,6 +669,83 @@ static void bufs_release(xsg_job* j) {
   j->all_bufs.clear();
 }
 
+// ---- NUMA: the feeder threads of a device run on the CPUs next to it -------------------------------
+// one reader/feeder group per GPU with NUMA-local pinned buffers.  The pinned buffers already are
+// (hipHostMalloc places them on the node nearest the current device unless hipHostMallocNumaUser is given); the
+// threads that fill and drain them are bound here to that node's CPUs, read from the PCI device's
+// local_cpulist, intersected with what the process may use.  XSG_NUMA=0 switches the binding off.
+static bool parse_cpulist(const char* text, cpu_set_t* out) {
+  CPU_ZERO(out);
+  const char* p = text;
+  bool any = false;
+  while (*p) {
+    char* end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') {
+      b = strtol(p + 1, &end, 10);
+      if (end == p + 1) break;
+      p = end;
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (c >= 0) CPU_SET((int)c, out), any = true;
+    if (*p == ',') ++p;
+    else break;
+  }
+  return any;
+}
+
+static int device_pci_file(int device, const char* leaf, char* buf, size_t cap) {
+  char bdf[64] = "";
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return -1;
+  for (char* q = bdf; *q; ++q) *q = (char)tolower((unsigned char)*q);
+  char path[160];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/%s", bdf, leaf);
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  const size_t n = fread(buf, 1, cap - 1, f);
+  fclose(f);
+  buf[n] = 0;
+  while (n && (buf[strlen(buf) - 1] == '\n' || buf[strlen(buf) - 1] == ' ')) buf[strlen(buf) - 1] = 0;
+  return 0;
+}
+
+// CPUs local to the device that this process may run on; false = no usable information (or XSG_NUMA=0)
+static bool device_cpuset(int device, cpu_set_t* out) {
+  const char* env = getenv("XSG_NUMA");
+  if (env && *env == '0') return false;
+  char text[1024];
+  if (device_pci_file(device, "local_cpulist", text, sizeof text) != 0) return false;
+  cpu_set_t local, mine;
+  if (!parse_cpulist(text, &local)) return false;
+  if (sched_getaffinity(0, sizeof mine, &mine) != 0) return false;
+  CPU_AND(out, &local, &mine);
+  return CPU_COUNT(out) > 0 && CPU_COUNT(out) < CPU_COUNT(&mine);  // nothing to do when it is the whole set anyway
+}
+
+static void bind_thread_to_device(int device) {
+  cpu_set_t set;
+  if (device_cpuset(device, &set)) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+
+extern "C" int xsg_device_numa(int device, int* node, char* cpulist, size_t cap) {
+  int n = 0;
+  XSG_TRY(xsg_device_count(&n));
+  if (device < 0 || device >= n) return fail(XSG_ENODEV, "device %d out of range", device);
+  char text[1024] = "";
+  if (node) {
+    *node = -1;
+    if (device_pci_file(device, "numa_node", text, sizeof text) == 0) *node = atoi(text);
+  }
+  if (cpulist && cap) {
+    cpulist[0] = 0;
+    if (device_pci_file(device, "local_cpulist", text, sizeof text) == 0) snprintf(cpulist, cap, "%s", text);
+  }
+  return XSG_OK;
+}
+
 // ---- stage 1: read (+ decompress) into a pinned buffer ------------------------
 static void reader_loop(xsg_job* j, double& t_read, double& t_dec, uint64_t& rbytes) {
   while (!j->stop.load()) {
@@ -716,6 +796,7 @@ static void reader_loop(xsg_job* j, double& t_read, double& t_dec, uint64_t& rby
 static void reader_main(xsg_job* j) {
   double t_read = 0, t_dec = 0;
   uint64_t rbytes = 0;
+  bind_thread_to_device(j->opts.device);
   try {
     reader_loop(j, t_read, t_dec, rbytes);
   } catch (const std::bad_alloc&) {
@@ -883,6 +964,7 @@ static void worker_body(xsg_job* j, double& t_dev, uint64_t& bytes, uint64_t& ch
 static void worker_main(xsg_job* j) {
   double t_dev = 0;
   uint64_t bytes = 0, chunks = 0;
+  bind_thread_to_device(j->opts.device);
   try {
     worker_body(j, t_dev, bytes, chunks);
   } catch (const std::bad_alloc&) {  // nothing may leave a thread body (or the extern "C" boundary) as an exception

@@ -353,7 +353,8 @@ __device__ __forceinline__ uint32_t cand_mask16(const uint32_t (&d)[8], const Pa
 // starts P.koff bytes earlier (koff is 0 except for long patterns).
 template <int KIND, bool ICASE>
 __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const PatternDev& P, const uint8_t* cbase,
-                                                 uint64_t unit_off, uint64_t limit, const uint8_t* lds_pat) {
+                                                 uint64_t unit_off, uint64_t limit, const uint8_t* lds_pat,
+                                                 uint8_t* lds_view) {
   uint32_t m = cand_mask16<KIND>(d, P);
   const uint32_t koff = KIND >= kLong ? P.koff : 0u;
   // the match starts at o = window - koff and must satisfy 0 <= o < limit
@@ -378,19 +379,50 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
     }
   }
   if (KIND == kClass) {
-    // the window compare saw only the literal bytes: every position against its byte set (LDS, 8 dwords each)
+    // The window compare saw only the bits the members of each set agree on: now every position of the candidate
+    // against its 256-bit set in LDS (8 dwords per position).  A candidate whose bytes all lie in the lane's
+    // 32-byte view (own unit + the next one, d[0..8)) is decided without touching memory and without an early
+    // exit, so the LDS reads of all positions are in flight together.  (Byte
+    // loads from global memory with an early exit -- the first version -- cost a microsecond per candidate:
+    // `She[r ]lock`, which really occurs every few KiB of the bench corpus, ran at 4.6 TB/s.)  Other candidates
+    // (match starts before the unit, expressions over kRegVerify positions) read memory, also without an early exit.
+    constexpr uint32_t kRegVerify = 12;
     const uint32_t* sets = reinterpret_cast<const uint32_t*>(lds_pat);
+    // the lane's view goes to its 48-byte slot in LDS once (the wave is here together: no lane is missing, and a
+    // wave's LDS accesses execute in order), a candidate then reads its dwords at its own byte offset -- LDS takes
+    // unaligned addresses -- instead of shifting 8 registers into place (which cost 25 VGPRs in every variant)
+    uint8_t* lane_view = lds_view + (threadIdx.x * 48u);
+    if (m) {
+      *reinterpret_cast<uint4*>(lane_view) = make_uint4(d[0], d[1], d[2], d[3]);
+      *reinterpret_cast<uint4*>(lane_view + 16) = make_uint4(d[4], d[5], d[6], d[7]);
+    }
     uint32_t c = m;
     while (c) {
       const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
       c &= c - 1u;
-      const uint8_t* s = cbase + unit_off + b - koff;
-      bool ok = true;
-      for (uint32_t k = 0; k < P.plen && ok; ++k) {
-        const uint32_t x = fold(s[k], ICASE);
-        ok = (sets[k * 8u + (x >> 5)] >> (x & 31u)) & 1u;
+      const int32_t start = (int32_t)b - (int32_t)koff;
+      uint32_t ok = 1u;
+      if (start >= 0 && (uint32_t)start + P.plen <= 32u && P.plen <= kRegVerify) {
+        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+        uint32_t w[kRegVerify / 4];
+#pragma unroll
+        for (int i = 0; i < (int)kRegVerify / 4; ++i)
+          w[i] = *reinterpret_cast<const u32_unaligned*>(lane_view + (uint32_t)start + 4u * (uint32_t)i);
+#pragma unroll
+        for (int k = 0; k < (int)kRegVerify; ++k) {
+          if ((uint32_t)k < P.plen) {
+            const uint32_t x = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;  // already folded when ICASE
+            ok &= sets[(uint32_t)k * 8u + (x >> 5)] >> (x & 31u);
+          }
+        }
+      } else {
+        const uint8_t* s = cbase + unit_off + b - koff;
+        for (uint32_t k = 0; k < P.plen; ++k) {
+          const uint32_t x = fold(s[k], ICASE);
+          ok &= sets[k * 8u + (x >> 5)] >> (x & 31u);
+        }
       }
-      if (!ok) m &= ~(1u << b);
+      if (!(ok & 1u)) m &= ~(1u << b);
     }
   }
   return m;
@@ -413,7 +445,8 @@ struct WaveState {
 template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool CAREFUL>
 __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, bool nx_is_vgpr, uint64_t unit_off,
                                               uint32_t lane, uint64_t L, uint64_t limit, const PatternDev& P,
-                                              const uint8_t* cbase, const uint8_t* s_pat, WaveState& st) {
+                                              const uint8_t* cbase, const uint8_t* s_pat, uint8_t* s_view,
+                                              WaveState& st) {
   // ignore_case, patterns of 4+ bytes (LAZY): the hot filter does not need the exact fold.  (x | 0x20) == (p | 0x20)
   // holds for every byte x that folds to the pattern byte p (exactly those when p is a letter, one more byte value
   // otherwise), so the candidate test runs on data OR-ed with 0x20 -- one op per dword instead of fold4's seven --
@@ -512,7 +545,15 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         d[4] = from_next_lane(f0, fold4(e0r), lane);
         d[5] = from_next_lane(f1, fold4(e1r), lane);
       }
-      m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat);
+      if (KIND == kClass) {
+        // class sequences verify their candidates in registers: the rest of the neighbour's unit joins the view
+        // (raw own bytes go out -- a lane's own view of them may be cleared at the chunk end, the reader's not)
+        const uint32_t e2r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
+        const uint32_t e3r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
+        d[6] = from_next_lane(ICASE ? fold4(cur.z) : cur.z, ICASE ? fold4(e2r) : e2r, lane);
+        d[7] = from_next_lane(ICASE ? fold4(cur.w) : cur.w, ICASE ? fold4(e3r) : e3r, lane);
+      }
+      m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat, s_view);
     }
   }
   if (EMIT) {
@@ -551,6 +592,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
   __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND >= kLong ? XSG_MAX_PATTERN : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_view[KIND == kClass ? kBlock * 48 : 16];  // match_mask16<kClass>
 
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (tile >= A.ntiles) return;
@@ -634,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
       st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, false>(
           v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit, lane, L, limit, P, cbase,
-          s_pat, st);
+          s_pat, s_view, st);
     }
   } else {
 #pragma unroll
@@ -642,7 +684,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
       st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, true>(
           v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit, lane, L, limit, P, cbase,
-          s_pat, st);
+          s_pat, s_view, st);
     }
   }
   const uint32_t cnt = st.cnt, nlc = st.nlc;

@@ -144,6 +144,7 @@ def load():
         "xsg_reduce_counts_async": (ci, [vp, vp, ci, vp]),
         "xsg_reduce_counts": (ci, [vp, C.POINTER(vp), ci, _u64p]),
         "xsg_allgather_u64": (ci, [vp, _u64p, _u64p]),
+        "xsg_device_numa": (ci, [ci, C.POINTER(ci), C.c_char_p, sz]),
         "xsg_jobs_reduce_total": (ci, [C.POINTER(vp), ci, _u64p, C.POINTER(ci)]),
         "xsg_scan_kernel_name": (ci, [vp, u32, C.c_char_p, sz]),
         "xsg_shard_tune": (ci, [vp, u32, C.POINTER(u32)]),
@@ -166,7 +167,7 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_host_offsets", "xsg_host_lines", "xsg_scan_kernel_name", "xsg_shard_tune", "xsg_count_begin",
            "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
            "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
-           "xsg_jobs_reduce_total"]
+           "xsg_jobs_reduce_total", "xsg_device_numa"]
 
 
 def _check(rc):
@@ -212,8 +213,21 @@ class Context:
         _check(self._lib.xsg_ctx_create(device, C.byref(h)))
         self.h = h
         self.device = device
+        # The C ABI wants shards and communicators destroyed before their context.  Python finalises the members
+        # of a reference cycle in no particular order (e.g. everything a caught exception's traceback keeps
+        # alive), so the context closes whatever is still open on it first; closing twice is harmless.
+        self._children = {}
+
+    def _adopt(self, child):
+        self._children[id(child)] = child
+
+    def _release(self, child):
+        self._children.pop(id(child), None)
 
     def close(self):
+        for child in list(self._children.values()):
+            child.close()
+        self._children.clear()
         if self.h:
             self._lib.xsg_ctx_destroy(self.h)
             self.h = None
@@ -245,11 +259,13 @@ class Shard:
                                           C.byref(h)))
         self.h = h
         self.nchunks = len(chunks)
+        ctx._adopt(self)
 
     def close(self):
         if self.h:
             self._lib.xsg_shard_destroy(self.h)
             self.h = None
+            self.ctx._release(self)
 
     def __del__(self):
         try:
@@ -341,6 +357,14 @@ def comm_library() -> str:
     return load().xsg_comm_library().decode()
 
 
+def device_numa(device: int = 0):
+    """-> (numa node or -1, local cpulist string)"""
+    node = C.c_int(-1)
+    buf = C.create_string_buffer(1024)
+    _check(load().xsg_device_numa(device, C.byref(node), buf, 1024))
+    return node.value, buf.value.decode()
+
+
 def jobs_reduce_total(jobs) -> tuple[int, bool]:
     """-> (sum of the count jobs' totals, whether it was exchanged over RCCL)"""
     lib = load()
@@ -356,6 +380,8 @@ class Comm:
 
     def __init__(self, h, ctxs, lib):
         self.h, self.ctxs, self._lib = h, ctxs, lib
+        for c in ctxs:
+            c._adopt(self)
 
     @classmethod
     def rank(cls, ctx: "Context", nranks: int, rank: int, uid: bytes):
@@ -399,6 +425,8 @@ class Comm:
         if self.h:
             self._lib.xsg_comm_destroy(self.h)
             self.h = None
+            for c in self.ctxs:
+                c._release(self)
 
     def __del__(self):
         try:
