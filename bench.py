@@ -171,11 +171,14 @@ def cpu_baseline(args, blocks, pattern: bytes):
     corp = CpuPoolCorpus(orc, blocks, plan, nthreads_touch=hw)
     tcount = [orc.count(b, pattern, False) for b in blocks]
     expect_all = int(sum(tcount[int(t)] for t in plan))
-    ts = sorted({1, pc, hw})
+    ts = {1, pc, hw}
+    if topo["cgroup_cpu_quota"]:  # the container may run only that many CPUs' worth of time: one thread each
+        ts.add(max(1, int(topo["cgroup_cpu_quota"])))
+    ts = sorted(ts)
     per_t = args.cpu_seconds / (len(ts) + 1)
     rates = {}
     for t in ts:
-        first = max(16, min(want_chunks, 16 * t)) if t == 1 else want_chunks  # one thread: a 16-chunk sample is plenty
+        first = min(want_chunks, 64) if t == 1 else want_chunks  # one thread: 1 GiB (beyond the L3) is plenty
         tot, sec, nb = corp.count(pattern, t, 1, first_chunks=first)  # calibration pass
         passes = max(1, min(200, int(per_t / max(sec, 1e-4))))
         tot, sec, nb = corp.count(pattern, t, passes, first_chunks=first)
@@ -188,7 +191,8 @@ def cpu_baseline(args, blocks, pattern: bytes):
     best_t = max((t for t in ts if t > 1), key=lambda t: rates[t][0], default=1)
     r1, rbest = rates[1][0], rates[best_t][0]
     note = (f"{best_t} threads are {rbest / r1:.1f}x one thread"
-            + (f"; cgroup limits this process to {topo['cgroup_cpu_quota']} CPUs" if topo["cgroup_cpu_quota"] else "")
+            + (f"; the cgroup of this process allows {topo['cgroup_cpu_quota']} CPUs' worth of time (cpu.max), so "
+               f"thread counts beyond that are throttled, not scaled" if topo["cgroup_cpu_quota"] else "")
             + ("; beyond that the search is DRAM-bandwidth-bound" if rbest / r1 < 0.5 * best_t and not topo["cgroup_cpu_quota"] else ""))
     return {
         "value": round(rbest, 3),

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define XSG_ABI_VERSION 1
+#define XSG_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 #define XSG_OK 0
@@ -376,9 +376,8 @@ int xsg_scan_kernel_name(xsg_shard* shard, uint32_t mode, char* out, size_t cap)
  * launches; replaces the per-variant default until the shard is destroyed or tuned again).  *chosen (optional)
  * receives the value, or UINT32_MAX when the default was kept (shard under 1 GiB, or XSG_TUNE set). */
 int xsg_shard_tune(xsg_shard* shard, uint32_t mode, uint32_t* chosen);
-/* Diagnostic: a kernel with k_scan's load shape and no work on the bytes, over the
- * shard's span -- the empirical HBM read ceiling for this access pattern. */
-int xsg_time_read_ceiling(xsg_shard* shard, int iters, float* avg_ms, uint64_t* bytes_per_launch);
+/* (The read-only HBM probes of round 1 -- xsg_time_read_ceiling and friends -- moved to libxsg_diag.so,
+ * x-search_amd/csrc/diag/xsg_diag.hip: the product library holds search code only.) */
 
 #ifdef __cplusplus
 }

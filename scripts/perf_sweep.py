@@ -45,6 +45,7 @@ def main():
     torch.cuda.synchronize()
     del dts
     chunks = xsg.make_chunks(off, ln)
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
     out = open(a.out, "w")
 
     def emit(**kw):
@@ -66,8 +67,9 @@ def main():
              ("e", xsg.COUNT_LINES, "count_lines")]
     for r in range(a.rounds):
         for tk, (ctx, sh) in shards.items():
-            ms, nb = sh.time_read_ceiling(a.iters)
-            emit(round=r, tile_kib=tk, what="read_ceiling", ms=ms, gbs=nb / ms / 1e6, bytes=nb)
+            import xsg_diag
+            ms, nb = xsg_diag.read(shard_t.data_ptr(), cap - 65536, sink.data_ptr(), tile_bytes=tk * 1024, variant=1, iters=a.iters)
+            emit(round=r, tile_kib=tk, what="read_ceiling_nt", ms=ms, gbs=nb / ms / 1e6, bytes=nb)
             for pat, mode, name in cases:
                 if r > 0 and pat != "Sherlock":
                     continue

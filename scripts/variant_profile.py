@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""One k_scan variant on a device-resident shard, a few launches: the unit that scripts/gpu_variants.sh runs under
+rocprofv3 (kernel trace / SQ counters / FETCH_SIZE), once per variant, so that every variant -- not only the plain
+count the bench times -- has tracked evidence under profiles/.  Prints one JSON line (HIP-event timing)."""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+for p in (ROOT, ROOT / "x-search_amd", ROOT / "oracle"):
+    sys.path.insert(0, str(p))
+import bench  # noqa: E402
+
+CASES = {
+    # name: (pattern, flags, mode)
+    "count_Sherlock": ("Sherlock", 0, "count"),
+    "count_nl_Sherlock": ("Sherlock", 0, "count+nl"),
+    "lines_Sherlock": ("Sherlock", 0, "count_lines"),
+    "icase_Sherlock": ("Sherlock", "icase", "count"),
+    "icase_that": ("that", "icase", "count"),
+    "mask1_e": ("e", 0, "count"),
+    "mask1_the": ("the", 0, "count"),
+    "lines_e": ("e", 0, "count_lines"),
+    "one_that": ("that", 0, "count"),
+    "mask2_Sherl": ("Sherl", 0, "count"),
+    "long_Sherlock_Holmes": ("Sherlock Holmes", 0, "count"),
+    "long_detective_street": ("detective street", 0, "count"),
+    "class_She_r_lock": ("She[r ]lock", "regex", "count"),
+    "class_Ss_herlock": ("[Ss]herlock", "regex", "count"),
+    "class_digits": ("[0-9]{4}-[0-9]{2}", "regex", "count"),
+    "class_The_az3": ("[Tt]he [a-z]{3} ", "regex", "count"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="count_Sherlock")
+    ap.add_argument("--gib", type=float, default=20.0)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--tune", action="store_true")
+    a = ap.parse_args()
+    import torch
+    import corpus
+    import xsg
+    args = argparse.Namespace(chunk_mib=16, templates=32, seed=0x5EED)
+    blocks = bench.template_blocks(args, b"Sherlock")
+    tbytes = np.array([b.size for b in blocks], dtype=np.int64)
+    nchunks = int(round(a.gib * 2**30 / (16 << 20)))
+    plan = bench.chunk_plan(args, 0, nchunks)
+    off, ln, cap = corpus.chunk_table(tbytes[plan])
+    nbytes = int(ln.sum())
+    dev = torch.device("cuda", 0)
+    shard_t = torch.empty(cap, dtype=torch.uint8, device=dev)
+    dts = [torch.from_numpy(b).to(dev) for b in blocks]
+    for c in range(nchunks):
+        o = int(off[c])
+        shard_t[o:o + dts[int(plan[c])].numel()].copy_(dts[int(plan[c])])
+    torch.cuda.synchronize()
+    del dts
+    ctx = xsg.Context(0)
+    sh = xsg.Shard(ctx, shard_t.data_ptr(), cap, xsg.make_chunks(off, ln))
+    names = [a.case] if a.case != "all" else list(CASES)
+    modes = {"count": xsg.COUNT_MATCHES, "count_lines": xsg.COUNT_LINES, "count+nl": xsg.COUNT_MATCHES | xsg.WITH_NEWLINES}
+    for name in names:
+        pat, fl, mode = CASES[name]
+        flags = {0: 0, "icase": xsg.FLAG_IGNORE_CASE, "regex": xsg.FLAG_REGEX}[fl]
+        ctx.set_pattern(pat.encode(), flags)
+        st = sh.tune(modes[mode]) if a.tune else None
+        ms = sh.time_scan_kernel(modes[mode], a.iters)
+        print(json.dumps({"case": name, "pattern": pat, "flags": fl, "mode": mode, "gib": a.gib, "bytes": nbytes,
+                          "kernel": sh.scan_kernel_name(modes[mode]), "tuned_stagger": st, "ms": round(ms, 4),
+                          "tb_s": round(nbytes / ms / 1e9, 3), "frac_of_8tbs": round(nbytes / ms / 1e9 / 8.0, 4)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

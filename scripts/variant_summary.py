@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/variants_<tag>/ (scripts/gpu_variants.sh) into the table that is committed under profiles/:
+per variant the rocprofv3 kernel-stats duration, the SQ instruction mix per wave (= per 4 KiB) and the HBM read
+traffic per launch against the algorithmic bytes (FETCH_SIZE x 2 x 1024 on gfx950, MI355X_MICROARCH.md)."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+root = Path(sys.argv[1])
+sweep = {}
+for name in ("sweep.jsonl", "sweep_tuned.jsonl"):
+    f = root / name
+    if f.exists():
+        for line in f.read_text().splitlines():
+            if line.startswith("{"):
+                d = json.loads(line)
+                sweep.setdefault(d["case"], {})[name] = d
+print("# HIP-event sweep, 50 GiB shard (scripts/variant_profile.py --case all [--tune])")
+print("case | pattern | mode | kernel | TB/s (default stagger) | TB/s (xsg_shard_tune) | frac of 8 TB/s (best)")
+for c, d in sweep.items():
+    a = d.get("sweep.jsonl")
+    b = d.get("sweep_tuned.jsonl")
+    best = max(x["tb_s"] for x in (a, b) if x)
+    print(f"{c} | {a['pattern']} | {a['mode']} | {a['kernel']} | {a['tb_s']} | "
+          f"{b['tb_s'] if b else '-'} (stagger {b['tuned_stagger'] if b else '-'}) | {best / 8.0:.3f}")
+print()
+print("# rocprofv3 passes, 20 GiB shard, per variant (kernel-trace --stats; --pmc SQ_*; --pmc FETCH_SIZE: separate runs)")
+for d in sorted(p for p in root.iterdir() if p.is_dir()):
+    case = d.name
+    line = {"case": case}
+    for f in glob.glob(str(d / "stats" / "*" / "*kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            if "k_scan<" in r["Name"]:
+                line["kernel"] = r["Name"].replace("void ", "").replace("(xsg::ScanArgs)", "")
+                line["calls"] = int(r["Calls"])
+                line["avg_ms"] = round(float(r["AverageNs"]) / 1e6, 4)
+                line["min_ms"] = round(float(r["MinNs"]) / 1e6, 4)
+    for log in (d / "stats.log",):
+        if log.exists():
+            for l in log.read_text().splitlines():
+                if l.startswith("{"):
+                    j = json.loads(l)
+                    line["bytes"] = j["bytes"]
+                    line["hip_event_ms"] = j["ms"]
+    acc = defaultdict(list)
+    for f in glob.glob(str(d / "sq" / "*" / "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "k_scan<" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if acc.get("SQ_WAVES"):
+        waves = sum(acc["SQ_WAVES"]) / len(acc["SQ_WAVES"])
+        for k, v in acc.items():
+            if k != "SQ_WAVES":
+                line[k + "_per_wave"] = round(sum(v) / len(v) / waves, 1)
+        if "SQ_WAIT_ANY" in acc and "SQ_WAVE_CYCLES" in acc:
+            line["wait_share"] = round(sum(acc["SQ_WAIT_ANY"]) / sum(acc["SQ_WAVE_CYCLES"]), 3)
+    fs = []
+    for f in glob.glob(str(d / "fetch" / "*" / "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "k_scan<" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+                fs.append(float(r["Counter_Value"]))
+    if fs and "bytes" in line:
+        line["hbm_read_bytes_per_launch"] = 2.0 * 1024.0 * sum(fs) / len(fs)
+        line["read_traffic_over_algorithmic"] = round(line["hbm_read_bytes_per_launch"] / line["bytes"], 4)
+    if "avg_ms" in line and "bytes" in line:
+        line["tb_s_rocprof_avg"] = round(line["bytes"] / line["avg_ms"] / 1e9, 3)
+    print(json.dumps(line))

@@ -692,100 +692,6 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   return XSG_OK;
 }
 
-static int time_read(xsg_shard* s, uint32_t tile_bytes, int variant, int iters, float* avg_ms,
-                     uint64_t* bytes_per_launch) {
-  if (!s || !avg_ms || iters <= 0) return fail(XSG_EINVAL, "bad argument");
-  xsg_ctx* c = s->ctx;
-  HIP_TRY(hipSetDevice(c->device));
-  // the span from the first to the last chunk, whole tiles only (padding between chunks is read too)
-  if (s->chunks.empty()) return fail(XSG_ESTATE, "empty shard");
-  const uint64_t lo = s->chunks.front().offset;
-  const uint64_t hi = s->chunks.back().offset + s->chunks.back().length;
-  const uint64_t bytes = ((hi - lo) / tile_bytes) * tile_bytes;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  uint32_t* sink = s->d_counters.as<uint32_t>();
-  HIP_TRY(launch_read_ceiling(s->base + lo, bytes, tile_bytes, variant, sink, c->stream));
-  HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < iters; ++i) HIP_TRY(launch_read_ceiling(s->base + lo, bytes, tile_bytes, variant, sink, c->stream));
-  HIP_TRY(hipEventRecord(e1, c->stream));
-  HIP_TRY(hipEventSynchronize(e1));
-  float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *avg_ms = ms / (float)iters;
-  if (bytes_per_launch) *bytes_per_launch = bytes;
-  return XSG_OK;
-}
-
-extern "C" int xsg_time_read_ceiling(xsg_shard* s, int iters, float* avg_ms, uint64_t* bytes_per_launch) {
-  if (!s) return fail(XSG_EINVAL, "shard is null");
-  return time_read(s, s->tile_bytes, 0, iters, avg_ms, bytes_per_launch);
-}
-
-// not in xsg.h: burst-shape experiments on a flat span (scripts/read_exp.py)
-extern "C" int xsg_diag_read_exp(xsg_shard* s, int loads, int block, uint32_t stagger, uint32_t gap, int iters,
-                                 float* avg_ms, uint64_t* bytes_out) {
-  if (!s || !avg_ms || iters <= 0) return fail(XSG_EINVAL, "bad argument");
-  xsg_ctx* c = s->ctx;
-  HIP_TRY(hipSetDevice(c->device));
-  if (s->chunks.empty() || s->chunks.front().offset != 0) return fail(XSG_ESTATE, "needs a shard that starts at offset 0");
-  const uint64_t span = std::min<uint64_t>(s->chunks.back().offset + s->chunks.back().length, s->capacity);
-  const uint64_t tile_bytes = (uint64_t)kWaveLoad * (uint64_t)loads * (uint64_t)(block / 64);
-  if (!tile_bytes) return fail(XSG_EINVAL, "bad geometry");
-  const uint64_t bytes = (span / tile_bytes) * tile_bytes;  // whole tiles only: never past the buffer
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  uint32_t* sink = s->d_counters.as<uint32_t>();
-  HIP_TRY(launch_read_exp(s->base, bytes, loads, block, stagger, gap, sink, c->stream));
-  HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < iters; ++i) HIP_TRY(launch_read_exp(s->base, bytes, loads, block, stagger, gap, sink, c->stream));
-  HIP_TRY(hipEventRecord(e1, c->stream));
-  HIP_TRY(hipEventSynchronize(e1));
-  float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *avg_ms = ms / (float)iters;
-  if (bytes_out) *bytes_out = bytes;
-  return XSG_OK;
-}
-
-// not in xsg.h: where does k_scan lose against the pure read? (scripts/perf_sweep.py)
-extern "C" int xsg_diag_read_probe(xsg_shard* s, int parts, int iters, float* avg_ms) {
-  if (!s || !avg_ms || iters <= 0) return fail(XSG_EINVAL, "bad argument");
-  xsg_ctx* c = s->ctx;
-  HIP_TRY(hipSetDevice(c->device));
-  if (s->chunks.empty() || s->chunks.front().offset != 0) return fail(XSG_ESTATE, "probe needs a shard that starts at offset 0");
-  ScanArgs a = scan_args(s);
-  // flat span: from the buffer start to the end of the last chunk, never past the capacity
-  const uint64_t flat = std::min<uint64_t>(s->chunks.back().offset + s->chunks.back().length, s->capacity);
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  uint32_t* sink = s->d_counters.as<uint32_t>();
-  HIP_TRY(launch_read_probe(a, parts, flat, sink, c->stream));
-  HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < iters; ++i) HIP_TRY(launch_read_probe(a, parts, flat, sink, c->stream));
-  HIP_TRY(hipEventRecord(e1, c->stream));
-  HIP_TRY(hipEventSynchronize(e1));
-  float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *avg_ms = ms / (float)iters;
-  return XSG_OK;
-}
-
-// not in xsg.h: access-pattern experiments for scripts/perf_sweep.py
-extern "C" int xsg_diag_read_variant(xsg_shard* s, uint32_t tile_bytes, int variant, int iters, float* avg_ms,
-                                     uint64_t* bytes_per_launch) {
-  return time_read(s, tile_bytes, variant, iters, avg_ms, bytes_per_launch);
-}
-
 // ---------------------------------------------------------------------------
 // list searches
 // ---------------------------------------------------------------------------

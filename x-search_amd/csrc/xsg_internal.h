@@ -111,11 +111,6 @@ hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s);
 hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s);
 // "xsg::k_scan<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE>" + the stagger launch_scan would use, for reports
 void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap);
-hipError_t launch_read_exp(const uint8_t* base, uint64_t bytes, int loads, int block, uint32_t stagger, uint32_t gap,
-                           uint32_t* sink, hipStream_t s);
-hipError_t launch_read_probe(const ScanArgs& a, int parts, uint64_t flat_bytes, uint32_t* sink, hipStream_t s);
-hipError_t launch_read_ceiling(const uint8_t* base, uint64_t bytes, uint32_t tile_bytes, int variant, uint32_t* sink,
-                               hipStream_t s);
 
 // exclusive scan: out[i] = sum_{k<i} in[k] for i in [0, n]; out has n+1 entries.
 // tmp must hold scan_tmp_elems(n) uint64 values.

@@ -832,192 +832,6 @@ hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, h
 hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s) { return launch_scan(a, false, false, true, s); }
 
 // ---------------------------------------------------------------------------
-// k_read_ceiling: diagnostic only.  The same load shape as k_scan (LOADS x
-// global_load_dwordx4 per lane, 1 KiB per wave-instruction) with no work on the
-// bytes: the empirical HBM read ceiling of this device for this access pattern.
-// ---------------------------------------------------------------------------
-// VARIANT 0: tile = block index (k_scan's mapping)      1: + non-temporal loads
-//         2: XCD-contiguous (blocks b, b+8, ... walk one eighth of the span)
-//         3: waves of a block interleave their KiBs instead of owning contiguous spans
-template <int LOADS, int VARIANT>
-__global__ __launch_bounds__(kBlock) void k_read_ceiling(const uint8_t* base, uint64_t ntiles, uint32_t* sink) {
-  uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
-  if (tile >= ntiles) return;
-  if (VARIANT == 2) {
-    const uint64_t per = ntiles / 8;
-    if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
-  }
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint8_t* tbase = base + tile * (uint64_t)(kWaveLoad * LOADS * kWaves);
-  uint4 v[LOADS];
-#pragma unroll
-  for (int j = 0; j < LOADS; ++j) {
-    const uint64_t off = VARIANT == 3 ? ((uint64_t)(j * kWaves + wave) * kWaveLoad + (uint64_t)lane * kUnit)
-                                      : ((uint64_t)wave * (kWaveLoad * LOADS) + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit);
-    if (VARIANT == 1) {
-      const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tbase + off));
-      v[j] = make_uint4(t.x, t.y, t.z, t.w);
-    } else {
-      v[j] = *reinterpret_cast<const uint4*>(tbase + off);
-    }
-  }
-  uint32_t x = 0;
-#pragma unroll
-  for (int j = 0; j < LOADS; ++j) x ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
-  if (x == 0xdeadbeefu) sink[0] = x;  // keeps the loads alive; practically never true
-}
-
-template <int LOADS>
-static void launch_rc(int variant, dim3 grid, hipStream_t s, const uint8_t* base, uint64_t ntiles, uint32_t* sink) {
-  switch (variant) {
-    case 1: hipLaunchKernelGGL((k_read_ceiling<LOADS, 1>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
-    case 2: hipLaunchKernelGGL((k_read_ceiling<LOADS, 2>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
-    case 3: hipLaunchKernelGGL((k_read_ceiling<LOADS, 3>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
-    default: hipLaunchKernelGGL((k_read_ceiling<LOADS, 0>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
-  }
-}
-
-hipError_t launch_read_ceiling(const uint8_t* base, uint64_t bytes, uint32_t tile_bytes, int variant, uint32_t* sink,
-                               hipStream_t s) {
-  const uint64_t ntiles = bytes / tile_bytes;
-  if (!ntiles) return hipSuccess;
-  const uint64_t maxx = 1u << 30;
-  const dim3 grid = ntiles <= maxx ? dim3((unsigned)ntiles) : dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx));
-  switch (tile_bytes) {
-    case 4096u: launch_rc<1>(variant, grid, s, base, ntiles, sink); break;
-    case 8192u: launch_rc<2>(variant, grid, s, base, ntiles, sink); break;
-    case 16384u: launch_rc<4>(variant, grid, s, base, ntiles, sink); break;
-    case 32768u: launch_rc<8>(variant, grid, s, base, ntiles, sink); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// k_read_exp: diagnostic.  Pure nt read of a flat span with the knobs of the burst
-// experiments: LOADS units per lane, any workgroup size, wave stagger, a pause
-// between the loads of one wave.
-// ---------------------------------------------------------------------------
-template <int LOADS>
-__global__ void k_read_exp(const uint8_t* base, uint64_t ntiles, uint32_t stagger, uint32_t gap, uint32_t* sink) {
-  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
-  if (tile >= ntiles) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t nwaves = blockDim.x >> 6;
-  for (uint32_t i = 0; i < stagger * wave; ++i) __builtin_amdgcn_s_sleep(1);
-  const uint8_t* p = base + tile * (uint64_t)(kWaveLoad * LOADS) * nwaves + (uint64_t)wave * (kWaveLoad * LOADS) +
-                     (uint64_t)lane * kUnit;
-  uint4 v[LOADS];
-#pragma unroll
-  for (int j = 0; j < LOADS; ++j) {
-    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + (uint64_t)j * kWaveLoad));
-    v[j] = make_uint4(t.x, t.y, t.z, t.w);
-    if (gap) {
-      __builtin_amdgcn_sched_barrier(0);
-      for (uint32_t i = 0; i < gap; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  uint32_t x = 0;
-#pragma unroll
-  for (int j = 0; j < LOADS; ++j) x ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
-  if (x == 0xdeadbeefu) sink[0] = x;
-}
-
-hipError_t launch_read_exp(const uint8_t* base, uint64_t bytes, int loads, int block, uint32_t stagger, uint32_t gap,
-                           uint32_t* sink, hipStream_t s) {
-  const uint64_t tile_bytes = (uint64_t)kWaveLoad * loads * (block / 64);
-  const uint64_t ntiles = bytes / tile_bytes;
-  if (!ntiles || block % 64 || block > 1024) return hipErrorInvalidValue;
-  const uint64_t maxx = 1u << 30;
-  const dim3 grid = ntiles <= maxx ? dim3((unsigned)ntiles) : dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx));
-  switch (loads) {
-    case 1: hipLaunchKernelGGL((k_read_exp<1>), grid, dim3(block), 0, s, base, ntiles, stagger, gap, sink); break;
-    case 2: hipLaunchKernelGGL((k_read_exp<2>), grid, dim3(block), 0, s, base, ntiles, stagger, gap, sink); break;
-    case 4: hipLaunchKernelGGL((k_read_exp<4>), grid, dim3(block), 0, s, base, ntiles, stagger, gap, sink); break;
-    case 8: hipLaunchKernelGGL((k_read_exp<8>), grid, dim3(block), 0, s, base, ntiles, stagger, gap, sink); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// k_read_probe: diagnostic.  nt loads of k_scan's shape plus, optionally, k_scan's
-// prologue (bit 0: tile -> chunk lookups), its epilogue (bit 1: LDS + barrier +
-// one store per tile) and a stand-in for its ALU work (bit 2).  Tells where the
-// gap between k_scan and the pure read ceiling comes from.
-// ---------------------------------------------------------------------------
-template <int PARTS>
-__global__ __launch_bounds__(kBlock) void k_read_probe(const ScanArgs A, uint64_t ntiles, uint32_t* sink) {
-  __shared__ uint32_t s_x[kWaves];
-  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
-  if (tile >= ntiles) return;  // ntiles: chunk tiles with the prologue, whole 16 KiB tiles of the flat span without
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint8_t* tbase;
-  uint64_t Lr = ~0ull, toff = 0;
-  if (PARTS & 1) {
-    const uint32_t c = A.tile_chunk ? A.tile_chunk[tile] : 0u;
-    const ChunkDev ch = A.chunks[c];
-    toff = (tile - A.chunk_tile0[c]) * (uint64_t)kDefaultTileBytes;
-    tbase = A.base + ch.offset + toff;
-    Lr = (ch.length + 15u) & ~(uint64_t)15u;
-  } else {
-    tbase = A.base + tile * (uint64_t)kDefaultTileBytes;
-  }
-  uint4 v[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    uint64_t off = (uint64_t)wave * 4096u + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
-    if (PARTS & 1) off = toff + off < Lr - kUnit ? off : (Lr - kUnit - toff);
-    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tbase + off));
-    v[j] = make_uint4(t.x, t.y, t.z, t.w);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  uint32_t x = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    x ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
-    if (PARTS & 4) {  // ~60 dependent-free VALU ops per load, like the window compares
-      uint32_t a = v[j].x, b = v[j].y, c2 = v[j].z, d = v[j].w;
-#pragma unroll
-      for (int k = 0; k < 15; ++k) {
-        a = __builtin_amdgcn_alignbyte(b, a, 1);
-        x += (a == A.pat.p0) + (b == A.pat.p1) + (c2 == A.pat.p0) + (d == A.pat.p1);
-        b ^= c2;
-      }
-    }
-  }
-  if (PARTS & 2) {
-    const uint32_t wx = wave_sum_u32(x);
-    if (lane == 0) s_x[wave] = wx;
-    __syncthreads();
-    if (threadIdx.x == 0) A.tile_cnt[tile] = (s_x[0] + s_x[1] + s_x[2] + s_x[3]) == 0xdeadbeefu;
-  } else {
-    if (x == 0xdeadbeefu) sink[0] = x;
-  }
-}
-
-hipError_t launch_read_probe(const ScanArgs& a, int parts, uint64_t flat_bytes, uint32_t* sink, hipStream_t s) {
-  // without the prologue the kernel walks a FLAT span: it must not exceed the buffer
-  const uint64_t ntiles = (parts & 1) ? a.ntiles : flat_bytes / kDefaultTileBytes;
-  if (!ntiles) return hipSuccess;
-  if (!(parts & 1) && (parts & 2) && ntiles > a.ntiles) return hipErrorInvalidValue;  // tile_cnt has a.ntiles entries
-  const uint64_t maxx = 1u << 30;
-  const dim3 grid = ntiles <= maxx ? dim3((unsigned)ntiles) : dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx));
-  switch (parts & 7) {
-    case 0: hipLaunchKernelGGL((k_read_probe<0>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
-    case 1: hipLaunchKernelGGL((k_read_probe<1>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
-    case 2: hipLaunchKernelGGL((k_read_probe<2>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
-    case 3: hipLaunchKernelGGL((k_read_probe<3>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
-    case 4: hipLaunchKernelGGL((k_read_probe<4>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
-    case 5: hipLaunchKernelGGL((k_read_probe<5>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
-    case 6: hipLaunchKernelGGL((k_read_probe<6>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
-    default: hipLaunchKernelGGL((k_read_probe<7>), grid, dim3(kBlock), 0, s, a, ntiles, sink); break;
-  }
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
 // k_count_finish: sums the per-tile outputs, replays the reference walk over
 // every chunk's tail zone, and leaves the per-tile arrays as the next pass
 // needs them (tile_cnt and tile_sum zero again).  One launch, no host-side

@@ -134,7 +134,6 @@ def load():
         "xsg_free": (None, [vp]),
         "xsg_ctx_info": (ci, [vp, C.c_char_p, sz, C.POINTER(ci), _u64p]),
         "xsg_time_scan_kernel": (ci, [vp, u32, ci, C.POINTER(C.c_float)]),
-        "xsg_time_read_ceiling": (ci, [vp, ci, C.POINTER(C.c_float), _u64p]),
         "xsg_comm_unique_id": (ci, [vp, sz]),
         "xsg_comm_create_rank": (ci, [vp, ci, ci, vp, C.POINTER(vp)]),
         "xsg_comm_create_local": (ci, [C.POINTER(vp), ci, C.POINTER(vp)]),
@@ -160,7 +159,7 @@ def load():
 EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_count", "xsg_ctx_create",
            "xsg_ctx_destroy", "xsg_set_pattern", "xsg_regex_check", "xsg_shard_create", "xsg_shard_rebind", "xsg_shard_destroy",
            "xsg_shard_set_line_base", "xsg_count_async", "xsg_count", "xsg_search", "xsg_result_u64",
-           "xsg_result_lines_size", "xsg_result_lines", "xsg_ctx_info", "xsg_time_scan_kernel", "xsg_time_read_ceiling", "xsg_result_newlines",
+           "xsg_result_lines_size", "xsg_result_lines", "xsg_ctx_info", "xsg_time_scan_kernel", "xsg_result_newlines",
            "xsg_job_opts_init", "xsg_job_start", "xsg_job_join", "xsg_job_destroy", "xsg_job_total", "xsg_job_wait", "xsg_job_poll",
            "xsg_job_get_u64", "xsg_job_get_line", "xsg_job_stats_get", "xsg_plan_chunks", "xsg_meta_read",
            "xsg_meta_write", "xsg_free", "xsg_host_searcher_create", "xsg_host_searcher_destroy", "xsg_host_count",
@@ -321,11 +320,6 @@ class Shard:
             out.append(raw[pos:pos + int(ln)])
             pos += int(ln)
         return out, offs
-
-    def time_read_ceiling(self, iters: int):
-        ms, nb = C.c_float(0), C.c_uint64(0)
-        _check(self._lib.xsg_time_read_ceiling(self.h, iters, C.byref(ms), C.byref(nb)))
-        return ms.value, nb.value
 
     def scan_kernel_name(self, mode: int) -> str:
         buf = C.create_string_buffer(160)
