@@ -1,18 +1,24 @@
-// xsg_classseq.cpp -- parser for the fixed-length class-sequence subset of RE2 syntax.
+// xsg_classseq.cpp -- parser for the regular expressions the scan kernel decides itself: alternations of
+// fixed-length class sequences, in RE2 syntax.
 //
-// Accepted (each item stands for exactly one byte position unless it is a multi-byte literal):
+// Accepted (each item stands for exactly one byte position unless it is a multi-byte literal or a group):
 //   literal bytes; non-ASCII literals must be well-formed UTF-8 (RE2 parses the pattern as UTF-8) and
 //   stand for their bytes
 //   \  + ASCII punctuation -> that character;  \a \f \n \r \t \v;  \xHH and \x{H..} up to 0x7f
 //   \d = [0-9]   \w = [0-9A-Za-z_]   \s = [\t\n\f\r ]        (RE2's ASCII definitions)
-//   [ ... ]  positive class of ASCII members: literals, a-z ranges, the escapes above, a leading ']'
-//   atom{n}  n >= 1 copies of a one-byte atom
-//   ( ... )  capture groups: transparent (the reference's walk reads group 1, and the API layer wraps the whole
+//   [ ... ]  class of ASCII members: literals, a-z ranges, the escapes above, [:alpha:] & co, a leading ']'
+//   .  [^ ... ]  \D \W \S   -> the ASCII bytes they accept ('.' excludes '\n', a negated class does not); they
+//            mark the expression `ascii_only`: RE2 matches whole code points there, so data with a byte >= 0x80
+//            is refused at search time rather than decided differently
+//   x{n}     n >= 1 copies of an atom or group
+//   ( ... ) (?: ... )  groups: transparent (the reference's walk reads group 1, and the API layer wraps the whole
 //            expression in one -- search_wrappers.h:70-75 only works with at least one group, the unit tests pass
 //            "(a[n|m]t)", the integration tests `She[r ]lock`)
-// Refused: . * + ? | ^ $ {n,m} (?...) \b \B \A \z \D \W \S \p \P \Q \C, backslash + letter/digit otherwise,
-//   negated classes, [:posix:] classes, class members >= 0x80 ('.', negation and wide members match multi-byte
-//   code points in RE2: not one byte per position), more than kMaxClassSeq positions, an empty expression.
+//   a|b      alternation at any depth, as long as every alternative of the whole expression ends up with the
+//            same length (then leftmost-first has nothing to choose: see xsg_classseq.h)
+// Refused: * + ? {n,m} {n,} ^ $ (?flags) (?P<..>) \b \B \A \z \p \P \Q \C, backslash + letter/digit otherwise,
+//   class members >= 0x80, alternatives of different lengths, more than kMaxClassSeq positions, more than
+//   kMaxAlt alternatives (after merging those that differ in one position), an empty expression or alternative.
 #include "xsg_classseq.h"
 
 #include <string.h>
@@ -40,6 +46,7 @@ struct Parser {
   std::vector<ByteSet>* seq;
   std::string* err;
   int depth = 0;
+  bool ascii_only = false;
 
   bool fail(const std::string& m) {
     *err = m + " (at byte " + std::to_string(i) + " of the expression)";
@@ -60,15 +67,21 @@ struct Parser {
     return -1;
   }
 
+  static ByteSet ascii_complement(const ByteSet& s) {
+    ByteSet r{};
+    for (int q = 0; q < 4; ++q) r[q] = ~s[q];  // bytes 0x00..0x7f only
+    return r;
+  }
+
   // after a backslash (i points at the escaped character): a byte set
   bool escape(ByteSet* out) {
     if (i >= n) return fail("trailing backslash");
     const uint8_t c = re[i++];
     ByteSet s{};
     switch (c) {
-      case 'd': add_range(s, '0', '9'); break;
-      case 'w': add_range(s, '0', '9'); add_range(s, 'A', 'Z'); add_range(s, 'a', 'z'); set_add(s, '_'); break;
-      case 's': set_add(s, '\t'); set_add(s, '\n'); set_add(s, '\f'); set_add(s, '\r'); set_add(s, ' '); break;
+      case 'd': case 'D': add_range(s, '0', '9'); break;
+      case 'w': case 'W': add_range(s, '0', '9'); add_range(s, 'A', 'Z'); add_range(s, 'a', 'z'); set_add(s, '_'); break;
+      case 's': case 'S': set_add(s, '\t'); set_add(s, '\n'); set_add(s, '\f'); set_add(s, '\r'); set_add(s, ' '); break;
       case 'a': set_add(s, 7); break;
       case 'f': set_add(s, '\f'); break;
       case 'n': set_add(s, '\n'); break;
@@ -96,6 +109,46 @@ struct Parser {
         if (!is_punct(c)) return fail(std::string("escape \\") + (char)c + " is not supported by the GPU matcher");
         set_add(s, c);
     }
+    if (c == 'D' || c == 'W' || c == 'S') {
+      s = ascii_complement(s);
+      ascii_only = true;
+    }
+    *out = s;
+    return true;
+  }
+
+  // "[:name:]" / "[:^name:]" at i (pointing at '['): RE2's ASCII classes
+  bool posix_class(ByteSet* out) {
+    const size_t end = [&] {
+      for (size_t j = i + 2; j + 1 < n; ++j)
+        if (re[j] == ':' && re[j + 1] == ']') return j;
+      return (size_t)0;
+    }();
+    if (!end) return fail("malformed [:class:]");
+    std::string name((const char*)re + i + 2, end - (i + 2));
+    bool neg = false;
+    if (!name.empty() && name[0] == '^') neg = true, name.erase(0, 1);
+    ByteSet s{};
+    if (name == "alnum") add_range(s, '0', '9'), add_range(s, 'A', 'Z'), add_range(s, 'a', 'z');
+    else if (name == "alpha") add_range(s, 'A', 'Z'), add_range(s, 'a', 'z');
+    else if (name == "ascii") add_range(s, 0, 0x7f);
+    else if (name == "blank") set_add(s, '\t'), set_add(s, ' ');
+    else if (name == "cntrl") add_range(s, 0, 0x1f), set_add(s, 0x7f);
+    else if (name == "digit") add_range(s, '0', '9');
+    else if (name == "graph") add_range(s, '!', '~');
+    else if (name == "lower") add_range(s, 'a', 'z');
+    else if (name == "print") add_range(s, ' ', '~');
+    else if (name == "punct") add_range(s, '!', '/'), add_range(s, ':', '@'), add_range(s, '[', '`'), add_range(s, '{', '~');
+    else if (name == "space") add_range(s, '\t', '\r'), set_add(s, ' ');
+    else if (name == "upper") add_range(s, 'A', 'Z');
+    else if (name == "word") add_range(s, '0', '9'), add_range(s, 'A', 'Z'), add_range(s, 'a', 'z'), set_add(s, '_');
+    else if (name == "xdigit") add_range(s, '0', '9'), add_range(s, 'A', 'F'), add_range(s, 'a', 'f');
+    else return fail("unknown [:" + name + ":] class");
+    if (neg) {
+      s = ascii_complement(s);
+      ascii_only = true;
+    }
+    i = end + 2;
     *out = s;
     return true;
   }
@@ -103,7 +156,8 @@ struct Parser {
   // i points just behind '['
   bool char_class(ByteSet* out) {
     ByteSet s{};
-    if (i < n && re[i] == '^') return fail("negated classes match multi-byte code points in RE2: not supported");
+    bool negated = false;
+    if (i < n && re[i] == '^') negated = true, ++i;
     bool first = true;
     for (;;) {
       if (i >= n) return fail("missing ]");
@@ -113,7 +167,12 @@ struct Parser {
         break;
       }
       first = false;
-      if (c == '[' && i + 1 < n && re[i + 1] == ':') return fail("[:posix:] classes are not supported");
+      if (c == '[' && i + 1 < n && re[i + 1] == ':') {
+        ByteSet ps{};
+        if (!posix_class(&ps)) return false;
+        for (int q = 0; q < 8; ++q) s[q] |= ps[q];
+        continue;
+      }
       if (c >= 0x80) return fail("non-ASCII class members are not supported");
       ByteSet lo_set{};
       bool lo_is_set = false;  // \d \w \s inside a class
@@ -143,97 +202,220 @@ struct Parser {
         for (int q = 0; q < 8; ++q) s[q] |= lo_set[q];
       }
     }
+    if (negated) {
+      s = ascii_complement(s);
+      ascii_only = true;
+    }
     if (set_size(s) == 0) return fail("empty class");
     *out = s;
     return true;
   }
 
-  bool push(const ByteSet& s) {
-    if (seq->size() >= kMaxClassSeq) return fail("expression longer than " + std::to_string(kMaxClassSeq) + " positions");
-    seq->push_back(s);
+  // ---- recursive descent over  alt := concat ('|' concat)* ;  concat := item* ;  item := atom ['{' n '}'] -------
+  using Seq = std::vector<ByteSet>;
+  using SeqSet = std::vector<Seq>;  // alternatives (any lengths while parsing; checked at the end)
+  static constexpr size_t kWorkAlts = 64;  // before merging
+
+  bool cross(SeqSet* acc, const SeqSet& rhs) {
+    SeqSet out;
+    if (acc->size() * rhs.size() > kWorkAlts) return fail("too many alternatives");
+    for (const Seq& a : *acc)
+      for (const Seq& b : rhs) {
+        if (a.size() + b.size() > kMaxClassSeq)
+          return fail("expression longer than " + std::to_string(kMaxClassSeq) + " positions");
+        Seq c = a;
+        c.insert(c.end(), b.begin(), b.end());
+        out.push_back(std::move(c));
+      }
+    acc->swap(out);
     return true;
   }
 
-  bool run() {
-    bool last_is_atom = false;  // the previous item was a one-byte atom a {n} may follow
-    while (i < n) {
-      const uint8_t c = re[i];
-      if (c == '(') {
-        if (i + 1 < n && re[i + 1] == '?') return fail("(?...) groups and flags are not supported");
-        ++i, ++depth;
-        last_is_atom = false;
-        continue;
-      }
-      if (c == ')') {
-        if (depth == 0) return fail("unmatched )");
-        ++i, --depth;
-        last_is_atom = false;  // a quantifier on a group is refused below
-        if (i < n && (re[i] == '{' || re[i] == '*' || re[i] == '+' || re[i] == '?')) return fail("quantified groups are not supported");
-        continue;
-      }
-      if (c == '{') {
-        if (!last_is_atom) return fail("{ without a one-byte atom before it");
-        size_t j = i + 1;
-        uint32_t cnt = 0, digits = 0;
-        while (j < n && re[j] >= '0' && re[j] <= '9' && digits < 4) cnt = cnt * 10 + (re[j++] - '0'), ++digits;
-        if (digits == 0 || j >= n || re[j] != '}') return fail("only the fixed repetition {n} is supported");
-        if (cnt == 0) return fail("{0} is not supported");
-        i = j + 1;
-        const ByteSet s = seq->back();
-        for (uint32_t k = 1; k < cnt; ++k)
-          if (!push(s)) return false;
-        last_is_atom = false;
-        continue;
-      }
-      if (c == '.' ) return fail("'.' matches multi-byte code points in RE2: not supported");
-      if (c == '*' || c == '+' || c == '?' || c == '|' || c == '^' || c == '$')
-        return fail(std::string("operator '") + (char)c + "' is not a fixed-length class sequence");
-      ByteSet s{};
-      if (c == '[') {
-        ++i;
-        if (!char_class(&s)) return false;
-        if (!push(s)) return false;
-        last_is_atom = true;
-        continue;
-      }
-      if (c == '\\') {
-        ++i;
-        if (!escape(&s)) return false;
-        if (!push(s)) return false;
-        last_is_atom = true;
-        continue;
-      }
-      if (c >= 0x80) {  // one well-formed UTF-8 sequence: its bytes, in order
-        const int len = c >= 0xf0 ? 4 : c >= 0xe0 ? 3 : 2;
-        if (c < 0xc2 || c > 0xf4 || i + len > n) return fail("pattern is not valid UTF-8");
-        for (int k = 1; k < len; ++k)
-          if ((re[i + k] & 0xc0) != 0x80) return fail("pattern is not valid UTF-8");
-        for (int k = 0; k < len; ++k)
-          if (!push(single(re[i + k]))) return false;
-        i += len;
-        last_is_atom = false;  // {n} would repeat the whole code point
-        if (i < n && re[i] == '{') return fail("repetition of a multi-byte character is not supported");
-        continue;
-      }
+  bool parse_atom(SeqSet* out) {
+    const uint8_t c = re[i];
+    ByteSet s{};
+    if (c == '(') {
       ++i;
-      if (!push(single(c))) return false;  // ']' and '}' on their own are literals in RE2 too
-      last_is_atom = true;
+      if (i < n && re[i] == '?') {
+        if (i + 1 < n && re[i + 1] == ':') i += 2;  // (?: ... ) is as transparent as ( ... )
+        else return fail("(?...) flags and named groups are not supported");
+      }
+      ++depth;
+      if (!parse_alt(out)) return false;
+      if (i >= n || re[i] != ')') return fail("missing )");
+      ++i, --depth;
+      return true;
     }
-    if (depth != 0) return fail("missing )");
-    if (seq->empty()) return fail("empty expression");
+    if (c == '[') {
+      ++i;
+      if (!char_class(&s)) return false;
+      out->assign(1, Seq(1, s));
+      return true;
+    }
+    if (c == '\\') {
+      ++i;
+      if (!escape(&s)) return false;
+      out->assign(1, Seq(1, s));
+      return true;
+    }
+    if (c == '.') {  // any character but '\n' (RE2 without (?s)); ASCII only, see the header
+      ++i;
+      add_range(s, 0, 0x7f);
+      s['\n' >> 5] &= ~(1u << ('\n' & 31));
+      ascii_only = true;
+      out->assign(1, Seq(1, s));
+      return true;
+    }
+    if (c == '*' || c == '+' || c == '?' || c == '^' || c == '$')
+      return fail(std::string("operator '") + (char)c + "' is not a fixed-length class sequence");
+    if (c == '{') return fail("{ without an atom before it");
+    if (c >= 0x80) {  // one well-formed UTF-8 sequence: its bytes, in order
+      const int len = c >= 0xf0 ? 4 : c >= 0xe0 ? 3 : 2;
+      if (c < 0xc2 || c > 0xf4 || i + len > n) return fail("pattern is not valid UTF-8");
+      for (int k = 1; k < len; ++k)
+        if ((re[i + k] & 0xc0) != 0x80) return fail("pattern is not valid UTF-8");
+      Seq q;
+      for (int k = 0; k < len; ++k) q.push_back(single(re[i + k]));
+      i += len;
+      out->assign(1, q);
+      return true;
+    }
+    ++i;
+    out->assign(1, Seq(1, single(c)));  // ']' and '}' on their own are literals in RE2 too
+    return true;
+  }
+
+  bool parse_item(SeqSet* out) {
+    if (!parse_atom(out)) return false;
+    if (i < n && (re[i] == '*' || re[i] == '+' || re[i] == '?'))
+      return fail(std::string("operator '") + (char)re[i] + "' is not a fixed-length class sequence");
+    if (i < n && re[i] == '{') {
+      size_t j = i + 1;
+      uint32_t cnt = 0, digits = 0;
+      while (j < n && re[j] >= '0' && re[j] <= '9' && digits < 4) cnt = cnt * 10 + (re[j++] - '0'), ++digits;
+      if (digits == 0 || j >= n || re[j] != '}') return fail("only the fixed repetition {n} is supported");
+      if (cnt == 0) return fail("{0} is not supported");
+      i = j + 1;
+      if (i < n && (re[i] == '?' || re[i] == '*' || re[i] == '+' || re[i] == '{')) return fail("stacked quantifiers");
+      const SeqSet base = *out;
+      for (uint32_t k = 1; k < cnt; ++k)
+        if (!cross(out, base)) return false;
+    }
+    return true;
+  }
+
+  bool parse_concat(SeqSet* out) {
+    out->assign(1, Seq());
+    bool any = false;
+    while (i < n && re[i] != '|' && re[i] != ')') {
+      SeqSet item;
+      if (!parse_item(&item)) return false;
+      if (!cross(out, item)) return false;
+      any = true;
+    }
+    if (!any) return fail("empty expression or alternative");
+    return true;
+  }
+
+  bool parse_alt(SeqSet* out) {
+    if (!parse_concat(out)) return false;
+    while (i < n && re[i] == '|') {
+      ++i;
+      SeqSet rhs;
+      if (!parse_concat(&rhs)) return false;
+      out->insert(out->end(), rhs.begin(), rhs.end());
+      if (out->size() > kWorkAlts) return fail("too many alternatives");
+    }
+    return true;
+  }
+
+  bool run(SeqSet* out) {
+    if (n == 0) return fail("empty expression");
+    if (!parse_alt(out)) return false;
+    if (i < n) return fail(re[i] == ')' ? "unmatched )" : "trailing garbage");
     return true;
   }
 };
 
+bool subset_of(const ByteSet& a, const ByteSet& b) {
+  for (int q = 0; q < 8; ++q)
+    if (a[q] & ~b[q]) return false;
+  return true;
+}
+
+// fewer alternatives, same language: drop an alternative another one covers; fuse two that differ in one position
+void merge_alternatives(std::vector<std::vector<ByteSet>>* alts) {
+  bool changed = true;
+  while (changed) {
+    changed = false;
+    for (size_t a = 0; a < alts->size() && !changed; ++a)
+      for (size_t b = 0; b < alts->size() && !changed; ++b) {
+        if (a == b) continue;
+        const auto &A = (*alts)[a], &B = (*alts)[b];
+        size_t differ = 0, at = 0;
+        bool a_in_b = true;
+        for (size_t k = 0; k < A.size(); ++k) {
+          if (A[k] != B[k]) ++differ, at = k;
+          a_in_b &= subset_of(A[k], B[k]);
+        }
+        if (a_in_b) {  // (covers A == B)
+          alts->erase(alts->begin() + (ptrdiff_t)a);
+          changed = true;
+        } else if (differ == 1) {
+          for (int q = 0; q < 8; ++q) (*alts)[b][at][q] |= A[at][q];
+          alts->erase(alts->begin() + (ptrdiff_t)a);
+          changed = true;
+        }
+      }
+  }
+}
+
 }  // namespace
 
-bool compile_class_sequence(const uint8_t* re, size_t n, std::vector<ByteSet>* seq, std::string* err) {
-  seq->clear();
-  Parser p{re, n, 0, seq, err};
-  if (!p.run()) {
-    seq->clear();
+bool compile_class_expr(const uint8_t* re, size_t n, ClassExpr* out, std::string* err) {
+  *out = ClassExpr{};
+  std::vector<ByteSet> unused;
+  Parser p{re, n, 0, &unused, err};
+  Parser::SeqSet alts;
+  if (!p.run(&alts)) return false;
+  const size_t len = alts[0].size();
+  for (const auto& a : alts)
+    if (a.size() != len) {
+      *err = "the alternatives have different lengths (" + std::to_string(len) + " and " + std::to_string(a.size()) +
+             " positions): not a fixed-length expression";
+      return false;
+    }
+  merge_alternatives(&alts);
+  if (alts.size() > kMaxAlt || alts.size() * len > kMaxAltSets) {
+    *err = "too many alternatives for the GPU matcher (" + std::to_string(alts.size()) + " x " + std::to_string(len) +
+           " positions; at most " + std::to_string(kMaxAlt) + " alternatives and " + std::to_string(kMaxAltSets) +
+           " sets)";
     return false;
   }
+  out->npos = (uint32_t)len;
+  out->alts = std::move(alts);
+  out->ascii_only = p.ascii_only;
+  return true;
+}
+
+std::vector<ByteSet> union_sets(const ClassExpr& e) {
+  std::vector<ByteSet> u(e.npos, ByteSet{});
+  for (const auto& a : e.alts)
+    for (uint32_t k = 0; k < e.npos; ++k)
+      for (int q = 0; q < 8; ++q) u[k][q] |= a[k][q];
+  return u;
+}
+
+// the round-1 entry point: one sequence, byte-exact on any data
+bool compile_class_sequence(const uint8_t* re, size_t n, std::vector<ByteSet>* seq, std::string* err) {
+  seq->clear();
+  ClassExpr e;
+  if (!compile_class_expr(re, n, &e, err)) return false;
+  if (e.alts.size() != 1 || e.ascii_only) {
+    *err = "not a single class sequence";
+    return false;
+  }
+  *seq = e.alts[0];
   return true;
 }
 

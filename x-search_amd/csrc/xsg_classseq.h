@@ -35,6 +35,25 @@ int set_single(const ByteSet& s);
 // class sequence of 1..kMaxClassSeq positions.
 bool compile_class_sequence(const uint8_t* re, size_t n, std::vector<ByteSet>* seq, std::string* err);
 
+// The wider family: an ALTERNATION of class sequences of one common length ( `|` at any depth, groups, atom{n},
+// group{n} ), still decided position by position: the expression matches at offset o iff one alternative accepts
+// every byte of data[o, o + npos).  All alternatives having the same length, RE2's leftmost-first rule has nothing
+// to choose between them: the match is [o, o + npos) for the smallest such o.
+// `ascii_only`: the expression used '.', a negated class or \D \W \S.  Those match whole code points in RE2; their
+// sets here hold the ASCII bytes only, which is the same thing on ASCII data and nothing else -- a search with
+// such an expression REFUSES data that holds a byte >= 0x80 (k_scan checks while it scans) instead of deciding it
+// differently from RE2.
+constexpr uint32_t kMaxAlt = 8;       // alternatives after merging
+constexpr uint32_t kMaxAltSets = 64;  // alternatives x positions: 64 x 32 bytes = 2 KiB of LDS
+struct ClassExpr {
+  uint32_t npos = 0;
+  std::vector<std::vector<ByteSet>> alts;  // each npos long
+  bool ascii_only = false;
+};
+bool compile_class_expr(const uint8_t* re, size_t n, ClassExpr* out, std::string* err);
+// position-wise union of the alternatives (what a filter or a '\n' / overlap test may look at: a superset)
+std::vector<ByteSet> union_sets(const ClassExpr& e);
+
 // ignore_case as for literals (toLower on data and pattern, src/utils/string_utils.cpp:11-33):
 // the kernel folds the data bytes, so every set is replaced by the fold of its members.
 void fold_sets(std::vector<ByteSet>* seq);

@@ -338,6 +338,40 @@ __device__ __forceinline__ bool cand_any(const uint32_t (&d)[8], const PatternDe
   return any;
 }
 
+// The hot trigger of the 8-byte-window kinds (kTwo, kLong, kClass): is there a lane whose unit MAY hold a window?
+// Instead of building the 20 unaligned windows of the unit and comparing each against the two window dwords
+// (15 v_alignbyte + 32 v_cmp per 16 bytes), the ALIGNED dwords of the view are compared against the four
+// sub-dwords of the window: a window that starts at byte b of the unit, b = 4i + r, contains the aligned dword
+// d[i+1] (r != 0) or d[i] (r == 0) at window offset (4 - r) % 4, so
+//     r = 0: d[i] == W[0:4] and d[i+1] == W[4:8]     r = 1: d[i+1] == W[3:7]
+//     r = 2: d[i+1] == W[2:6]                         r = 3: d[i+1] == W[1:5]
+// 25 compares on d[0..5], no byte shuffling at all; the sub-dwords are wave-uniform (scalar registers).  A superset
+// of the exact candidates (three of the four alignments test 4 of the 8 bytes): a wave-load that triggers runs the
+// exact slow path.  Whole-word decoys of the window's halves ("Sher", "lock" for `Sherlock`) only pass the r = 0
+// test together; the other alignments look at "herl", "erlo", "rloc", which are words of nobody's lexicon.
+template <int KIND>
+__device__ __forceinline__ bool trigger_aligned(const uint32_t (&d)[8], const PatternDev& P) {
+  const uint64_t w = ((uint64_t)P.p1 << 32) | P.p0;
+  const uint32_t a1 = (uint32_t)(w >> 8), a2 = (uint32_t)(w >> 16), a3 = (uint32_t)(w >> 24);
+  bool t = false;
+  if (KIND == kClass) {  // masked: a position of the window pins only the bits its set agrees on
+    const uint64_t mw = ((uint64_t)P.m1 << 32) | P.m0;
+    const uint32_t m1 = (uint32_t)(mw >> 8), m2 = (uint32_t)(mw >> 16), m3 = (uint32_t)(mw >> 24);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      t |= ((d[q] & m1) == a1) | ((d[q] & m2) == a2) | ((d[q] & m3) == a3);
+      t |= ((d[q] & P.m0) == P.p0) & ((d[q + 1] & P.m1) == P.p1);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      t |= (d[q] == a1) | (d[q] == a2) | (d[q] == a3);
+      t |= (d[q] == P.p0) & (d[q + 1] == P.p1);
+    }
+  }
+  return t;
+}
+
 template <int KIND>
 __device__ __forceinline__ uint32_t cand_mask16(const uint32_t (&d)[8], const PatternDev& P) {
   uint32_t w[20];
@@ -537,7 +571,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
       Pf.p0 = P.q0;
       Pf.p1 = P.q1;
     }
-    const bool any_c = cand_any<KIND>(d, Pf);
+    const bool any_c = (KIND == kTwo || KIND == kLong || KIND == kClass) ? trigger_aligned<KIND>(d, Pf) : cand_any<KIND>(d, Pf);
     if (__ballot(any_c) != 0) {
       if (LAZY) {  // now the exact view: properly folded bytes, own and neighbour's
         const uint32_t f0 = fold4(cur.x), f1 = fold4(cur.y);
