@@ -82,15 +82,23 @@ enum xsg_mode {
 /* The pattern is a regular expression.  The reference hands a pattern that "does
  * not match itself as a regex" (include/xsearch/utils/utils.h:17-25) to RE2 and
  * walks the chunk with RE2::PartialMatch
- * (include/xsearch/string_search/search_wrappers.h:63-87,209-271).  Served here:
- * fixed-length sequences of byte classes -- literals, [positive ASCII classes],
- * \d \w \s, escapes, atom{n}, transparent ( ) -- which is every regex the
- * reference's tests use (`She[r ]lock`, test/src/xsearchTest.cpp:9; `(a[n|m]t)`,
- * test/src/string_search/search_wrappersTest.cpp:78).  Up to 32 positions.
- * Anything else (repetition, alternation, anchors, '.', negated classes) returns
- * XSG_ENOTSUP from xsg_set_pattern: refused, never approximated.  No tail
- * quirk applies (RE2 is exact); XSG_FLAG_IGNORE_CASE folds ASCII letters in the
- * data and in every class, as for literals. */
+ * (include/xsearch/string_search/search_wrappers.h:63-87,209-271).  Served here,
+ * decided position by position in the scan kernel: alternations of fixed-length
+ * sequences of byte classes -- literals, [ASCII classes] incl. [:alpha:] & co,
+ * \d \w \s, escapes, x{n}, groups ( ) (?: ), `a|b` at any depth as long as all
+ * alternatives of the whole expression have one length (then leftmost-first has
+ * nothing to choose) -- which covers every regex the reference's tests use
+ * (`She[r ]lock`, test/src/xsearchTest.cpp:9; `(a[n|m]t)`,
+ * test/src/string_search/search_wrappersTest.cpp:78).  Up to 32 positions, 8
+ * alternatives, 64 sets in all.
+ * '.', negated classes and \D \W \S are accepted with their ASCII meaning ('.' =
+ * any ASCII byte but '\n'); RE2 matches whole code points there, so a search with
+ * such an expression REFUSES data that holds a byte >= 0x80 (XSG_ENOTSUP from the
+ * search call; xsg_count_async hands out UINT64_MAX in all four counters) rather
+ * than decide it differently.  Everything of variable length (* + ? {n,m}), anchors
+ * and (?flags) return XSG_ENOTSUP from xsg_set_pattern: refused, never
+ * approximated.  No tail quirk applies (RE2 is exact); XSG_FLAG_IGNORE_CASE folds
+ * ASCII letters in the data and in every class, as for literals. */
 #define XSG_FLAG_REGEX 0x4u
 
 #define XSG_MAX_PATTERN 1024u
@@ -143,6 +151,11 @@ int xsg_set_pattern(xsg_ctx* ctx, const void* pattern, size_t plen, uint32_t fla
  * bit b of sets[8*k + b/32] set <=> position k accepts byte b; folded if
  * XSG_FLAG_IGNORE_CASE is in flags). */
 int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets);
+/* The same with the whole structure: number of alternatives, whether the expression is exact on ASCII data only
+ * ('.', negated classes), and every alternative's sets (room for 64 x 8 uint32, alternative-major).  xsg_regex_check
+ * returns the position-wise UNION of the alternatives. */
+int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* alternatives,
+                   uint32_t* ascii_only, uint32_t* sets);
 
 /* ---- shards ---------------------------------------------------------------- */
 /* d_base/capacity: device memory owned by the caller (hipMalloc, a torch

@@ -579,7 +579,7 @@ uint64_t xso_pool_count_chunks(xso_pool* p, const char* base, const uint64_t* of
 }
 
 /* ------------------------------------------------------------------------ */
-/* Regex wrappers for fixed-length class sequences                           */
+/* Regex wrappers for (alternations of) fixed-length class sequences         */
 /* (include/xsearch/string_search/search_wrappers.h:63-103, 209-271).        */
 /*                                                                           */
 /* The reference calls re2::RE2::PartialMatch(input, pattern, &match).  RE2  */
@@ -595,19 +595,23 @@ uint64_t xso_pool_count_chunks(xso_pool* p, const char* base, const uint64_t* of
 /* {0,113,176,460}, 4) and cross-checked against CPython's `re`              */
 /* (tests/test_oracle_regex.py).                                             */
 /* ------------------------------------------------------------------------ */
-static int cs_accepts(const xso_classseq* cs, uint32_t k, unsigned char b) {
-  return (cs->sets[k][b >> 5] >> (b & 31u)) & 1u;
+static int cs_accepts(const xso_classseq* cs, uint32_t a, uint32_t k, unsigned char b) {
+  return (cs->sets[a * cs->plen + k][b >> 5] >> (b & 31u)) & 1u;
 }
 
-/* stand-in for RE2::PartialMatch(input, "(<class sequence>)", &match): offset of the match in input or -1
- * (match.size() is always cs->plen) */
+/* stand-in for RE2::PartialMatch(input, "(<expression>)", &match): offset of the match in input or -1.  Every
+ * alternative has cs->plen positions, so whichever alternative RE2's leftmost-first rule prefers at the leftmost
+ * offset, the match is the same span: match.size() is always cs->plen. */
 static int64_t cs_partial_match(const xso_classseq* cs, const char* input, size_t len) {
   if (cs->plen == 0 || len < cs->plen) return -1;
   const size_t last = len - cs->plen;
+  const uint32_t nalt = cs->nalt ? cs->nalt : 1u;
   for (size_t o = 0; o <= last; ++o) {
-    uint32_t k = 0;
-    while (k < cs->plen && cs_accepts(cs, k, (unsigned char)input[o + k])) ++k;
-    if (k == cs->plen) return (int64_t)o;
+    for (uint32_t a = 0; a < nalt; ++a) {
+      uint32_t k = 0;
+      while (k < cs->plen && cs_accepts(cs, a, k, (unsigned char)input[o + k])) ++k;
+      if (k == cs->plen) return (int64_t)o;
+    }
   }
   return -1;
 }

@@ -81,12 +81,13 @@ uint64_t xso_line_indices(const char* data, size_t len, const char* pat, size_t 
 uint64_t xso_count_newlines(const char* data, size_t len);
 
 /* ---- regex wrappers, class-sequence family only (search_wrappers.h:63-103,209-271) ---- */
-/* RE2 (unpinned submodule, absent) is restated for fixed-length sequences of byte sets only: see the
- * block comment in xs_oracle.c.  The expression -> sets parser of the oracle lives in xs_oracle.py
+/* RE2 (unpinned submodule, absent) is restated for alternations of fixed-length sequences of byte sets
+ * (all alternatives of one length) only: see the block comment in xs_oracle.c.  The expression -> sets parser of the oracle lives in xs_oracle.py
  * (compile_class_sequence); bit b of sets[k] set <=> position k accepts byte b. */
 typedef struct xso_classseq {
   uint32_t plen;          /* 1..32 positions */
-  uint32_t sets[32][8];
+  uint32_t nalt;          /* alternatives of that common length (0 is read as 1) */
+  uint32_t sets[256][8];  /* alternative a, position k: sets[a * plen + k] */
 } xso_classseq;
 uint64_t xso_regex_byte_offsets_match(const char* data, size_t len, const xso_classseq* cs, int skip_to_nl,
                                       uint64_t* out, uint64_t cap);                              /* :242-245 */

@@ -89,150 +89,236 @@ class UnsupportedRegex(ValueError):
 
 
 class ClassSeq(C.Structure):
-    """xso_classseq: bit b of sets[k] set <=> position k accepts byte b."""
-    _fields_ = [("plen", C.c_uint32), ("sets", (C.c_uint32 * 8) * 32)]
+    """xso_classseq: bit b of sets[a * plen + k] set <=> alternative a accepts byte b at position k."""
+    _fields_ = [("plen", C.c_uint32), ("nalt", C.c_uint32), ("sets", (C.c_uint32 * 8) * 256)]
+    ascii_only = False  # the expression used '.', a negated class or \D \W \S: meaningful on ASCII data only
 
     def accepts(self, k: int, b: int) -> bool:
-        return bool((self.sets[k][b >> 5] >> (b & 31)) & 1)
+        """does ANY alternative accept byte b at position k?"""
+        return any((self.sets[a * self.plen + k][b >> 5] >> (b & 31)) & 1 for a in range(max(self.nalt, 1)))
 
 
 _PUNCT = set(range(0x21, 0x7f)) - set(range(0x30, 0x3a)) - set(range(0x41, 0x5b)) - set(range(0x61, 0x7b))
+_ASCII = frozenset(range(0x80))
 _ESC_SETS = {ord("d"): set(range(0x30, 0x3a)),
              ord("w"): set(range(0x30, 0x3a)) | set(range(0x41, 0x5b)) | set(range(0x61, 0x7b)) | {0x5f},
              ord("s"): {9, 10, 12, 13, 32},  # RE2: \s == [\t\n\f\r ]
              ord("a"): {7}, ord("f"): {12}, ord("n"): {10}, ord("r"): {13}, ord("t"): {9}, ord("v"): {11}}
+_POSIX = {
+    b"alnum": _ESC_SETS[ord("w")] - {0x5f}, b"alpha": set(range(0x41, 0x5b)) | set(range(0x61, 0x7b)),
+    b"ascii": set(range(0x80)), b"blank": {9, 32}, b"cntrl": set(range(0x20)) | {0x7f},
+    b"digit": set(range(0x30, 0x3a)), b"graph": set(range(0x21, 0x7f)), b"lower": set(range(0x61, 0x7b)),
+    b"print": set(range(0x20, 0x7f)), b"punct": set(_PUNCT), b"space": {9, 10, 11, 12, 13, 32},
+    b"upper": set(range(0x41, 0x5b)), b"word": set(_ESC_SETS[ord("w")]),
+    b"xdigit": set(range(0x30, 0x3a)) | set(range(0x41, 0x47)) | set(range(0x61, 0x67)),
+}
+
+
+class _RegexReader:
+    """The oracle's own reading of the RE2 syntax subset (written independently of
+    x-search_amd/csrc/xsg_classseq.cpp; tests/test_oracle_regex.py checks both against CPython's `re`).
+    Grammar:  alt := cat ('|' cat)* ;  cat := piece+ ;  piece := atom ['{' n '}'] ;
+              atom := literal | escape | '[' class ']' | '.' | '(' ['?:'] alt ')'
+    Every function returns the LIST of alternatives it can stand for, each a tuple of frozensets (one per byte
+    position); concatenation is the cross product, alternation the concatenation of the lists."""
+
+    def __init__(self, e: bytes, ignore_case: bool = False):
+        self.e, self.i, self.ascii_only, self.icase = e, 0, False, ignore_case
+
+    def negate(self, members) -> frozenset:
+        """ASCII complement; under ignore_case the members are closed under case first, as RE2's (?i) does
+        ((?i)[^a] excludes 'a' and 'A')"""
+        m = set(members)
+        if self.icase:
+            m |= {b ^ 0x20 for b in m if 0x41 <= (b & ~0x20) <= 0x5a and b < 0x80}
+        self.ascii_only = True
+        return _ASCII - m
+
+    def peek(self):
+        return self.e[self.i] if self.i < len(self.e) else None
+
+    def escape(self):  # self.i is at the character after the backslash
+        e = self.e
+        if self.i >= len(e):
+            raise UnsupportedRegex("trailing backslash")
+        c = e[self.i]
+        self.i += 1
+        if c in _ESC_SETS:
+            return frozenset(_ESC_SETS[c])
+        if c in (ord("D"), ord("W"), ord("S")):
+            return self.negate(_ESC_SETS[c | 0x20])
+        if c == ord("x"):
+            if e[self.i:self.i + 1] == b"{":
+                k = e.find(b"}", self.i + 1)
+                body = e[self.i + 1:k] if k > 0 else b""
+                if not body or len(body) > 8 or any(ch not in b"0123456789abcdefABCDEF" for ch in body):
+                    raise UnsupportedRegex("malformed \\x{...}")
+                v, self.i = int(body, 16), k + 1
+            else:
+                body = e[self.i:self.i + 2]
+                if len(body) != 2 or any(ch not in b"0123456789abcdefABCDEF" for ch in body):
+                    raise UnsupportedRegex("malformed \\xHH")
+                v, self.i = int(body, 16), self.i + 2
+            if v > 0x7f:
+                raise UnsupportedRegex("code point above 0x7f")
+            return frozenset({v})
+        if c in _PUNCT:
+            return frozenset({c})
+        raise UnsupportedRegex(f"escape \\{chr(c)!r}")
+
+    def bracket(self):  # self.i is just behind '['
+        e = self.e
+        neg = e[self.i:self.i + 1] == b"^"
+        if neg:
+            self.i += 1
+        members, first = set(), True
+        while True:
+            if self.i >= len(e):
+                raise UnsupportedRegex("missing ]")
+            m = e[self.i]
+            if m == ord("]") and not first:
+                self.i += 1
+                break
+            first = False
+            if m == ord("[") and e[self.i + 1:self.i + 2] == b":":
+                k = e.find(b":]", self.i + 2)
+                if k < 0:
+                    raise UnsupportedRegex("malformed [:class:]")
+                name = e[self.i + 2:k]
+                pneg = name[:1] == b"^"
+                name = name[1:] if pneg else name
+                if name not in _POSIX:
+                    raise UnsupportedRegex("unknown posix class")
+                members |= self.negate(_POSIX[name]) if pneg else _POSIX[name]
+                self.i = k + 2
+                continue
+            if m >= 0x80:
+                raise UnsupportedRegex("non-ASCII class member")
+            self.i += 1
+            lo = self.escape() if m == ord("\\") else frozenset({m})
+            if len(lo) == 1 and e[self.i:self.i + 1] == b"-" and self.i + 1 < len(e) and e[self.i + 1] != ord("]"):
+                h = e[self.i + 1]
+                self.i += 2
+                if h >= 0x80:
+                    raise UnsupportedRegex("non-ASCII class member")
+                hi = self.escape() if h == ord("\\") else frozenset({h})
+                if len(hi) != 1 or min(hi) < min(lo):
+                    raise UnsupportedRegex("bad range")
+                members |= set(range(min(lo), min(hi) + 1))
+            else:
+                members |= lo
+        if neg:
+            members = set(self.negate(members))
+        if not members:
+            raise UnsupportedRegex("empty class")
+        return frozenset(members)
+
+    def atom(self):
+        e, c = self.e, self.peek()
+        if c == ord("("):
+            self.i += 1
+            if e[self.i:self.i + 1] == b"?":
+                if e[self.i:self.i + 2] != b"?:":
+                    raise UnsupportedRegex("(?")
+                self.i += 2
+            alts = self.alt()
+            if self.peek() != ord(")"):
+                raise UnsupportedRegex("missing )")
+            self.i += 1
+            return alts
+        if c == ord("["):
+            self.i += 1
+            return [(self.bracket(),)]
+        if c == ord("\\"):
+            self.i += 1
+            return [(self.escape(),)]
+        if c == ord("."):
+            self.i += 1
+            self.ascii_only = True
+            return [(_ASCII - {10},)]
+        if c in b"*+?^${":
+            raise UnsupportedRegex(f"operator {chr(c)!r}")
+        if c >= 0x80:
+            n = 4 if c >= 0xf0 else 3 if c >= 0xe0 else 2
+            try:
+                e[self.i:self.i + n].decode("utf-8")
+            except UnicodeDecodeError:
+                raise UnsupportedRegex("pattern is not valid UTF-8")
+            seq = tuple(frozenset({b}) for b in e[self.i:self.i + n])
+            self.i += n
+            return [seq]
+        self.i += 1
+        return [(frozenset({c}),)]
+
+    @staticmethod
+    def cross(left, right):
+        out = [a + b for a in left for b in right]
+        if len(out) > 64 or any(len(s) > 32 for s in out):
+            raise UnsupportedRegex("too many alternatives or positions")
+        return out
+
+    def piece(self):
+        alts = self.atom()
+        if self.peek() is not None and self.peek() in b"*+?":
+            raise UnsupportedRegex("repetition operator")
+        if self.peek() == ord("{"):
+            k = self.e.find(b"}", self.i)
+            body = self.e[self.i + 1:k] if k > 0 else b""
+            if not body.isdigit() or len(body) > 4 or int(body) == 0:
+                raise UnsupportedRegex("only x{n}, n >= 1")
+            self.i = k + 1
+            if self.peek() is not None and self.peek() in b"*+?{":
+                raise UnsupportedRegex("stacked quantifiers")
+            base = alts
+            for _ in range(int(body) - 1):
+                alts = self.cross(alts, base)
+        return alts
+
+    def cat(self):
+        alts, any_piece = [()], False
+        while self.peek() is not None and self.peek() not in b"|)":
+            alts = self.cross(alts, self.piece())
+            any_piece = True
+        if not any_piece:
+            raise UnsupportedRegex("empty expression or alternative")
+        return alts
+
+    def alt(self):
+        alts = self.cat()
+        while self.peek() == ord("|"):
+            self.i += 1
+            alts = alts + self.cat()
+            if len(alts) > 64:
+                raise UnsupportedRegex("too many alternatives")
+        return alts
 
 
 def compile_class_sequence(expr: bytes, ignore_case: bool = False) -> ClassSeq:
-    """The oracle's own reading of the RE2 syntax subset (written independently of
-    x-search_amd/csrc/xsg_classseq.cpp; tests/test_oracle_regex.py checks both against
-    CPython's `re`).  One set of bytes per position; raises UnsupportedRegex otherwise.
-    ignore_case: as for literals -- toLower on the data and on every set
-    (src/utils/string_utils.cpp:11-33)."""
-    e = bytes(expr)
-    pos: list[set[int]] = []
-    i, depth, atom = 0, 0, False
-
-    def escape(j):  # e[j] is the character after the backslash -> (set, next index)
-        if j >= len(e):
-            raise UnsupportedRegex("trailing backslash")
-        c = e[j]
-        if c in _ESC_SETS:
-            return set(_ESC_SETS[c]), j + 1
-        if c == ord("x"):
-            if j + 1 < len(e) and e[j + 1] == ord("{"):
-                k = e.find(b"}", j + 2)
-                if k < 0 or k == j + 2 or k - (j + 2) > 8:
-                    raise UnsupportedRegex("malformed \\x{...}")
-                try:
-                    v = int(e[j + 2:k].decode("ascii"), 16)
-                except ValueError:
-                    raise UnsupportedRegex("malformed \\x{...}")
-                nxt = k + 1
-            else:
-                try:
-                    hx = e[j + 1:j + 3].decode("ascii")
-                    if len(hx) != 2 or not all(ch in "0123456789abcdefABCDEF" for ch in hx):
-                        raise ValueError
-                    v = int(hx, 16)
-                except (ValueError, UnicodeDecodeError):
-                    raise UnsupportedRegex("malformed \\xHH")
-                nxt = j + 3
-            if v > 0x7f:
-                raise UnsupportedRegex("code point above 0x7f")
-            return {v}, nxt
-        if c in _PUNCT:
-            return {c}, j + 1
-        raise UnsupportedRegex(f"escape \\{chr(c)!r}")
-
-    while i < len(e):
-        c = e[i]
-        if c == ord("("):
-            if e[i + 1:i + 2] == b"?":
-                raise UnsupportedRegex("(?")
-            depth, i, atom = depth + 1, i + 1, False
-        elif c == ord(")"):
-            if depth == 0:
-                raise UnsupportedRegex("unmatched )")
-            depth, i, atom = depth - 1, i + 1, False
-            if e[i:i + 1] in (b"{", b"*", b"+", b"?"):
-                raise UnsupportedRegex("quantified group")
-        elif c == ord("{"):
-            k = e.find(b"}", i)
-            body = e[i + 1:k] if k > 0 else b""
-            if not atom or not body.isdigit() or len(body) > 4 or int(body) == 0:
-                raise UnsupportedRegex("only atom{n}, n >= 1")
-            pos.extend(set(pos[-1]) for _ in range(int(body) - 1))
-            i, atom = k + 1, False
-        elif c in b".*+?|^$":
-            raise UnsupportedRegex(f"operator {chr(c)!r}")
-        elif c == ord("["):
-            i += 1
-            if e[i:i + 1] == b"^":
-                raise UnsupportedRegex("negated class")
-            members: set[int] = set()
-            first = True
-            while True:
-                if i >= len(e):
-                    raise UnsupportedRegex("missing ]")
-                m = e[i]
-                if m == ord("]") and not first:
-                    i += 1
-                    break
-                first = False
-                if m == ord("[") and e[i + 1:i + 2] == b":":
-                    raise UnsupportedRegex("posix class")
-                if m >= 0x80:
-                    raise UnsupportedRegex("non-ASCII class member")
-                if m == ord("\\"):
-                    lo, i = escape(i + 1)
-                else:
-                    lo, i = {m}, i + 1
-                if len(lo) == 1 and e[i:i + 1] == b"-" and i + 1 < len(e) and e[i + 1] != ord("]"):
-                    h = e[i + 1]
-                    if h >= 0x80:
-                        raise UnsupportedRegex("non-ASCII class member")
-                    if h == ord("\\"):
-                        hi, i = escape(i + 2)
-                    else:
-                        hi, i = {h}, i + 2
-                    if len(hi) != 1 or min(hi) < min(lo):
-                        raise UnsupportedRegex("bad range")
-                    members |= set(range(min(lo), min(hi) + 1))
-                else:
-                    members |= lo
-            if not members:
-                raise UnsupportedRegex("empty class")
-            pos.append(members)
-            atom = True
-        elif c == ord("\\"):
-            st, i = escape(i + 1)
-            pos.append(st)
-            atom = True
-        elif c >= 0x80:
-            n = 4 if c >= 0xf0 else 3 if c >= 0xe0 else 2
-            try:
-                e[i:i + n].decode("utf-8")
-            except UnicodeDecodeError:
-                raise UnsupportedRegex("pattern is not valid UTF-8")
-            pos.extend({b} for b in e[i:i + n])
-            i, atom = i + n, False
-            if e[i:i + 1] == b"{":
-                raise UnsupportedRegex("repetition of a multi-byte character")
-        else:
-            pos.append({c})
-            i, atom = i + 1, True
-    if depth:
-        raise UnsupportedRegex("missing )")
-    if not pos or len(pos) > 32:
-        raise UnsupportedRegex("empty or longer than 32 positions")
+    """expression -> ClassSeq (all alternatives, every one `plen` positions long); raises UnsupportedRegex for
+    anything else.  ignore_case: as for literals -- toLower on the data and on every set
+    (src/utils/string_utils.cpp:11-33).  `.ascii_only` is set when the expression used '.', a negated class or
+    \\D \\W \\S: the oracle's walks then refuse non-ASCII data, like the product."""
+    rd = _RegexReader(bytes(expr), ignore_case)
+    if not rd.e:
+        raise UnsupportedRegex("empty expression")
+    alts = rd.alt()
+    if rd.i < len(rd.e):
+        raise UnsupportedRegex("unmatched )" if rd.peek() == ord(")") else "trailing garbage")
+    plen = len(alts[0])
+    if any(len(a) != plen for a in alts):
+        raise UnsupportedRegex("alternatives of different lengths")
+    alts = list(dict.fromkeys(alts))  # duplicates change nothing
+    if plen == 0 or plen > 32 or len(alts) * plen > 256:
+        raise UnsupportedRegex("empty, longer than 32 positions, or more than 256 sets")
     cs = ClassSeq()
-    cs.plen = len(pos)
-    for k, st in enumerate(pos):
-        if ignore_case:
-            st = {b + 32 if 0x41 <= b <= 0x5a else b for b in st}
-        for b in st:
-            cs.sets[k][b >> 5] |= 1 << (b & 31)
+    cs.plen, cs.nalt = plen, len(alts)
+    cs.ascii_only = rd.ascii_only
+    for a, seq in enumerate(alts):
+        for k, st in enumerate(seq):
+            if ignore_case:
+                st = {b + 32 if 0x41 <= b <= 0x5a else b for b in st}
+            for b in st:
+                cs.sets[a * plen + k][b >> 5] |= 1 << (b & 31)
     return cs
 
 
@@ -383,19 +469,32 @@ class Oracle:
         return self._list(self.lib.xso_line_indices, b.addr, b.len, p, len(p), int(line_base))
 
     # -- regex wrappers (class sequences; cs = compile_class_sequence(expr)) ----
+    @staticmethod
+    def _ascii_guard(data, cs):
+        """an ascii_only expression ('.', negated classes) has no byte-per-position meaning on non-ASCII data:
+        refused, like the product does"""
+        if getattr(cs, "ascii_only", False):
+            a = data if isinstance(data, np.ndarray) else np.frombuffer(_as_bytes(data), dtype=np.uint8)
+            if a.size and int(a.max()) >= 0x80:
+                raise UnsupportedRegex("ascii-only expression on non-ASCII data")
+
     def regex_byte_offsets_match(self, data, cs, skip_to_nl=False) -> np.ndarray:
+        self._ascii_guard(data, cs)
         b = _Buf(data)
         return self._list(self.lib.xso_regex_byte_offsets_match, b.addr, b.len, C.byref(cs), 1 if skip_to_nl else 0)
 
     def regex_byte_offsets_line(self, data, cs) -> np.ndarray:
+        self._ascii_guard(data, cs)
         b = _Buf(data)
         return self._list(self.lib.xso_regex_byte_offsets_line, b.addr, b.len, C.byref(cs))
 
     def regex_count(self, data, cs, skip_to_nl=True) -> int:
+        self._ascii_guard(data, cs)
         b = _Buf(data)
         return self.lib.xso_regex_count(b.addr, b.len, C.byref(cs), 1 if skip_to_nl else 0)
 
     def regex_lines_spans(self, data, cs):
+        self._ascii_guard(data, cs)
         b = _Buf(data)
         n = self.lib.xso_regex_lines(b.addr, b.len, C.byref(cs), None, None, 0)
         beg = np.empty(n, dtype=np.uint64)
@@ -405,6 +504,7 @@ class Oracle:
         return beg, ln
 
     def regex_line_indices(self, data, cs, line_base=0) -> np.ndarray:
+        self._ascii_guard(data, cs)
         b = _Buf(data)
         return self._list(self.lib.xso_regex_line_indices, b.addr, b.len, C.byref(cs), int(line_base))
 

@@ -9,7 +9,8 @@ import pytest
 import corpus
 import xsg
 from gpu_util import GpuSearch, oracle_all_modes, oracle_regex_all_modes
-from test_oracle_regex import ACCEPTED, REFUSED, rand_expr
+from test_oracle_regex import ACCEPTED, REFUSED, rand_expr, rand_expr2
+from xs_oracle import UnsupportedRegex
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).parent / "golden"
@@ -21,8 +22,23 @@ def gs():
 
 
 def check(gs, oracle, blocks, expr, icase=False, ctx="", **kw):
-    want, with_lines = oracle_regex_all_modes(oracle, blocks, expr, icase, **kw)
-    got = gs.all_modes(expr, xsg.FLAG_REGEX | (xsg.FLAG_IGNORE_CASE if icase else 0), lines=with_lines)
+    flags = xsg.FLAG_REGEX | (xsg.FLAG_IGNORE_CASE if icase else 0)
+    try:
+        want, with_lines = oracle_regex_all_modes(oracle, blocks, expr, icase, **kw)
+    except UnsupportedRegex:
+        # an ascii_only expression ('.', negated classes) on data with bytes >= 0x80: every entry point refuses
+        gs.ctx.set_pattern(expr, flags)
+        s = gs.shard
+        calls = [lambda: s.count(xsg.COUNT_MATCHES), lambda: s.search_u64(xsg.MATCH_BYTE_OFFSETS)]
+        n, sets = xsg.regex_check(expr, flags & xsg.FLAG_IGNORE_CASE)
+        if not any((int(sets[k][0]) >> 10) & 1 for k in range(n)):  # line modes too, unless the expression can match '\n'
+            calls += [lambda: s.count(xsg.COUNT_LINES), lambda: s.search_u64(xsg.LINE_INDICES), lambda: s.search_lines()]
+        for call in calls:
+            with pytest.raises(xsg.XsgError) as ei:
+                call()
+            assert ei.value.code == xsg.ENOTSUP and "0x80" in str(ei.value), ctx
+        return None
+    got = gs.all_modes(expr, flags, lines=with_lines)
     for k in want:
         assert got[k] == want[k], f"{ctx} expr={expr!r} icase={icase}: {k}: got {str(got[k])[:160]} want {str(want[k])[:160]}"
     return want
@@ -78,6 +94,46 @@ def test_accepted_expressions_and_literal_only_ones(gs, oracle):
     assert a == gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
 
 
+def test_alternation_dot_and_negation_on_ascii_text(gs, oracle):
+    """round 2 of the regex row: equal-length alternations, '.', negated classes -- on ASCII text, where the
+    byte-per-position reading IS RE2's"""
+    blocks = [corpus.text_block(4242, i, 1_500_000 + 333 * i, needle_rate=1e-4) for i in range(3)]
+    gs.bind(blocks)
+    for expr in (b"Sherlock|She lock", b"Holmes|Watson", b"(Sher|pad)lock", b"She.lock", b"S.{6}k", b"[^a-z]he ",
+                 b"(the|and|for) (cat|dog|she)", b"street|locked|Watson", b"\\D\\d\\D", b"lock[^e]", b"(ab|cd){2}",
+                 b"S(her|HER)lock", b"[[:upper:]][[:lower:]]{5} "):
+        for icase in (False, True):
+            want = check(gs, oracle, blocks, expr, icase, "ascii")
+            assert want is not None
+    # an alternation whose alternatives differ in one position is the class sequence it merges into
+    a = check(gs, oracle, blocks, b"She(r| )lock")
+    b = check(gs, oracle, blocks, b"She[r ]lock")
+    assert a == b and a["count_matches"] > 0
+
+
+def test_ascii_only_expressions_refuse_non_ascii_data(gs, oracle):
+    """'.' and negated classes match whole code points in RE2: on data with a byte >= 0x80 the search is refused
+    (XSG_ENOTSUP), never decided byte by byte; the same data is fine for expressions without them, and the same
+    expressions are fine again on the next ASCII shard (the refusal leaves no state behind)."""
+    import torch
+    text = corpus.text_block(99, 0, 400_000)
+    dirty = text.copy()
+    dirty[123_457:123_459] = (0xc3, 0xa9)  # one 'é' somewhere in the middle
+    gs.bind([text, dirty])
+    assert check(gs, oracle, [text, dirty], b"She.lock") is None
+    assert check(gs, oracle, [text, dirty], b"[^x]he ", True) is None
+    assert check(gs, oracle, [text, dirty], b"She[r ]lock") is not None       # byte-exact on any data
+    assert check(gs, oracle, [text, dirty], b"caf\xc3\xa9|She l") is not None
+    # the asynchronous count has no return code to refuse with: it poisons all four counters
+    gs.ctx.set_pattern(b"t.e", xsg.FLAG_REGEX)
+    c = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    gs.shard.count_async(xsg.COUNT_MATCHES, 0, c.data_ptr())
+    torch.cuda.synchronize()
+    assert all(int(x) == -1 for x in c.cpu())
+    gs.bind([text])
+    assert check(gs, oracle, [text], b"t.e") is not None
+
+
 @pytest.mark.parametrize("expr", REFUSED[:12])
 def test_refused_expressions_fail_loudly(gs, expr):
     with pytest.raises(xsg.XsgError) as ei:
@@ -101,8 +157,8 @@ def regex_rounds(seed, oracle, gs, rounds=20):
                 b[-1] = 10
             blocks.append(b)
         gs.bind(blocks)
-        for _ in range(6):
-            expr = rand_expr(rng)
+        for k in range(6):
+            expr = rand_expr(rng) if k % 2 == 0 else rand_expr2(rng)
             try:
                 xsg.regex_check(expr)
             except xsg.XsgError:

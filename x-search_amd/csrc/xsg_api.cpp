@@ -162,14 +162,14 @@ static uint32_t mask32(size_t n) { return n >= 4 ? 0xffffffffu : (n == 0 ? 0u : 
 // XSG_FLAG_REGEX: a fixed-length class sequence (xsg_classseq.h).  RE2 has no lossy tail, so the
 // matching is exact up to the end of the chunk (as with XSG_FLAG_EXACT_TAIL).
 static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t flags) {
-  std::vector<xsg::ByteSet> seq;
+  xsg::ClassExpr ex;
   std::string err;
-  if (!xsg::compile_class_sequence(re, n, &seq, &err))
-    return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
   const bool icase = (flags & XSG_FLAG_IGNORE_CASE) != 0;
-  if (icase) xsg::fold_sets(&seq);
-  const size_t plen = seq.size();
-  bool literal = true;
+  if (!xsg::compile_class_expr(re, n, icase, &ex, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
+  const size_t plen = ex.npos;
+  const std::vector<xsg::ByteSet> seq = xsg::union_sets(ex);  // what the filter, the overlap and '\n' tests look at
+  bool literal = ex.alts.size() == 1;
   std::vector<uint8_t> lit(plen);
   for (size_t k = 0; k < plen; ++k) {
     const int b = xsg::set_single(seq[k]);
@@ -186,7 +186,8 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   // What the window compare can know about a position: the bits all members of its set agree on (a literal: all
   // eight; [Ss]: seven; [0-9]: the upper four; [a-z]: the upper three).  (x & agree) == (member & agree) holds for
   // every member x, so it is a superset filter at no cost -- the compare is masked per byte anyway -- and the
-  // exact decision against the sets follows for the rare candidate.
+  // exact decision against the sets follows for the rare candidate.  With several alternatives the sets are the
+  // position-wise unions.
   std::vector<uint8_t> agree(plen), value(plen);
   for (size_t k = 0; k < plen; ++k) {
     int first = -1;
@@ -215,10 +216,12 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
     pw[i >> 2] |= (uint32_t)value[koff + i] << (8 * (i & 3));
     mw[i >> 2] |= (uint32_t)agree[koff + i] << (8 * (i & 3));
   }
-  XSG_TRY(c->d_pat.ensure(XSG_MAX_PATTERN + 16));
-  static_assert(xsg::kMaxClassSeq * sizeof(xsg::ByteSet) <= XSG_MAX_PATTERN, "sets must fit the pattern buffer");
-  std::vector<uint8_t> padded(XSG_MAX_PATTERN + 16, 0);
-  memcpy(padded.data(), seq.data(), plen * sizeof(xsg::ByteSet));
+  // device copy: the alternatives' sets, alternative-major ([alt][position], 32 bytes each)
+  constexpr size_t kSetBytes = xsg::kMaxAltSets * sizeof(xsg::ByteSet);
+  XSG_TRY(c->d_pat.ensure(std::max<size_t>(XSG_MAX_PATTERN, kSetBytes) + 16));
+  std::vector<uint8_t> padded(std::max<size_t>(XSG_MAX_PATTERN, kSetBytes) + 16, 0);
+  for (size_t a = 0; a < ex.alts.size(); ++a)
+    memcpy(padded.data() + a * plen * sizeof(xsg::ByteSet), ex.alts[a].data(), plen * sizeof(xsg::ByteSet));
   HIP_TRY(hipMemcpyAsync(c->d_pat.p, padded.data(), padded.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
 
@@ -232,21 +235,40 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = 1u;
   P.icase = icase ? 1u : 0u;
+  P.nalt = (uint32_t)ex.alts.size();
+  P.ascii_only = ex.ascii_only ? 1u : 0u;
   P.has_newline = 0;
-  for (const xsg::ByteSet& s : seq) P.has_newline |= xsg::set_has(s, '\n') ? 1u : 0u;
+  for (const xsg::ByteSet& st : seq) P.has_newline |= xsg::set_has(st, '\n') ? 1u : 0u;
   return XSG_OK;
 }
 
 extern "C" int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets) {
   if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
   if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
-  std::vector<xsg::ByteSet> seq;
+  xsg::ClassExpr ex;
   std::string err;
-  if (!xsg::compile_class_sequence(static_cast<const uint8_t*>(expr), n, &seq, &err))
+  if (!xsg::compile_class_expr(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &ex, &err))
     return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
-  if (flags & XSG_FLAG_IGNORE_CASE) xsg::fold_sets(&seq);
+  const std::vector<xsg::ByteSet> seq = xsg::union_sets(ex);
   if (positions) *positions = (uint32_t)seq.size();
   if (sets) memcpy(sets, seq.data(), seq.size() * sizeof(xsg::ByteSet));
+  return XSG_OK;
+}
+
+extern "C" int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* alternatives,
+                              uint32_t* ascii_only, uint32_t* sets) {
+  if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
+  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  xsg::ClassExpr ex;
+  std::string err;
+  if (!xsg::compile_class_expr(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &ex, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
+  if (positions) *positions = ex.npos;
+  if (alternatives) *alternatives = (uint32_t)ex.alts.size();
+  if (ascii_only) *ascii_only = ex.ascii_only ? 1u : 0u;
+  if (sets)
+    for (size_t a = 0; a < ex.alts.size(); ++a)
+      memcpy(sets + a * ex.npos * 8, ex.alts[a].data(), ex.npos * sizeof(xsg::ByteSet));
   return XSG_OK;
 }
 
@@ -442,6 +464,7 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.tile_nl = s->d_tile_nl.as<uint32_t>();
   a.tile_sum = s->d_tile_sum.as<uint32_t>();
   a.tile_last = s->d_tile_last.as<uint32_t>();
+  a.flags = reinterpret_cast<uint32_t*>(s->d_finish.as<uint64_t>() + 3 * (size_t)kFinishBlocks) + 1;  // behind the ticket
   return a;
 }
 
@@ -517,6 +540,7 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   f.host_counters = host_counters;
   f.partials = s->d_finish.as<uint64_t>();
   f.ticket = reinterpret_cast<uint32_t*>(s->d_finish.as<uint64_t>() + 3 * (size_t)kFinishBlocks);
+  f.flags = a.flags;
   f.total_bytes = s->total_bytes;
   f.want_nl = want_nl;
   f.want_lines = want_lines;
@@ -525,6 +549,15 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   s->cnt_clean = true;
   if (want_lines) s->sum_clean = true;
   if (scan_nl) s->nl_cached = true;
+  return XSG_OK;
+}
+
+static const char* const kNonAsciiMsg =
+    "the expression uses '.', a negated class or \\D \\W \\S, which match whole code points in RE2; the data holds "
+    "bytes >= 0x80, where one byte per position is not the same thing: refused, not approximated";
+
+static int refuse_if_poisoned(const uint64_t counters[XSG_NUM_COUNTERS]) {
+  if (counters[XSG_CTR_BYTES] == UINT64_MAX) return fail(XSG_ENOTSUP, "%s", kNonAsciiMsg);
   return XSG_OK;
 }
 
@@ -583,7 +616,7 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
   HIP_TRY(hipStreamSynchronize(c->stream));
   s->table_pending = false;
   memcpy(counters, s->h_counters, 8 * XSG_NUM_COUNTERS);
-  return XSG_OK;
+  return refuse_if_poisoned(counters);
 }
 
 // Split-phase xsg_count for host pipelines: begin enqueues the pass on the ctx stream (results go to the shard's
@@ -621,7 +654,7 @@ extern "C" int xsg_count_end(xsg_shard* s, uint64_t counters[XSG_NUM_COUNTERS]) 
   HIP_TRY(hipEventSynchronize(s->table_ev));
   s->table_pending = false;
   memcpy(counters, s->h_counters, 8 * XSG_NUM_COUNTERS);
-  return XSG_OK;
+  return refuse_if_poisoned(counters);
 }
 
 extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, float* avg_ms) {
@@ -649,6 +682,7 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *avg_ms = ms / (float)iters;
+  HIP_TRY(hipMemsetAsync(a.flags, 0, 4, c->stream));  // no finish kernel consumed what the scans may have raised
   return XSG_OK;
 }
 
@@ -729,7 +763,14 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(std::max<uint64_t>(ntiles, nchunks) + 1)));
   HIP_TRY(launch_exclusive_scan_u32(a.tile_cnt, s->d_tile_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(), st));
   uint64_t M = 0;
+  uint32_t scan_flags = 0;
+  if (c->pat.kind == kClass && c->pat.ascii_only)
+    HIP_TRY(hipMemcpyAsync(&scan_flags, a.flags, 4, hipMemcpyDeviceToHost, st));
   XSG_TRY(d2h_u64(c, s->d_tile_off.as<uint64_t>() + ntiles, &M));
+  if (scan_flags & 1u) {  // non-ASCII data under an ascii_only expression
+    HIP_TRY(hipMemsetAsync(a.flags, 0, 4, st));
+    return fail(XSG_ENOTSUP, "%s", kNonAsciiMsg);
+  }
 
   // 3. ordered emission of every bulk occurrence
   XSG_TRY(s->d_m_pos.ensure(8 * std::max<uint64_t>(M, 1)));

@@ -47,6 +47,7 @@ struct Parser {
   std::string* err;
   int depth = 0;
   bool ascii_only = false;
+  bool icase = false;
 
   bool fail(const std::string& m) {
     *err = m + " (at byte " + std::to_string(i) + " of the expression)";
@@ -67,7 +68,13 @@ struct Parser {
     return -1;
   }
 
-  static ByteSet ascii_complement(const ByteSet& s) {
+  // Negation under ignore_case: RE2 folds the listed members first ((?i)[^a] excludes 'a' AND 'A'), so they are
+  // closed under ASCII case before the complement is taken.  (Folding the complement afterwards instead would map
+  // the surviving 'A' onto 'a' and let [^a] accept 'a'.)
+  ByteSet ascii_complement(ByteSet s) const {
+    if (icase)
+      for (uint32_t b = 'a'; b <= 'z'; ++b)
+        if (set_has(s, b) || set_has(s, b - 32)) set_add(s, b), set_add(s, b - 32);
     ByteSet r{};
     for (int q = 0; q < 4; ++q) r[q] = ~s[q];  // bytes 0x00..0x7f only
     return r;
@@ -372,10 +379,11 @@ void merge_alternatives(std::vector<std::vector<ByteSet>>* alts) {
 
 }  // namespace
 
-bool compile_class_expr(const uint8_t* re, size_t n, ClassExpr* out, std::string* err) {
+bool compile_class_expr(const uint8_t* re, size_t n, bool ignore_case, ClassExpr* out, std::string* err) {
   *out = ClassExpr{};
   std::vector<ByteSet> unused;
   Parser p{re, n, 0, &unused, err};
+  p.icase = ignore_case;
   Parser::SeqSet alts;
   if (!p.run(&alts)) return false;
   const size_t len = alts[0].size();
@@ -392,6 +400,9 @@ bool compile_class_expr(const uint8_t* re, size_t n, ClassExpr* out, std::string
            " sets)";
     return false;
   }
+  if (ignore_case)  // as for literals: the kernel lowers the data bytes, so every set holds the lowered members
+    for (auto& a : alts) fold_sets(&a);
+  merge_alternatives(&alts);  // folding may have made alternatives equal
   out->npos = (uint32_t)len;
   out->alts = std::move(alts);
   out->ascii_only = p.ascii_only;
@@ -410,7 +421,7 @@ std::vector<ByteSet> union_sets(const ClassExpr& e) {
 bool compile_class_sequence(const uint8_t* re, size_t n, std::vector<ByteSet>* seq, std::string* err) {
   seq->clear();
   ClassExpr e;
-  if (!compile_class_expr(re, n, &e, err)) return false;
+  if (!compile_class_expr(re, n, false, &e, err)) return false;
   if (e.alts.size() != 1 || e.ascii_only) {
     *err = "not a single class sequence";
     return false;

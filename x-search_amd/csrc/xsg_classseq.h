@@ -50,7 +50,9 @@ struct ClassExpr {
   std::vector<std::vector<ByteSet>> alts;  // each npos long
   bool ascii_only = false;
 };
-bool compile_class_expr(const uint8_t* re, size_t n, ClassExpr* out, std::string* err);
+// ignore_case: the sets come back folded (every 'A'..'Z' member replaced by its lower-case letter: the kernel lowers
+// the data), negated classes having been closed under case BEFORE the complement, as RE2's (?i) does.
+bool compile_class_expr(const uint8_t* re, size_t n, bool ignore_case, ClassExpr* out, std::string* err);
 // position-wise union of the alternatives (what a filter or a '\n' / overlap test may look at: a superset)
 std::vector<ByteSet> union_sets(const ClassExpr& e);
 

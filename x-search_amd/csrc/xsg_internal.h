@@ -53,6 +53,9 @@ struct PatternDev {
   uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL
   uint32_t has_newline;     // pattern contains '\n'
   uint32_t icase;           // XSG_FLAG_IGNORE_CASE: data bytes are ASCII-lowered before every compare (pattern is lowered on the host)
+  uint32_t nalt;            // kClass: alternatives (d_pat holds nalt x plen sets, alternative-major); 0/1 otherwise
+  uint32_t ascii_only;      // kClass: the expression is exact on ASCII data only ('.', negated classes): k_scan raises
+                            // ScanArgs::flags bit 0 when it meets a byte >= 0x80
 };
 
 // Per-tile line summaries (XSG_COUNT_LINES): see xsg_linesum.h.
@@ -74,6 +77,7 @@ struct ScanArgs {
   uint32_t* tile_nl;                   // '\n' in the tile              (WANT_NL; every tile is written)
   uint32_t* tile_sum;                  // line summary PER WAVE (4 per tile), stored XOR kSumNl (WANT_LINES)
   uint32_t* tile_last;                 // (epoch << 16) | max (match offset + plen) in the tile, relative to the tile start
+  uint32_t* flags;                     // one word per shard, zero at rest: bit 0 = "non-ASCII byte under an ascii_only expression"
   // inputs/outputs of the emit pass
   const uint64_t* tile_off;  // exclusive prefix of tile_cnt
   uint64_t* m_pos;           // chunk-local offset of every match, ascending
@@ -99,6 +103,7 @@ struct FinishArgs {
   uint64_t* host_counters;  // optional: pinned host mirror of the same four values
   uint64_t* partials;       // scratch: 3 x kFinishBlocks
   uint32_t* ticket;         // zero at rest: the last workgroup to arrive does the final sum and resets it
+  uint32_t* flags;          // ScanArgs::flags: read and cleared by that workgroup; bit 0 poisons the counters (UINT64_MAX)
   uint64_t total_bytes;     // sum of the chunk lengths (host-side knowledge)
   uint32_t want_nl;
   uint32_t want_lines;

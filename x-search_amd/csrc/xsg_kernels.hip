@@ -442,19 +442,30 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
 #pragma unroll
         for (int i = 0; i < (int)kRegVerify / 4; ++i)
           w[i] = *reinterpret_cast<const u32_unaligned*>(lane_view + (uint32_t)start + 4u * (uint32_t)i);
+        uint32_t any = 0;
+        for (uint32_t a = 0; a < P.nalt; ++a) {  // one alternative must accept every position
+          const uint32_t* sa = sets + a * P.plen * 8u;
+          uint32_t oka = 1u;
 #pragma unroll
-        for (int k = 0; k < (int)kRegVerify; ++k) {
-          if ((uint32_t)k < P.plen) {
-            const uint32_t x = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;  // already folded when ICASE
-            ok &= sets[(uint32_t)k * 8u + (x >> 5)] >> (x & 31u);
+          for (int k = 0; k < (int)kRegVerify; ++k) {
+            if ((uint32_t)k < P.plen) {
+              const uint32_t x = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;  // already folded when ICASE
+              oka &= sa[(uint32_t)k * 8u + (x >> 5)] >> (x & 31u);
+            }
           }
+          any |= oka;
         }
+        ok = any;
       } else {
         const uint8_t* s = cbase + unit_off + b - koff;
+        uint32_t alive = P.nalt >= 32u ? 0xffffffffu : (1u << P.nalt) - 1u;  // bit a: alternative a still accepts
         for (uint32_t k = 0; k < P.plen; ++k) {
           const uint32_t x = fold(s[k], ICASE);
-          ok &= sets[k * 8u + (x >> 5)] >> (x & 31u);
+          uint32_t acc = 0;
+          for (uint32_t a = 0; a < P.nalt; ++a) acc |= ((sets[(a * P.plen + k) * 8u + (x >> 5)] >> (x & 31u)) & 1u) << a;
+          alive &= acc;
         }
+        ok = alive != 0;
       }
       if (!(ok & 1u)) m &= ~(1u << b);
     }
@@ -470,6 +481,7 @@ struct WaveState {
   uint32_t wsum = 0;      // line summary of the wave span so far (lane 0); 0 is the identity
   bool run_nl = false;    // the current run of match-less loads holds a newline (wave-uniform)
   uint32_t masks[4] = {0, 0, 0, 0};
+  uint32_t hi = 0;        // OR of the lane's bytes (ascii_only expressions: bit 7 of any byte set = non-ASCII data)
 };
 
 // One wave-load (1 KiB): `cur` is this lane's 16-byte unit, `nx` the unit that
@@ -515,6 +527,9 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
   d[4] = from_next_lane(own0, e0, lane);
   d[5] = from_next_lane(own1, e1, lane);
   const uint32_t(&nlsrc)[8] = LAZY ? r : d;  // own bytes as the newline tests must see them
+  if (KIND == kClass) {
+    if (P.ascii_only) st.hi |= r[0] | r[1] | r[2] | r[3];  // own bytes (beyond the chunk end: cleared); folding keeps bit 7
+  }
 
   if (WANT_NL) st.nlc += nl_count16(nlsrc);
 
@@ -571,7 +586,18 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
       Pf.p0 = P.q0;
       Pf.p1 = P.q1;
     }
-    const bool any_c = (KIND == kTwo || KIND == kLong || KIND == kClass) ? trigger_aligned<KIND>(d, Pf) : cand_any<KIND>(d, Pf);
+    // 8-byte-window kinds: a cascade.  The aligned-dword trigger (25 compares, 4 of the 8 bytes for three of the
+    // four alignments) runs always; only a wave-load that passes it pays for the window filter proper (20
+    // unaligned windows x 2 compares), and only one that passes that too takes the exact slow path.  Sub-dwords
+    // that are common in the text (a window made of lexicon words) thus cost what the window filter alone did
+    // before, everything else about half.
+    bool any_c;
+    if (KIND == kTwo || KIND == kLong || KIND == kClass) {
+      any_c = false;
+      if (__ballot(trigger_aligned<KIND>(d, Pf)) != 0) any_c = cand_any<KIND>(d, Pf);
+    } else {
+      any_c = cand_any<KIND>(d, Pf);
+    }
     if (__ballot(any_c) != 0) {
       if (LAZY) {  // now the exact view: properly folded bytes, own and neighbour's
         const uint32_t f0 = fold4(cur.x), f1 = fold4(cur.y);
@@ -625,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   constexpr uint32_t kTile = kWaveSpan * kWaves;         // bytes per workgroup
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
-  __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND >= kLong ? XSG_MAX_PATTERN : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND == kClass ? 2048 : KIND == kLong ? XSG_MAX_PATTERN : 16];
   __shared__ __attribute__((aligned(16))) uint8_t s_view[KIND == kClass ? kBlock * 48 : 16];  // match_mask16<kClass>
 
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
@@ -641,8 +667,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
     for (uint32_t k = tid; k < P.plen; k += kBlock) s_pat[k] = P.d_pat[k];
     __syncthreads();
   }
-  if (KIND == kClass) {  // 256-bit set per position (P.plen <= 32: at most 1 KiB)
-    for (uint32_t k = tid; k < P.plen * 8u; k += kBlock)
+  if (KIND == kClass) {  // 256-bit set per alternative and position (at most 64 sets = 2 KiB)
+    for (uint32_t k = tid; k < P.plen * P.nalt * 8u; k += kBlock)
       reinterpret_cast<uint32_t*>(s_pat)[k] = reinterpret_cast<const uint32_t*>(P.d_pat)[k];
     __syncthreads();
   }
@@ -730,6 +756,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   for (int j = 0; j < kLoads; ++j) masks[j] = st.masks[j < 4 ? j : 0];
   if (WANT_LINES && !EMIT && run_nl) wsum = sum_combine(wsum, kSumNl);
 
+  if (KIND == kClass) {
+    if (P.ascii_only && __any((st.hi & 0x80808080u) != 0) && lane == 0) atomicOr(A.flags, 1u);  // the search must refuse
+  }
   if (!EMIT) {
     // ---- epilogue.  A store per tile, however small, interleaves writes into the
     // read stream (DRAM bus turnarounds): a probe kernel with k_scan's loads lost
@@ -1087,16 +1116,16 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   a1 = block_sum_u64(a1, sh);
   a2 = block_sum_u64(a2, sh);
   if (threadIdx.x == 0) {
-    A.counters[XSG_CTR_MATCHES] = a0;
-    A.counters[XSG_CTR_LINES] = a1;
-    A.counters[XSG_CTR_NEWLINES] = a2;
-    A.counters[XSG_CTR_BYTES] = A.total_bytes;  // known on the host
-    if (A.host_counters) {
-      A.host_counters[XSG_CTR_MATCHES] = a0;
-      A.host_counters[XSG_CTR_LINES] = a1;
-      A.host_counters[XSG_CTR_NEWLINES] = a2;
-      A.host_counters[XSG_CTR_BYTES] = A.total_bytes;
+    // an ascii_only expression met non-ASCII data: no number is handed out (all four counters read UINT64_MAX)
+    const bool refuse = A.pat.kind == kClass && A.pat.ascii_only &&
+                        (__hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0;
+    const uint64_t v[XSG_NUM_COUNTERS] = {refuse ? UINT64_MAX : a0, refuse ? UINT64_MAX : a1, refuse ? UINT64_MAX : a2,
+                                          refuse ? UINT64_MAX : A.total_bytes};
+    for (int k = 0; k < XSG_NUM_COUNTERS; ++k) {
+      A.counters[k] = v[k];
+      if (A.host_counters) A.host_counters[k] = v[k];
     }
+    *A.flags = 0u;
     *A.ticket = 0u;  // at rest for the next launch (stream order)
   }
 }

@@ -100,6 +100,7 @@ def load():
         "xsg_ctx_destroy": (None, [vp]),
         "xsg_set_pattern": (ci, [vp, C.c_char_p, sz, u32]),
         "xsg_regex_check": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32)]),
+        "xsg_regex_info": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "xsg_shard_create": (ci, [vp, vp, u64, vp, u64, C.POINTER(vp)]),
         "xsg_shard_rebind": (ci, [vp, vp, u64, vp, u64]),
         "xsg_shard_destroy": (None, [vp]),
@@ -166,7 +167,7 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_host_offsets", "xsg_host_lines", "xsg_scan_kernel_name", "xsg_shard_tune", "xsg_count_begin",
            "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
            "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
-           "xsg_jobs_reduce_total", "xsg_device_numa"]
+           "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info"]
 
 
 def _check(rc):
@@ -181,6 +182,16 @@ def regex_check(expr: bytes, flags: int = 0):
     sets = np.zeros((32, 8), dtype=np.uint32)
     _check(lib.xsg_regex_check(expr, len(expr), flags, C.byref(n), sets.ctypes.data_as(C.POINTER(C.c_uint32))))
     return int(n.value), sets[:n.value].copy()
+
+
+def regex_info(expr: bytes, flags: int = 0):
+    """-> (positions, alternatives, ascii_only, sets[alternatives, positions, 8] uint32); raises XsgError if refused"""
+    lib = load()
+    n, na, ao = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    sets = np.zeros((64, 8), dtype=np.uint32)
+    _check(lib.xsg_regex_info(expr, len(expr), flags, C.byref(n), C.byref(na), C.byref(ao),
+                              sets.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return int(n.value), int(na.value), bool(ao.value), sets[:n.value * na.value].reshape(na.value, n.value, 8).copy()
 
 
 def device_count() -> int:
