@@ -22,8 +22,21 @@ def upload(blocks, global_offsets=None, line_bases=None):
 class GpuSearch:
     """One context + one shard, re-bound per case."""
 
-    def __init__(self):
-        self.ctx = xsg.Context(0)
+    def __init__(self, hot=None):
+        """hot=0/1 pins the hot filter of the 8-byte-window kinds (XSG_HOT, read when the context is created):
+        the test shards are far below the size at which the library measures and picks one itself."""
+        import os
+        old = os.environ.get("XSG_HOT")
+        if hot is not None:
+            os.environ["XSG_HOT"] = str(hot)
+        try:
+            self.ctx = xsg.Context(0)
+        finally:
+            if hot is not None:
+                if old is None:
+                    del os.environ["XSG_HOT"]
+                else:
+                    os.environ["XSG_HOT"] = old
         self.shard = None
         self.keep = None
 

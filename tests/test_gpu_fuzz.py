@@ -74,3 +74,10 @@ def fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_fuzz(seed, oracle):
     fuzz_rounds(seed, oracle, GpuSearch())
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_with_the_aligned_dword_trigger(seed, oracle):
+    """the other hot filter of the 8-byte-window kinds (k_scan<..., ALIGNED = true>), which the library only picks
+    by measurement on shards of 64 MiB and more: pinned here"""
+    fuzz_rounds(seed, oracle, GpuSearch(hot=1))

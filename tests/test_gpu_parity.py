@@ -48,6 +48,19 @@ def test_reference_unit_test_known_answers(gs):
             gs.ctx.set_pattern(_b(p))
             offs = gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
             assert (offs[0] if offs else -1) == want, p
+    # findNext / findNextNewLine with shift != 0 (simd_searchTest.cpp:62-81): the reference searches str + shift
+    # for len - shift bytes (simd_search.cpp:289-303), i.e. the suffix as a chunk of its own -- its 32-byte blocks and
+    # its scalar tail are anchored at the shift -- and adds the shift back
+    for p, shift, want in ka["findNext"]:
+        gs.bind([text[shift:].copy()])
+        gs.ctx.set_pattern(_b(p))
+        offs = gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
+        assert (offs[0] + shift if offs else -1) == want, (p, shift)
+    for shift, want in ka["findNextNewLine"]:
+        gs.bind([text[shift:].copy()])
+        gs.ctx.set_pattern(b"\n")
+        offs = gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
+        assert (offs[0] + shift if offs else -1) == want, shift
     kw = G.load("ref_search_wrappers_known_answers.json")
     gs.bind([np.frombuffer(_b(kw["text"]), dtype=np.uint8)])
     r = gs.all_modes(_b(kw["pattern"]))

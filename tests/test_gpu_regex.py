@@ -171,6 +171,11 @@ def test_random_expressions(gs, oracle, seed):
     regex_rounds(seed, oracle, gs)
 
 
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_expressions_with_the_aligned_dword_trigger(oracle, seed):
+    regex_rounds(seed, oracle, GpuSearch(hot=1))
+
+
 def test_global_offsets_line_bases_and_job_api(gs, oracle, tmp_path):
     blocks = [corpus.text_block(77, i, 200_000) for i in range(3)]
     goffs = [10**9, 5 * 10**9, 2**40]

@@ -91,6 +91,7 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
     return fail(XSG_ENODEV, "device %d is %s; this library carries gfx950 (MI355X) code only", device, a.c_str());
   }
   if (const char* tn = getenv("XSG_TUNE")) c->tune = (uint32_t)strtoul(tn, nullptr, 0);
+  if (const char* hf = getenv("XSG_HOT")) c->hot_env = (*hf == '0' || *hf == '1') ? *hf - '0' : -1;
   if (const char* tk = getenv("XSG_TILE_KIB")) {
     const int v = atoi(tk);
     if (v == 16) c->tile_bytes = (uint32_t)v * 1024u;
@@ -182,6 +183,7 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   HIP_TRY(hipSetDevice(c->device));
   c->pattern.assign(re, re + n);
   c->flags = flags;
+  ++c->pattern_serial;
   c->bordered = xsg::sequence_can_overlap(seq);
   // What the window compare can know about a position: the bits all members of its set agree on (a literal: all
   // eight; [Ss]: seven; [0-9]: the upper four; [a-z]: the upper three).  (x & agree) == (member & agree) holds for
@@ -286,6 +288,7 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
       if (b >= 'A' && b <= 'Z') b = (uint8_t)(b + 32);
   const uint8_t* p = c->pattern.data();
   c->flags = flags;
+  ++c->pattern_serial;
   // border <=> the pattern can overlap itself (KMP failure function of the last position > 0)
   std::vector<uint32_t> pi(plen, 0);
   for (size_t i = 1, k = 0; i < plen; ++i) {
@@ -365,6 +368,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
 
   // whatever was derived from the old binding's bytes is void
   s->nl_cached = s->nl_off_cached = false;
+  s->hot_serial = 0;
   bool grew = false;
   XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
   XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
@@ -460,6 +464,7 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.tune = s->ctx->tune != kTuneAuto ? s->ctx->tune : s->tune;  // XSG_TUNE, else xsg_shard_tune's choice, else per variant
   a.epoch = s->epoch;
   a.pat = s->ctx->pat;
+  a.pat.hot = s->ctx->hot_env >= 0 ? (uint32_t)s->ctx->hot_env : (s->hot_serial == s->ctx->pattern_serial ? s->hot : 0u);
   a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
   a.tile_nl = s->d_tile_nl.as<uint32_t>();
   a.tile_sum = s->d_tile_sum.as<uint32_t>();
@@ -512,9 +517,49 @@ static int ensure_tile_nl(xsg_shard* s) {
   return XSG_OK;
 }
 
+static bool is_window_kind(uint32_t k) { return k == kTwo || k == kLong || k == kClass; }
+
+// The window kinds have two hot filters (k_scan<..., ALIGNED>): the aligned-dword trigger does half the VALU work
+// but looks at 4 bytes of the window where the window filter looks at 8, so text in which the window's 4-byte
+// pieces are common (a window made of words of the text) sends it into the slow path all the time.  Which one is
+// faster is a property of (pattern, data): measured once per binding and pattern on a prefix of the shard (up to
+// 256 MiB: four launches of ~50 us and one sync), remembered until the shard is re-bound or the pattern changes.
+// Shards under 64 MiB keep the window filter (their scans take microseconds either way); XSG_HOT pins the choice.
+static int choose_hot_filter(xsg_shard* s, bool want_nl, bool want_lines, hipStream_t st) {
+  xsg_ctx* c = s->ctx;
+  if (!is_window_kind(c->pat.kind) || c->hot_env >= 0 || s->hot_serial == c->pattern_serial) return XSG_OK;
+  s->hot = 0;
+  s->hot_serial = c->pattern_serial;
+  if (s->total_bytes < (64ull << 20)) return XSG_OK;
+  XSG_TRY(prepare_tiles(s, want_lines, st));
+  s->cnt_clean = s->sum_clean = false;  // no finish kernel behind these launches
+  hipEvent_t ev[3];
+  for (hipEvent_t& e : ev) HIP_TRY(hipEventCreate(&e));
+  float ms[2] = {0, 0};
+  int rc = XSG_OK;
+  for (uint32_t hot = 0; hot < 2 && rc == XSG_OK; ++hot) {
+    ScanArgs a = scan_args(s);
+    a.pat.hot = hot;
+    a.ntiles = std::min<uint64_t>(a.ntiles, 16384);
+    hipError_t e = launch_scan_count(a, want_nl, want_lines, st);  // warm-up (also pulls the code in)
+    if (e == hipSuccess) e = hipEventRecord(ev[0], st);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_scan_count(a, want_nl, want_lines, st);
+    if (e == hipSuccess) e = hipEventRecord(ev[1], st);
+    if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms[hot], ev[0], ev[1]);
+    if (e != hipSuccess) rc = fail(XSG_EHIP, "hot-filter probe failed: %s", hipGetErrorString(e));
+  }
+  for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
+  if (rc != XSG_OK) return rc;
+  HIP_TRY(hipMemsetAsync(scan_args(s).flags, 0, 4, st));
+  s->hot = ms[1] < 0.97f * ms[0] ? 1u : 0u;  // the aligned trigger has to win clearly
+  return XSG_OK;
+}
+
 static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool want_nl, hipStream_t st,
                          uint64_t* d_counters, uint64_t* host_counters) {
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
+  XSG_TRY(choose_hot_filter(s, want_nl && !s->nl_cached, want_lines, st));
   const uint64_t nchunks = s->chunks.size();
   XSG_TRY(prepare_tiles(s, want_lines, st));
   const bool scan_nl = want_nl && !s->nl_cached;  // the per-tile newline counts of this binding may already exist
@@ -666,6 +711,7 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
   const bool want_lines = m == XSG_COUNT_LINES;
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
+  XSG_TRY(choose_hot_filter(s, want_nl, want_lines, c->stream));  // time what a real pass of this mode would launch
   XSG_TRY(prepare_tiles(s, want_lines, c->stream));
   ScanArgs a = scan_args(s);
   s->cnt_clean = s->sum_clean = false;  // no finish kernel runs behind these launches
@@ -710,18 +756,25 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   if (c->tune != kTuneAuto || s->total_bytes < (1ull << 30)) return XSG_OK;  // XSG_TUNE wins; too small to measure
   static const uint32_t cand[] = {0, 4, 8, 10, 12, 14, 16, 20};
   float best_ms = 0;
-  uint32_t best = kTuneAuto;
-  for (uint32_t t : cand) {
-    s->tune = t;
-    float ms = 0;
-    const int r = xsg_time_scan_kernel(s, mode, 3, &ms);
-    if (r != XSG_OK) {
-      s->tune = kTuneAuto;
-      return r;
+  uint32_t best = kTuneAuto, best_hot = 0;
+  const uint32_t nhot = (is_window_kind(c->pat.kind) && c->hot_env < 0) ? 2u : 1u;
+  for (uint32_t hot = 0; hot < nhot; ++hot) {
+    s->hot = hot;
+    s->hot_serial = c->pattern_serial;
+    for (uint32_t t : cand) {
+      s->tune = t;
+      float ms = 0;
+      const int r = xsg_time_scan_kernel(s, mode, 3, &ms);
+      if (r != XSG_OK) {
+        s->tune = kTuneAuto;
+        s->hot_serial = 0;
+        return r;
+      }
+      if (best == kTuneAuto || ms < best_ms) best_ms = ms, best = t, best_hot = hot;
     }
-    if (best == kTuneAuto || ms < best_ms) best_ms = ms, best = t;
   }
   s->tune = best;
+  s->hot = best_hot;
   if (chosen) *chosen = best;
   return XSG_OK;
 }
@@ -751,6 +804,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
 
   // 1. bulk count per tile
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
+  XSG_TRY(choose_hot_filter(s, want_nl && !s->nl_cached, false, st));
   XSG_TRY(prepare_tiles(s, false, st));
   ScanArgs a = scan_args(s);
   s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them

@@ -488,7 +488,7 @@ struct WaveState {
 // follows the wave-load (lane 0's unit of the next load, or the bytes after the
 // span).  CAREFUL: the wave-load may reach past the end of the chunk.
 // Returns the lane's exact match-start bits (also accumulated into `st`).
-template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool CAREFUL>
+template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool CAREFUL, bool ALIGNED>
 __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, bool nx_is_vgpr, uint64_t unit_off,
                                               uint32_t lane, uint64_t L, uint64_t limit, const PatternDev& P,
                                               const uint8_t* cbase, const uint8_t* s_pat, uint8_t* s_view,
@@ -586,18 +586,14 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
       Pf.p0 = P.q0;
       Pf.p1 = P.q1;
     }
-    // 8-byte-window kinds: a cascade.  The aligned-dword trigger (25 compares, 4 of the 8 bytes for three of the
-    // four alignments) runs always; only a wave-load that passes it pays for the window filter proper (20
-    // unaligned windows x 2 compares), and only one that passes that too takes the exact slow path.  Sub-dwords
-    // that are common in the text (a window made of lexicon words) thus cost what the window filter alone did
-    // before, everything else about half.
-    bool any_c;
-    if (KIND == kTwo || KIND == kLong || KIND == kClass) {
-      any_c = false;
-      if (__ballot(trigger_aligned<KIND>(d, Pf)) != 0) any_c = cand_any<KIND>(d, Pf);
-    } else {
-      any_c = cand_any<KIND>(d, Pf);
-    }
+    // 8-byte-window kinds: two hot filters, one per kernel instantiation.  ALIGNED: the aligned-dword trigger (25
+    // compares; 4 of the 8 window bytes for three of the four alignments) straight in front of the exact slow
+    // path -- half the VALU work of the window filter, the right choice whenever the window's 4-byte pieces are
+    // rare in the text.  Otherwise the window filter proper (20 unaligned windows x 2 compares).  Which one runs
+    // is decided per shard and pattern by measurement (xsg_api.cpp: choose_hot_filter); running both as a cascade
+    // was measured slower than either (the straight-line body outgrows the instruction cache).
+    const bool any_c = (ALIGNED && (KIND == kTwo || KIND == kLong || KIND == kClass)) ? trigger_aligned<KIND>(d, Pf)
+                                                                                    : cand_any<KIND>(d, Pf);
     if (__ballot(any_c) != 0) {
       if (LAZY) {  // now the exact view: properly folded bytes, own and neighbour's
         const uint32_t f0 = fold4(cur.x), f1 = fold4(cur.y);
@@ -644,7 +640,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
 // summaries.  EMIT=true: the same decisions, writing every match offset at its
 // rank (tile_off[tile] + rank inside the tile).
 // ---------------------------------------------------------------------------
-template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, int LOADS, bool ICASE>
+template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, int LOADS, bool ICASE, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   constexpr int kLoads = LOADS;                          // 16-byte units per lane
   constexpr uint32_t kWaveSpan = kWaveLoad * kLoads;     // contiguous bytes per wave
@@ -734,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
-      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, false>(
+      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, false, ALIGNED>(
           v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit, lane, L, limit, P, cbase,
           s_pat, s_view, st);
     }
@@ -742,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
-      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, true>(
+      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, true, ALIGNED>(
           v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit, lane, L, limit, P, cbase,
           s_pat, s_view, st);
     }
@@ -818,22 +814,22 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   }
 }
 
-template <int KIND, bool ICASE>
+template <int KIND, bool ICASE, bool ALIGNED>
 static hipError_t launch_scan_kind(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, dim3 grid,
                                    hipStream_t s) {
   constexpr int LOADS = 4;  // 16 KiB tiles (32 KiB measured 8 % slower)
   if (emit) {
-    hipLaunchKernelGGL((k_scan<KIND, false, false, true, LOADS, ICASE>), grid, dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((k_scan<KIND, false, false, true, LOADS, ICASE, ALIGNED>), grid, dim3(kBlock), 0, s, a);
   } else if (want_lines) {
     if (want_nl)
-      hipLaunchKernelGGL((k_scan<KIND, true, true, false, LOADS, ICASE>), grid, dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_scan<KIND, true, true, false, LOADS, ICASE, ALIGNED>), grid, dim3(kBlock), 0, s, a);
     else
-      hipLaunchKernelGGL((k_scan<KIND, false, true, false, LOADS, ICASE>), grid, dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_scan<KIND, false, true, false, LOADS, ICASE, ALIGNED>), grid, dim3(kBlock), 0, s, a);
   } else {
     if (want_nl)
-      hipLaunchKernelGGL((k_scan<KIND, true, false, false, LOADS, ICASE>), grid, dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_scan<KIND, true, false, false, LOADS, ICASE, ALIGNED>), grid, dim3(kBlock), 0, s, a);
     else
-      hipLaunchKernelGGL((k_scan<KIND, false, false, false, LOADS, ICASE>), grid, dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_scan<KIND, false, false, false, LOADS, ICASE, ALIGNED>), grid, dim3(kBlock), 0, s, a);
   }
   return hipGetLastError();
 }
@@ -842,8 +838,12 @@ template <int KIND>
 static hipError_t launch_scan_loads(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, dim3 grid,
                                     hipStream_t s) {
   if (a.tile_bytes != kDefaultTileBytes) return hipErrorInvalidValue;
-  return a.pat.icase ? launch_scan_kind<KIND, true>(a, want_nl, want_lines, emit, grid, s)
-                     : launch_scan_kind<KIND, false>(a, want_nl, want_lines, emit, grid, s);
+  constexpr bool kWindow = KIND == kTwo || KIND == kLong || KIND == kClass;
+  if (kWindow && a.pat.hot)  // the aligned-dword trigger exists for the 8-byte-window kinds only
+    return a.pat.icase ? launch_scan_kind<KIND, true, kWindow>(a, want_nl, want_lines, emit, grid, s)
+                       : launch_scan_kind<KIND, false, kWindow>(a, want_nl, want_lines, emit, grid, s);
+  return a.pat.icase ? launch_scan_kind<KIND, true, false>(a, want_nl, want_lines, emit, grid, s)
+                     : launch_scan_kind<KIND, false, false>(a, want_nl, want_lines, emit, grid, s);
 }
 
 static dim3 tile_grid(uint64_t ntiles) {
@@ -870,8 +870,10 @@ static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, b
 void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap) {
   if (!out || !cap) return;
   const char* b[2] = {"false", "true"};
-  snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s> stagger=%u", (int)a.pat.kind, b[emit ? 0 : want_nl],
-           b[emit ? 0 : want_lines], b[emit], b[a.pat.icase ? 1 : 0], pick_stagger(a, want_nl, want_lines, emit));
+  const bool window = a.pat.kind == kTwo || a.pat.kind == kLong || a.pat.kind == kClass;
+  snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s, %s> stagger=%u", (int)a.pat.kind, b[emit ? 0 : want_nl],
+           b[emit ? 0 : want_lines], b[emit], b[a.pat.icase ? 1 : 0], b[window && a.pat.hot ? 1 : 0],
+           pick_stagger(a, want_nl, want_lines, emit));
 }
 
 static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_lines, bool emit, hipStream_t s) {
@@ -1537,16 +1539,38 @@ __global__ __launch_bounds__(kBlock) void k_line_lengths(const LineOutArgs A) {
   A.out_u64[i] = ch.global_offset + A.f_pos[i];
 }
 
-// one wave per line copies its bytes to the packed output
+// xs::lines: the bytes of every reported line, packed.  One THREAD per line: a line of text is a few dozen bytes,
+// which a lane moves with one or two 16-byte loads and stores (unaligned global accesses are native on gfx950) --
+// a wave per line, the first version, kept 64 lanes busy with 30 bytes (19 ms for the 66 M lines that contain
+// `She` in 10 GiB).  Lines over 256 bytes wait until the wave has finished its short ones and are then copied by
+// all 64 lanes together, 1 KiB a step.
+typedef uint4 uint4_unaligned __attribute__((aligned(1)));
 __global__ __launch_bounds__(kBlock) void k_line_gather(const LineOutArgs A) {
-  const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
-  if (i >= A.total) return;
-  const uint64_t len = A.line_len[i];
-  if (len == UINT64_MAX) return;
-  const uint8_t* src = A.base + A.chunks[A.f_chunk[i]].offset + A.f_pos[i];
-  uint8_t* dst = A.line_bytes + A.line_out_off[i];
-  for (uint64_t k = lane; k < len; k += 64) dst[k] = src[k];
+  uint64_t len = i < A.total ? A.line_len[i] : UINT64_MAX;
+  const bool live = len != UINT64_MAX;  // UINT64_MAX: no terminating newline -> not reported
+  const uint8_t* src = live ? A.base + A.chunks[A.f_chunk[i]].offset + A.f_pos[i] : nullptr;
+  uint8_t* dst = live ? A.line_bytes + A.line_out_off[i] : nullptr;
+  if (!live) len = 0;
+  const bool big = len > 256;
+  if (!big) {
+    uint64_t k = 0;
+    for (; k + 16 <= len; k += 16) *reinterpret_cast<uint4_unaligned*>(dst + k) = *reinterpret_cast<const uint4_unaligned*>(src + k);
+    for (; k < len; ++k) dst[k] = src[k];
+  }
+  unsigned long long pend = __ballot(big);
+  while (pend) {  // wave-uniform
+    const int L = __builtin_ctzll(pend);
+    pend &= pend - 1ull;
+    const uint8_t* s2 = reinterpret_cast<const uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)src, L));
+    uint8_t* d2 = reinterpret_cast<uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)dst, L));
+    const uint64_t n2 = (uint64_t)__shfl((long long)len, L);
+    const uint64_t whole = n2 & ~(uint64_t)15;
+    for (uint64_t k = (uint64_t)lane * 16u; k < whole; k += 64u * 16u)
+      *reinterpret_cast<uint4_unaligned*>(d2 + k) = *reinterpret_cast<const uint4_unaligned*>(s2 + k);
+    if (whole + lane < n2) d2[whole + lane] = s2[whole + lane];
+  }
 }
 
 hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s) {
@@ -1572,7 +1596,7 @@ hipError_t launch_line_lengths(const LineOutArgs& a, hipStream_t s) {
 }
 hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s) {
   if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_line_gather, grid_for(a.total * 64), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(k_line_gather, grid_for(a.total), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 
