@@ -523,27 +523,32 @@ static bool is_window_kind(uint32_t k) { return k == kTwo || k == kLong || k == 
 // but looks at 4 bytes of the window where the window filter looks at 8, so text in which the window's 4-byte
 // pieces are common (a window made of words of the text) sends it into the slow path all the time.  Which one is
 // faster is a property of (pattern, data): measured once per binding and pattern on a prefix of the shard (up to
-// 256 MiB: four launches of ~50 us and one sync), remembered until the shard is re-bound or the pattern changes.
-// Shards under 64 MiB keep the window filter (their scans take microseconds either way); XSG_HOT pins the choice.
-static int choose_hot_filter(xsg_shard* s, bool want_nl, bool want_lines, hipStream_t st) {
+// 2 GiB, a few launches of a fraction of a millisecond and one sync), remembered until the shard is re-bound or the
+// pattern changes.  The probe runs the newline-counting variant whatever the caller's mode: it is the
+// VALU-heaviest, so it shows a difference that the plain count -- HBM-bound with either filter -- hides, and a
+// filter with less ALU work is the right one for the light variants too.  Shards under 64 MiB keep the window
+// filter (their scans take microseconds either way); XSG_HOT pins the choice.
+static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   xsg_ctx* c = s->ctx;
   if (!is_window_kind(c->pat.kind) || c->hot_env >= 0 || s->hot_serial == c->pattern_serial) return XSG_OK;
   s->hot = 0;
   s->hot_serial = c->pattern_serial;
   if (s->total_bytes < (64ull << 20)) return XSG_OK;
-  XSG_TRY(prepare_tiles(s, want_lines, st));
-  s->cnt_clean = s->sum_clean = false;  // no finish kernel behind these launches
-  hipEvent_t ev[3];
+  XSG_TRY(ensure_tile_nl(s));
+  XSG_TRY(prepare_tiles(s, false, st));
+  s->cnt_clean = false;  // no finish kernel behind these launches
+  hipEvent_t ev[2];
   for (hipEvent_t& e : ev) HIP_TRY(hipEventCreate(&e));
   float ms[2] = {0, 0};
   int rc = XSG_OK;
   for (uint32_t hot = 0; hot < 2 && rc == XSG_OK; ++hot) {
     ScanArgs a = scan_args(s);
     a.pat.hot = hot;
-    a.ntiles = std::min<uint64_t>(a.ntiles, 16384);
-    hipError_t e = launch_scan_count(a, want_nl, want_lines, st);  // warm-up (also pulls the code in)
+    a.tune = 0;
+    a.ntiles = std::min<uint64_t>(a.ntiles, 131072);
+    hipError_t e = launch_scan_count(a, true, false, st);  // warm-up (also pulls the code in)
     if (e == hipSuccess) e = hipEventRecord(ev[0], st);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_scan_count(a, want_nl, want_lines, st);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = launch_scan_count(a, true, false, st);
     if (e == hipSuccess) e = hipEventRecord(ev[1], st);
     if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
     if (e == hipSuccess) e = hipEventElapsedTime(&ms[hot], ev[0], ev[1]);
@@ -559,7 +564,7 @@ static int choose_hot_filter(xsg_shard* s, bool want_nl, bool want_lines, hipStr
 static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool want_nl, hipStream_t st,
                          uint64_t* d_counters, uint64_t* host_counters) {
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
-  XSG_TRY(choose_hot_filter(s, want_nl && !s->nl_cached, want_lines, st));
+  XSG_TRY(choose_hot_filter(s, st));
   const uint64_t nchunks = s->chunks.size();
   XSG_TRY(prepare_tiles(s, want_lines, st));
   const bool scan_nl = want_nl && !s->nl_cached;  // the per-tile newline counts of this binding may already exist
@@ -711,7 +716,7 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
   const bool want_lines = m == XSG_COUNT_LINES;
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
-  XSG_TRY(choose_hot_filter(s, want_nl, want_lines, c->stream));  // time what a real pass of this mode would launch
+  XSG_TRY(choose_hot_filter(s, c->stream));  // time what a real pass of this mode would launch
   XSG_TRY(prepare_tiles(s, want_lines, c->stream));
   ScanArgs a = scan_args(s);
   s->cnt_clean = s->sum_clean = false;  // no finish kernel runs behind these launches
@@ -804,7 +809,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
 
   // 1. bulk count per tile
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
-  XSG_TRY(choose_hot_filter(s, want_nl && !s->nl_cached, false, st));
+  XSG_TRY(choose_hot_filter(s, st));
   XSG_TRY(prepare_tiles(s, false, st));
   ScanArgs a = scan_args(s);
   s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them

@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(kBlock) void k_line_lengths(const LineOutArgs A) {
 // a wave per line, the first version, kept 64 lanes busy with 30 bytes (19 ms for the 66 M lines that contain
 // `She` in 10 GiB).  Lines over 256 bytes wait until the wave has finished its short ones and are then copied by
 // all 64 lanes together, 1 KiB a step.
-typedef uint4 uint4_unaligned __attribute__((aligned(1)));
+typedef unsigned int uint4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 __global__ __launch_bounds__(kBlock) void k_line_gather(const LineOutArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
