@@ -33,6 +33,7 @@ def main():
     rd, wr = 2.0 * fetch_kb * 1024.0, write_kb * 1024.0
     out = {
         "kernel": bench["roofline"]["kernel"],
+        "pattern": bench["config"]["pattern"],
         "config": bench["config"]["workload"],
         "bytes_per_gpu": bench["config"]["bytes_per_gpu"],
         "FETCH_SIZE_KB_avg": fetch_kb, "WRITE_SIZE_KB_avg": write_kb, "launches_averaged": [nf, nw],
@@ -40,9 +41,10 @@ def main():
                       "MI355X_MICROARCH.md HBM section); WRITE_SIZE x 1024 exact",
         "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
         "algorithmic_bytes_per_launch": alg, "ratio_traffic_over_algorithmic": (rd + wr) / alg,
-        "collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (scripts/gpu_bench.sh {tag})",
+        "collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (scripts/gpu_profiles.sh {tag})",
     }
-    (ROOT / "profiles" / "pmc_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
+    name = f"{tag}_pmc_traffic.json" if tag else "pmc_traffic.json"
+    (ROOT / "profiles" / name).write_text(json.dumps(out, indent=1) + "\n")
     print(json.dumps(out))
 
 

@@ -108,3 +108,20 @@ def test_jobs_total_over_rccl_or_host(tmp_path, blocks, oracle):
     assert via == (ndev >= 2)
     for j in jobs:
         j.close()
+
+
+def test_distributed_search_over_the_library_collective(tmp_path, blocks, oracle):
+    """x-search_amd/dist_search.py with the exchange step on the library's RCCL communicator (one rank here: the
+    communicator, the all-reduce and the all-gather are real, the clique has one member)"""
+    from dist_search import LibraryCollective, distributed_search
+    p = tmp_path / "d.txt"
+    data = np.concatenate(blocks)
+    data.tofile(p)
+    coll = LibraryCollective(None, 0)
+    try:
+        want = sum(oracle.count(b, b"Sherlock", False) for b in blocks)
+        assert distributed_search(b"Sherlock", str(p), xsg.COUNT_MATCHES, chunk_bytes=1 << 18, collective=coll) == want
+        idx = distributed_search(b"Sherlock", str(p), xsg.LINE_INDICES, chunk_bytes=1 << 18, collective=coll)
+        assert idx.tolist() == oracle.line_indices(data, b"Sherlock").tolist()
+    finally:
+        coll.close()

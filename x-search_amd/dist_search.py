@@ -43,13 +43,46 @@ def _gpu_scan_range(pattern, path, mode, meta_path, lo, hi, device, num_threads,
         j.close()
 
 
+class LibraryCollective:
+    """The exchange step through the library's own RCCL communicator (include/xsg.h "Multi-GPU", rank form) instead
+    of torch.distributed's: rank 0 makes the id, `dist` (any backend) only carries those 128 bytes to the others."""
+
+    def __init__(self, dist, device: int):
+        import torch
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
+        box = [xsg.comm_unique_id() if rank == 0 else None]
+        if dist is not None and world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self.ctx = xsg.Context(device)
+        self.comm = xsg.Comm.rank(self.ctx, world, rank, box[0])
+        self.buf = torch.zeros(64, dtype=torch.int64, device=f"cuda:{device}")
+        self.world, self.rank = world, rank
+
+    def sum(self, values):
+        import torch
+        k = len(values)
+        self.buf[:k] = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        torch.cuda.synchronize(self.buf.device)
+        return [int(x) for x in self.comm.reduce_counts(self.buf.data_ptr(), k)]
+
+    def gather(self, value: int):
+        return [int(x) for x in self.comm.allgather_u64([int(value)])]
+
+    def close(self):
+        self.comm.close()
+        self.ctx.close()
+
+
 def distributed_search(pattern: bytes, path: str, mode: int, meta_path: str | None = None, *, dist=None,
                        tensor_device="cpu", device: int = 0, num_threads: int = 2, chunk_bytes: int = 16 << 20,
-                       scan_range=None):
+                       scan_range=None, collective=None):
     """Run one xs:: tag over `path` with the chunks sharded across the ranks of `dist`.
 
     Count tags return the global count on every rank.  List tags return this
     rank's part (global byte offsets / global line indices / lines).
+    collective: a LibraryCollective to run the exchange step over the library's RCCL communicator; default:
+    torch.distributed's all_reduce / all_gather on `tensor_device`.
     """
     import torch
     world = dist.get_world_size() if dist is not None else 1
@@ -65,6 +98,10 @@ def distributed_search(pattern: bytes, path: str, mode: int, meta_path: str | No
         result, newlines = (0 if mode in (xsg.COUNT_MATCHES, xsg.COUNT_LINES) else ([] if mode == xsg.LINES else
                                                                                     np.zeros(0, np.uint64))), 0
     if mode in (xsg.COUNT_MATCHES, xsg.COUNT_LINES):
+        if collective is not None:
+            total, chunks = collective.sum([int(result), hi - lo])
+            assert chunks == len(plan)
+            return total
         t = torch.tensor([int(result), hi - lo], dtype=torch.int64, device=tensor_device)
         if dist is not None:
             dist.all_reduce(t)  # sum; 16 bytes: latency-bound, xGMI bandwidth is irrelevant
@@ -72,6 +109,9 @@ def distributed_search(pattern: bytes, path: str, mode: int, meta_path: str | No
         return int(t[0])
     if mode == xsg.LINE_INDICES and not meta_path:
         # line-index base of this rank = newlines in all lower ranks' ranges
+        if collective is not None:
+            allnl = collective.gather(int(newlines))
+            return np.asarray(result, dtype=np.uint64) + np.uint64(sum(allnl[:rank]))
         mine = torch.tensor([int(newlines)], dtype=torch.int64, device=tensor_device)
         if dist is not None:
             allnl = [torch.zeros_like(mine) for _ in range(world)]
