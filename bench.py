@@ -521,9 +521,12 @@ def main():
             tj = json.loads(tfile.read_text())
         except Exception:
             continue
-        # only a record of THIS workload and kernel instantiation counts (same bytes, same pattern, same variant)
+        # only a record of THIS workload and kernel variant counts (same bytes, same pattern, same instantiation up
+        # to the hot filter -- the last template argument -- which does not change what is read)
+        def variant(name):
+            return str(name).split(" stagger")[0].rsplit(",", 1)[0]
         if (tj.get("bytes_per_gpu") == shard_bytes and tj.get("pattern", "Sherlock") == args.pattern
-                and str(tj.get("kernel", "")).split(" stagger")[0] == kernel_name.split(" stagger")[0]):
+                and variant(tj.get("kernel", "")) == variant(kernel_name)):
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = f"profiles/{tfile.name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command " \
                              f"(separate runs; not measured in this run)"

@@ -13,14 +13,19 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def avg_counter(path, counter):
-    vals = []
+    """average over the FULL-SHARD k_scan launches only (largest grid): the library's hot-filter probe also launches
+    k_scan, on a 2 GiB prefix of the shard"""
+    rows = []
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] == counter and "k_scan<" in row["Kernel_Name"]:
-                vals.append(float(row["Counter_Value"]))
-    if not vals:
+                rows.append((int(row["Grid_Size"]), float(row["Counter_Value"]), row["Kernel_Name"]))
+    if not rows:
         raise SystemExit(f"no {counter} rows for k_scan in {path}")
-    return sum(vals) / len(vals), len(vals)
+    full = max(g for g, _, _ in rows)
+    vals = [v for g, v, _ in rows if g == full]
+    names = sorted({n for g, _, n in rows if g == full})
+    return sum(vals) / len(vals), len(vals), names
 
 
 def main():
@@ -28,11 +33,12 @@ def main():
     tag = sys.argv[4] if len(sys.argv) > 4 else ""
     bench = json.loads(Path(bench_json).read_text().splitlines()[-1])
     alg = bench["roofline"]["algorithmic_bytes_per_launch"]
-    fetch_kb, nf = avg_counter(fetch_csv, "FETCH_SIZE")
-    write_kb, nw = avg_counter(write_csv, "WRITE_SIZE")
+    fetch_kb, nf, names = avg_counter(fetch_csv, "FETCH_SIZE")
+    write_kb, nw, _ = avg_counter(write_csv, "WRITE_SIZE")
     rd, wr = 2.0 * fetch_kb * 1024.0, write_kb * 1024.0
     out = {
         "kernel": bench["roofline"]["kernel"],
+        "kernels_profiled": names,
         "pattern": bench["config"]["pattern"],
         "config": bench["config"]["workload"],
         "bytes_per_gpu": bench["config"]["bytes_per_gpu"],
