@@ -219,7 +219,8 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
     host-read-bound, reported beside -- never as -- `value`.  N > 1: every rank searches its contiguous chunk range
     of the SAME file (config 3/5's fan-out); the rate is file bytes / the slowest rank's wall time."""
     import xsg
-    n = max(world, int(args.e2e_gib * 2**30 / (args.chunk_mib << 20)))
+    # the file grows with the number of GPUs (every rank gets --e2e-gib of it, 16 GiB at most in all)
+    n = max(world, int(min(args.e2e_gib * world, 16.0) * 2**30 / (args.chunk_mib << 20)))
     plan = chunk_plan(args, 0xE2E, n)
     d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     path = os.path.join(d, f"xsg_bench_e2e_{os.environ.get('MASTER_PORT', os.getpid())}.txt")
@@ -270,7 +271,7 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         mp, dp = path + ".lz4.meta", path + ".lz4"
         if rank == 0:
             small = path + ".part"
-            nsmall = max(world, n // 4)
+            nsmall = min(max(world, n // 4), 128)
             with open(small, "wb") as f:
                 for c in plan[:nsmall]:
                     f.write(blocks[int(c)].tobytes())
@@ -279,7 +280,7 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
             made += [mp, dp]
         if dist is not None:
             dist.barrier()
-        nsmall = max(world, n // 4)
+        nsmall = min(max(world, n // 4), 128)
         lo, hi = (nsmall * rank) // world, (nsmall * (rank + 1)) // world
         want_l = int(sum(tcount[int(c)] for c in plan[lo:hi]))
         nreaders = int(os.environ.get("XSG_E2E_DECODERS", "12"))
@@ -400,6 +401,20 @@ def main():
 
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
+    # XSG_BENCH_COLL=xsg (opt-in): the per-step all-reduce goes through the LIBRARY's RCCL communicator
+    # (include/xsg.h: xsg_comm_create_rank / xsg_reduce_counts_async) instead of torch.distributed's; torch only
+    # carries the 128-byte id to the ranks.  Every rank first agrees that it has a librccl, so that no rank waits
+    # in ncclCommInitRank for one that cannot come.
+    lib_comm = None
+    if dist is not None and backend == "nccl" and os.environ.get("XSG_BENCH_COLL") == "xsg":
+        have = torch.tensor([1 if xsg.comm_library() else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if int(have.item()) == 1:
+            box = [xsg.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            lib_comm = xsg.Comm.rank(ctx, world, rank, box[0])
+
     def all_reduce_(t, op=None):
         """in-place all-reduce of a device tensor (through host memory only in the gloo rehearsal)"""
         if backend == "nccl":
@@ -446,7 +461,10 @@ def main():
             scan_done[b].record(stream)
             with torch.cuda.stream(coll_stream):
                 coll_stream.wait_event(scan_done[b])
-                all_reduce_(c)  # RCCL sum of the 4 uint64 counters
+                if lib_comm is not None:  # ncclAllReduce(sum, uint64 x 4) on the library's communicator
+                    lib_comm.reduce_counts_async(c.data_ptr(), xsg.NUM_COUNTERS, coll_stream.cuda_stream)
+                else:
+                    all_reduce_(c)  # RCCL sum of the 4 uint64 counters
                 if results is not None:
                     results[i] = c[xsg.CTR_MATCHES]
                 coll_done[b].record(coll_stream)
@@ -568,6 +586,8 @@ def main():
             "strong": strong,
             "rccl_ranks": (world if (dist is not None and backend == "nccl") else 0),
             "collective_backend": (backend if dist is not None else None),
+            "collective_through": (None if dist is None else "libxsg (xsg_reduce_counts_async)" if lib_comm is not None
+                                   else "torch.distributed"),
             "allreduce_us": None if allreduce_us is None else round(allreduce_us, 1),
             "roofline": {
                 "bound": "hbm",
@@ -588,6 +608,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, blocks, pattern)
         print(json.dumps(line), flush=True)
+    if lib_comm is not None:
+        torch.cuda.synchronize()
+        lib_comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

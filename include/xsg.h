@@ -198,6 +198,10 @@ int xsg_search(xsg_shard* shard, uint32_t mode, uint64_t* n_results);
 /* Copy the uint64 results of the last XSG_MATCH_BYTE_OFFSETS /
  * XSG_LINE_BYTE_OFFSETS / XSG_LINE_INDICES search, ascending, to host memory. */
 int xsg_result_u64(xsg_shard* shard, uint64_t* out, uint64_t cap);
+/* The same without the copy into caller memory: *out points at *n values in pinned host memory owned by the shard,
+ * valid until the next search on it (a dense needle returns hundreds of MB: D2H into pageable memory runs at a
+ * sixth of the pinned rate). */
+int xsg_result_u64_view(xsg_shard* shard, const uint64_t** out, uint64_t* n);
 /* After an XSG_LINES search: total number of line bytes (no '\n's). */
 int xsg_result_lines_size(xsg_shard* shard, uint64_t* n_lines, uint64_t* total_bytes);
 /* line i = bytes[ starts[i] .. starts[i] + lengths[i] ), in file order;

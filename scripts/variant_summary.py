@@ -31,25 +31,36 @@ print("# rocprofv3 passes, 20 GiB shard, per variant (kernel-trace --stats; --pm
 for d in sorted(p for p in root.iterdir() if p.is_dir()):
     case = d.name
     line = {"case": case}
-    for f in glob.glob(str(d / "stats" / "*" / "*kernel_stats.csv")):
-        for r in csv.DictReader(open(f)):
-            if "k_scan<" in r["Name"]:
-                line["kernel"] = r["Name"].replace("void ", "").replace("(xsg::ScanArgs)", "")
-                line["calls"] = int(r["Calls"])
-                line["avg_ms"] = round(float(r["AverageNs"]) / 1e6, 4)
-                line["min_ms"] = round(float(r["MinNs"]) / 1e6, 4)
-    for log in (d / "stats.log",):
-        if log.exists():
-            for l in log.read_text().splitlines():
-                if l.startswith("{"):
-                    j = json.loads(l)
-                    line["bytes"] = j["bytes"]
-                    line["hip_event_ms"] = j["ms"]
+    want = None  # the instantiation this case's timed launches ran (the library's hot-filter probe launches others)
+    log = d / "stats.log"
+    if log.exists():
+        for l in log.read_text().splitlines():
+            if l.startswith("{"):
+                j = json.loads(l)
+                line["bytes"] = j["bytes"]
+                line["hip_event_ms"] = j["ms"]
+                want = j["kernel"].split(" stagger")[0]
+                line["kernel"] = j["kernel"]
+    if want is None:
+        continue
+    full = "void " + want + "(xsg::ScanArgs)"
+    for f in glob.glob(str(d / "stats" / "*" / "*kernel_trace.csv")):
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])) for r in csv.DictReader(open(f))
+                if r["Kernel_Name"] == full]
+        if durs:
+            g = max(x[1] for x in durs)
+            ds = [x[0] for x in durs if x[1] == g]  # full-shard launches only
+            line["calls"] = len(ds)
+            line["avg_ms"] = round(sum(ds) / len(ds) / 1e6, 4)
+            line["min_ms"] = round(min(ds) / 1e6, 4)
     acc = defaultdict(list)
     for f in glob.glob(str(d / "sq" / "*" / "*counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
-            if "k_scan<" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == full]
+        if rows:
+            g = max(int(r["Grid_Size"]) for r in rows)
+            for r in rows:
+                if int(r["Grid_Size"]) == g:
+                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     if acc.get("SQ_WAVES"):
         waves = sum(acc["SQ_WAVES"]) / len(acc["SQ_WAVES"])
         for k, v in acc.items():
@@ -59,9 +70,10 @@ for d in sorted(p for p in root.iterdir() if p.is_dir()):
             line["wait_share"] = round(sum(acc["SQ_WAIT_ANY"]) / sum(acc["SQ_WAVE_CYCLES"]), 3)
     fs = []
     for f in glob.glob(str(d / "fetch" / "*" / "*counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
-            if "k_scan<" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
-                fs.append(float(r["Counter_Value"]))
+        rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == full and r["Counter_Name"] == "FETCH_SIZE"]
+        if rows:
+            g = max(int(r["Grid_Size"]) for r in rows)
+            fs += [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == g]
     if fs and "bytes" in line:
         line["hbm_read_bytes_per_launch"] = 2.0 * 1024.0 * sum(fs) / len(fs)
         line["read_traffic_over_algorithmic"] = round(line["hbm_read_bytes_per_launch"] / line["bytes"], 4)

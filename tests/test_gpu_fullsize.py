@@ -58,6 +58,7 @@ def test_config2_match_byte_offsets_10gib(shard10, oracle):
     assert got.size == want.size > 5000
     assert np.array_equal(got, want)
     assert np.all(np.diff(got.astype(np.int64)) > 0)  # sorted, unique
+    assert np.array_equal(s["shard"].search_u64_view(xsg.MATCH_BYTE_OFFSETS), want)  # the pinned view holds the same
     # count through both entry points agrees
     assert int(s["shard"].count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == want.size
 

@@ -394,3 +394,21 @@ def test_half_a_gigabyte_without_a_newline(gs, oracle):
         assert want["count_matches"] == 3 and want["count_lines"] == (2 if with_nl else 1)
         assert dt < 10.0, f"single-line chunk took {dt:.1f} s"
         print(f"512 MiB single line (newline in the middle: {with_nl}): all tags in {dt:.2f} s")
+
+
+def test_one_long_chain_of_overlapping_occurrences(gs, oracle):
+    """A megabyte-long run of one byte searched for `aa` / `aaa` is ONE chain of overlapping occurrences per chunk:
+    the greedy non-overlap walk (simd_search.cpp:333, search_wrappers.h:42) keeps every 2nd / 3rd of a million
+    candidates (k_greedy_keep walks it eight entries a fetch)."""
+    import time
+    run = np.full(1 << 20, ord("a"), dtype=np.uint8)
+    blocks = [np.concatenate([run, np.frombuffer(b"\n", dtype=np.uint8)]),
+              np.concatenate([np.frombuffer(b"xa", dtype=np.uint8), run[:300_001], np.frombuffer(b"b\naa\n", dtype=np.uint8)])]
+    gs.bind(blocks)
+    for pat in (b"aa", b"aaa", b"aaaaaaaaa"):
+        t0 = time.perf_counter()
+        got = gs.all_modes(pat)
+        dt = time.perf_counter() - t0
+        assert_same(got, oracle_all_modes(oracle, blocks, pat), f"run of a, {pat!r}")
+        assert got["count_matches"] >= (1 << 20) // len(pat)
+        assert dt < 5.0, dt

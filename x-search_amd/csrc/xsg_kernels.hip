@@ -398,18 +398,42 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
   if (KIND >= kLong && unit_off < koff)
     m &= koff - unit_off >= kUnit ? 0u : ~((1u << (uint32_t)(koff - unit_off)) - 1u);
   if (KIND == kLong) {
-    // everything outside the window [koff, koff+8): compare from memory against the pattern in LDS (rare: the
-    // 8 bytes of the window already matched).  An in-register check of the next 8 bytes (28 windows live) was
-    // dropped: it raised the kernel to 69-87 VGPRs = 5-7 waves per SIMD instead of 8, for every long pattern.
+    // Everything outside the window [koff, koff+8) against the pattern staged in LDS.  A candidate whose bytes all
+    // lie in the lane's 32-byte view (patterns up to 32 bytes whose match starts in the lane's own unit) is compared
+    // there: the view is parked in LDS once and read back at the match's own byte offset, a dword at a time, next to
+    // the pattern's dwords -- no memory access.  (Byte loads from global memory with an early exit, the first
+    // version, cost a microsecond per candidate: `detective street`, whose window recurs every ~20 KiB in the bench
+    // corpus, spent 65 % of its wave cycles in s_waitcnt.)  Other candidates read memory, 16 bytes between exits.
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    uint8_t* lane_view = lds_view + (threadIdx.x * 48u);
+    if (m && P.plen <= 32u) {
+      *reinterpret_cast<uint4*>(lane_view) = make_uint4(d[0], d[1], d[2], d[3]);
+      *reinterpret_cast<uint4*>(lane_view + 16) = make_uint4(d[4], d[5], d[6], d[7]);
+    }
     uint32_t c = m;
     while (c) {
       const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
       c &= c - 1u;
-      const uint8_t* s = cbase + unit_off + b - koff;  // start of the match
-      bool ok = true;
-      for (uint32_t k = 0; k < koff && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
-      for (uint32_t k = koff + 8; k < P.plen && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
-      if (!ok) m &= ~(1u << b);
+      const int32_t start = (int32_t)b - (int32_t)koff;
+      uint32_t diff = 0;
+      if (start >= 0 && (uint32_t)start + P.plen <= 32u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if ((uint32_t)(4 * i) < P.plen) {
+            const uint32_t have = *reinterpret_cast<const u32_unaligned*>(lane_view + (uint32_t)start + 4u * (uint32_t)i);
+            const uint32_t want = reinterpret_cast<const uint32_t*>(lds_pat)[i];  // zero-padded behind the pattern
+            const uint32_t rest = P.plen - 4u * (uint32_t)i;
+            diff |= (have ^ want) & (rest >= 4u ? 0xffffffffu : (1u << (8u * rest)) - 1u);
+          }
+        }
+      } else {
+        const uint8_t* s = cbase + unit_off + b - koff;  // start of the match
+        for (uint32_t k0 = 0; k0 < P.plen && !diff; k0 += 16u) {
+          const uint32_t k1 = k0 + 16u < P.plen ? k0 + 16u : P.plen;
+          for (uint32_t k = k0; k < k1; ++k) diff |= (uint32_t)(fold(s[k], ICASE) ^ lds_pat[k]);
+        }
+      }
+      if (diff) m &= ~(1u << b);
     }
   }
   if (KIND == kClass) {
@@ -571,9 +595,15 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
                            (uint32_t)__popc(fl[3]);
         if (n) {
           st.cnt += n;
-          const uint32_t hq = fl[3] ? 3u : fl[2] ? 2u : fl[1] ? 1u : 0u;  // highest dword with a match
-          const uint32_t hf = fl[3] ? fl[3] : fl[2] ? fl[2] : fl[1] ? fl[1] : fl[0];
-          st.last_end = unit_off + 4u * hq + ((31u - (uint32_t)__clz(hf)) >> 3) + P.plen;
+          // where the last match ends: only the end-of-chunk walk asks, and a one-byte pattern has none (strchr is
+          // exact everywhere, xsg_tail.h) -- the dozen ops per unit matter for a needle that is in every unit
+          if (P.plen > 1) {
+            const uint32_t hq = fl[3] ? 3u : fl[2] ? 2u : fl[1] ? 1u : 0u;  // highest dword with a match
+            const uint32_t hf = fl[3] ? fl[3] : fl[2] ? fl[2] : fl[1] ? fl[1] : fl[0];
+            st.last_end = unit_off + 4u * hq + ((31u - (uint32_t)__clz(hf)) >> 3) + P.plen;
+          } else {
+            st.last_end = unit_off + 1u;  // unused by the finish kernel, but it must stay inside the tile (tile_last's tag)
+          }
         }
         return 0;
       }
@@ -601,8 +631,8 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         d[4] = from_next_lane(f0, fold4(e0r), lane);
         d[5] = from_next_lane(f1, fold4(e1r), lane);
       }
-      if (KIND == kClass) {
-        // class sequences verify their candidates in registers: the rest of the neighbour's unit joins the view
+      if (KIND >= kLong) {
+        // long patterns and class sequences verify their candidates in the lane's view: the rest of the neighbour's unit joins it
         // (raw own bytes go out -- a lane's own view of them may be cleared at the chunk end, the reader's not)
         const uint32_t e2r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
         const uint32_t e3r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
@@ -648,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
   __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND == kClass ? 2048 : KIND == kLong ? XSG_MAX_PATTERN : 16];
-  __shared__ __attribute__((aligned(16))) uint8_t s_view[KIND == kClass ? kBlock * 48 : 16];  // match_mask16<kClass>
+  __shared__ __attribute__((aligned(16))) uint8_t s_view[KIND >= kLong ? kBlock * 48 : 16];  // match_mask16<kLong/kClass>
 
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (tile >= A.ntiles) return;
@@ -659,8 +689,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps wbase and the branches on it scalar
 
-  if (KIND == kLong) {
-    for (uint32_t k = tid; k < P.plen; k += kBlock) s_pat[k] = P.d_pat[k];
+  if (KIND == kLong) {  // the device copy is zero-padded (XSG_MAX_PATTERN + 16 bytes): whole dwords
+    for (uint32_t k = tid; k < ((P.plen + 3u) & ~3u); k += kBlock) s_pat[k] = P.d_pat[k];
     __syncthreads();
   }
   if (KIND == kClass) {  // 256-bit set per alternative and position (at most 64 sets = 2 KiB)
@@ -1283,12 +1313,34 @@ __global__ void k_greedy_keep(const ListArgs A) {
   const bool head = i == 0 || A.m_chunk[i - 1] != c || A.m_pos[i] - A.m_pos[i - 1] >= plen;
   if (!head) return;
   A.keep[i] = 1u;
-  uint64_t last = A.m_pos[i];
-  for (uint64_t j = i + 1; j < A.M; ++j) {
-    if (A.m_chunk[j] != c || A.m_pos[j] - A.m_pos[j - 1] >= plen) break;
-    const bool k = A.m_pos[j] >= last + plen;
-    A.keep[j] = k ? 1u : 0u;
-    if (k) last = A.m_pos[j];
+  uint64_t last = A.m_pos[i], prev = last;
+  // The walk is a chain of dependent decisions, but not of dependent LOADS: eight entries are fetched at a time
+  // (independent loads, one latency) and decided from registers -- a long chain (a run of one byte searched for
+  // `aa` is one chain per chunk) moves at ~6 ns per occurrence instead of ~50.
+  for (uint64_t j = i + 1; j < A.M;) {
+    uint64_t p[8];
+    uint32_t ch[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint64_t idx = j + (uint64_t)u < A.M ? j + (uint64_t)u : A.M - 1;
+      p[u] = A.m_pos[idx];
+      ch[u] = A.m_chunk[idx];
+    }
+    bool done = false;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (done || j + (uint64_t)u >= A.M) continue;
+      if (ch[u] != c || p[u] - prev >= plen) {  // the chain ends: the next occurrence is a head of its own
+        done = true;
+        continue;
+      }
+      const bool k = p[u] >= last + plen;
+      A.keep[j + (uint64_t)u] = k ? 1u : 0u;
+      if (k) last = p[u];
+      prev = p[u];
+    }
+    if (done) break;
+    j += 8;
   }
 }
 

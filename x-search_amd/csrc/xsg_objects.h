@@ -122,6 +122,8 @@ struct xsg_shard {
   void* h_stage = nullptr;  // pinned
   hipEvent_t table_ev = nullptr;
   bool table_pending = false;  // an upload has been enqueued on the ctx stream since the last sync
+  void* h_result = nullptr;  // pinned: xsg_result_u64_view
+  size_t h_result_cap = 0;
   uint64_t* h_counters = nullptr;  // pinned mirror of the four counters (xsg_count reads it after the stream sync)
   bool begin_sync_result = false;  // xsg_count_begin had to run synchronously: _end hands out begin_counters
   uint64_t begin_counters[XSG_NUM_COUNTERS] = {0, 0, 0, 0};
@@ -140,6 +142,9 @@ struct xsg_shard {
     for (DevBuf* b : all) b->release();
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_counters) (void)hipHostFree(h_counters);
+    if (h_result) (void)hipHostFree(h_result);
+    h_result = nullptr;
+    h_result_cap = 0;
     if (table_ev) (void)hipEventDestroy(table_ev);
     h_stage = nullptr;
     h_counters = nullptr;

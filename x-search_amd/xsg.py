@@ -111,6 +111,7 @@ def load():
         "xsg_count_end": (ci, [vp, _u64p]),
         "xsg_search": (ci, [vp, u32, _u64p]),
         "xsg_result_u64": (ci, [vp, _u64p, u64]),
+        "xsg_result_u64_view": (ci, [vp, C.POINTER(_u64p), _u64p]),
         "xsg_result_lines_size": (ci, [vp, _u64p, _u64p]),
         "xsg_result_lines": (ci, [vp, _u64p, vp, u64, _u64p]),
         "xsg_result_newlines": (ci, [vp, _u64p]),
@@ -167,7 +168,8 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_host_offsets", "xsg_host_lines", "xsg_scan_kernel_name", "xsg_shard_tune", "xsg_count_begin",
            "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
            "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
-           "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info"]
+           "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info",
+           "xsg_result_u64_view"]
 
 
 def _check(rc):
@@ -313,6 +315,16 @@ class Shard:
         out = np.empty(n.value, dtype=np.uint64)
         _check(self._lib.xsg_result_u64(self.h, out.ctypes.data_as(_u64p), n.value))
         return out
+
+    def search_u64_view(self, mode: int) -> np.ndarray:
+        """like search_u64, but the array is a VIEW of the shard's pinned result buffer: valid until the next search"""
+        n = C.c_uint64(0)
+        _check(self._lib.xsg_search(self.h, mode, C.byref(n)))
+        ptr, cnt = _u64p(), C.c_uint64(0)
+        _check(self._lib.xsg_result_u64_view(self.h, C.byref(ptr), C.byref(cnt)))
+        if cnt.value == 0:
+            return np.zeros(0, dtype=np.uint64)
+        return np.ctypeslib.as_array(ptr, shape=(cnt.value,))
 
     def search_lines(self):
         """-> (list of bytes, global byte offset of every line start)"""
