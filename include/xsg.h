@@ -178,8 +178,16 @@ int xsg_shard_set_line_base(xsg_shard* shard, uint64_t line_base);
 /* Asynchronous: enqueues the scan on `stream` (a hipStream_t, NULL = the
  * ctx's own stream) and returns.  d_counters: device memory for
  * XSG_NUM_COUNTERS uint64 values, overwritten by the call.  Serves
- * XSG_COUNT_MATCHES (optionally | XSG_WITH_NEWLINES) for patterns that cannot
- * overlap themselves, and XSG_COUNT_LINES; otherwise XSG_ENOTSUP -> use xsg_count. */
+ * XSG_COUNT_LINES for every pattern, and XSG_COUNT_MATCHES (optionally |
+ * XSG_WITH_NEWLINES) for patterns that cannot overlap themselves.  A pattern
+ * that can -- a literal with a border (`that`, `aa`, `abab`) or a class
+ * sequence two of whose occurrences may overlap (`[a-z]{4}`, `t.e`; the test is
+ * conservative) -- needs the greedy non-overlap walk over the ordered occurrence
+ * list, whose size must come back to the host first: XSG_ENOTSUP here, served
+ * by xsg_count / xsg_count_begin (synchronously, through the list route).
+ * The first pass of a (binding, pattern) on a shard of 64 MiB or more also runs
+ * the library's hot-filter probe (a few short launches and one stream sync,
+ * DESIGN.md 3.1); every later call only enqueues. */
 int xsg_count_async(xsg_shard* shard, uint32_t mode, void* stream, uint64_t* d_counters);
 /* Synchronous, any pattern, XSG_COUNT_MATCHES or XSG_COUNT_LINES
  * (| XSG_WITH_NEWLINES): result in host memory. */

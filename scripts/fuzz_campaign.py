@@ -23,14 +23,14 @@ ap.add_argument("--first-seed", type=int, default=100)
 ap.add_argument("--hot", type=int, default=-1, help="pin the hot filter of the window kinds (0 window filter, 1 aligned trigger); -1 = alternate per seed")
 a = ap.parse_args()
 oracle = xs_oracle.Oracle()
-searchers = {0: GpuSearch(hot=0), 1: GpuSearch(hot=1)}
+searchers = {0: GpuSearch(hot=0), 1: GpuSearch(hot=1), 2: GpuSearch(probe=True)}
 t0 = time.time()
 seed = a.first_seed
 out = ROOT / "gpurun_out" / "fuzz_campaign.json"
 out.parent.mkdir(exist_ok=True)
 status = {"first_seed": a.first_seed, "seeds_done": 0, "failed": None, "hot": a.hot}
 while time.time() - t0 < a.minutes * 60:
-    gs = searchers[a.hot if a.hot >= 0 else seed & 1]
+    gs = searchers[a.hot if a.hot >= 0 else seed % 3]
     try:
         fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000 if seed % 4 else 600000)
         if seed % 3 == 0:

@@ -22,21 +22,28 @@ def upload(blocks, global_offsets=None, line_bases=None):
 class GpuSearch:
     """One context + one shard, re-bound per case."""
 
-    def __init__(self, hot=None):
+    def __init__(self, hot=None, probe=False):
         """hot=0/1 pins the hot filter of the 8-byte-window kinds (XSG_HOT, read when the context is created):
-        the test shards are far below the size at which the library measures and picks one itself."""
+        the test shards are far below the size at which the library measures and picks one itself.
+        probe=True lets it measure on shards of any size (XSG_PROBE_MIN_BYTES=0): on kilobyte shards the timings are
+        noise, so both filters and every candidate window of a long pattern get picked at random -- which is the
+        point: whatever the probe chooses, the results must not change."""
         import os
-        old = os.environ.get("XSG_HOT")
+        env = {}
         if hot is not None:
-            os.environ["XSG_HOT"] = str(hot)
+            env["XSG_HOT"] = str(hot)
+        if probe:
+            env["XSG_PROBE_MIN_BYTES"] = "0"
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
             self.ctx = xsg.Context(0)
         finally:
-            if hot is not None:
-                if old is None:
-                    del os.environ["XSG_HOT"]
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
                 else:
-                    os.environ["XSG_HOT"] = old
+                    os.environ[k] = v
         self.shard = None
         self.keep = None
 

@@ -81,3 +81,10 @@ def test_fuzz_with_the_aligned_dword_trigger(seed, oracle):
     """the other hot filter of the 8-byte-window kinds (k_scan<..., ALIGNED = true>), which the library only picks
     by measurement on shards of 64 MiB and more: pinned here"""
     fuzz_rounds(seed, oracle, GpuSearch(hot=1))
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_with_the_probe_choosing(seed, oracle):
+    """hot filter and, for long patterns, the filter window picked by the library's measurement (on shards this small:
+    at random) -- results must not depend on the choice"""
+    fuzz_rounds(seed, oracle, GpuSearch(probe=True))

@@ -92,6 +92,7 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
   }
   if (const char* tn = getenv("XSG_TUNE")) c->tune = (uint32_t)strtoul(tn, nullptr, 0);
   if (const char* hf = getenv("XSG_HOT")) c->hot_env = (*hf == '0' || *hf == '1') ? *hf - '0' : -1;
+  if (const char* pm = getenv("XSG_PROBE_MIN_BYTES")) c->probe_min_bytes = strtoull(pm, nullptr, 0);
   if (const char* tk = getenv("XSG_TILE_KIB")) {
     const int v = atoi(tk);
     if (v == 16) c->tile_bytes = (uint32_t)v * 1024u;
@@ -160,6 +161,36 @@ static uint32_t pick_filter_window(const uint8_t* p, size_t plen) {
 
 static uint32_t mask32(size_t n) { return n >= 4 ? 0xffffffffu : (n == 0 ? 0u : ((1u << (8 * n)) - 1u)); }
 
+// the window-dependent fields of a literal pattern: the 8 bytes at p[koff..] as compare dwords and masks
+static void window_fields(const uint8_t* p, size_t plen, uint32_t koff, PatternDev* P) {
+  const uint8_t* w = p + koff;
+  const size_t wlen = plen - koff;  // >= 8 when koff > 0
+  P->koff = koff;
+  P->p0 = le32(w, wlen);
+  P->m0 = mask32(wlen);
+  P->p1 = wlen > 4 ? le32(w + 4, wlen - 4) : 0u;
+  P->m1 = wlen > 4 ? mask32(wlen - 4) : 0u;
+  P->q0 = (P->p0 | 0x20202020u) & P->m0;
+  P->q1 = (P->p1 | 0x20202020u) & P->m1;
+}
+
+// Long patterns: the windows worth MEASURING on the data (choose_hot_filter): the static heuristic's pick first, then
+// the next best-looking ones -- every position for patterns up to 20 bytes, the eight best scores beyond.
+static std::vector<uint32_t> window_candidates(const uint8_t* p, size_t plen) {
+  std::vector<uint32_t> out;
+  if (plen <= 8) return out;
+  std::vector<std::pair<int, uint32_t>> scored;
+  for (size_t k = 0; k + 8 <= plen; ++k) {
+    int score = 0;
+    for (int i = 0; i < 8; ++i) score += byte_rarity(p[k + i], i);
+    scored.push_back({-score, (uint32_t)k});
+  }
+  std::stable_sort(scored.begin(), scored.end());
+  const size_t n = plen <= 20 ? scored.size() : std::min<size_t>(scored.size(), 8);
+  for (size_t i = 0; i < n; ++i) out.push_back(scored[i].second);
+  return out;
+}
+
 // XSG_FLAG_REGEX: a fixed-length class sequence (xsg_classseq.h).  RE2 has no lossy tail, so the
 // matching is exact up to the end of the chunk (as with XSG_FLAG_EXACT_TAIL).
 static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t flags) {
@@ -184,6 +215,7 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   c->pattern.assign(re, re + n);
   c->flags = flags;
   ++c->pattern_serial;
+  c->koff_cands.clear();
   c->bordered = xsg::sequence_can_overlap(seq);
   // What the window compare can know about a position: the bits all members of its set agree on (a literal: all
   // eight; [Ss]: seven; [0-9]: the upper four; [a-z]: the upper three).  (x & agree) == (member & agree) holds for
@@ -307,16 +339,8 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
 
   PatternDev& P = c->pat;
   P.plen = (uint32_t)plen;
-  const uint32_t koff = pick_filter_window(p, plen);  // 0 unless plen > 8
-  const uint8_t* w = p + koff;
-  const size_t wlen = plen - koff;  // >= 8 when koff > 0
-  P.koff = koff;
-  P.p0 = le32(w, wlen);
-  P.m0 = mask32(wlen);
-  P.p1 = wlen > 4 ? le32(w + 4, wlen - 4) : 0u;
-  P.m1 = wlen > 4 ? mask32(wlen - 4) : 0u;
-  P.q0 = (P.p0 | 0x20202020u) & P.m0;
-  P.q1 = (P.p1 | 0x20202020u) & P.m1;
+  window_fields(p, plen, pick_filter_window(p, plen), &P);  // koff 0 unless plen > 8
+  c->koff_cands = window_candidates(p, plen);
   P.kind = plen < 4 ? kMask1 : plen == 4 ? kOne : plen < 8 ? kMask2 : plen == 8 ? kTwo : kLong;
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;
@@ -465,6 +489,8 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.epoch = s->epoch;
   a.pat = s->ctx->pat;
   a.pat.hot = s->ctx->hot_env >= 0 ? (uint32_t)s->ctx->hot_env : (s->hot_serial == s->ctx->pattern_serial ? s->hot : 0u);
+  if (a.pat.kind == kLong && s->hot_serial == s->ctx->pattern_serial && s->koff_chosen)
+    window_fields(s->ctx->pattern.data(), s->ctx->pattern.size(), s->koff, &a.pat);  // the window measured best on this shard
   a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
   a.tile_nl = s->d_tile_nl.as<uint32_t>();
   a.tile_sum = s->d_tile_sum.as<uint32_t>();
@@ -533,7 +559,7 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   if (!is_window_kind(c->pat.kind) || c->hot_env >= 0 || s->hot_serial == c->pattern_serial) return XSG_OK;
   s->hot = 0;
   s->hot_serial = c->pattern_serial;
-  if (s->total_bytes < (64ull << 20)) return XSG_OK;
+  if (s->total_bytes < c->probe_min_bytes || s->ntiles == 0) return XSG_OK;
   XSG_TRY(ensure_tile_nl(s));
   XSG_TRY(prepare_tiles(s, false, st));
   s->cnt_clean = false;  // no finish kernel behind these launches
@@ -541,6 +567,40 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   for (hipEvent_t& e : ev) HIP_TRY(hipEventCreate(&e));
   float ms[2] = {1e30f, 1e30f};
   int rc = XSG_OK;
+  // Long patterns first settle WHICH 8 bytes the hot loop looks for: how often a window occurs in this text decides
+  // how often the slow path runs (`detective street` on the bench corpus: "ective s" every 4 KiB, "ve stree" every
+  // 11 KiB), and no static letter table knows the text.  Each candidate: the window filter on a 1 GiB prefix.
+  s->koff_chosen = false;
+  if (c->pat.kind == kLong && c->koff_cands.size() > 1) {
+    float best = 1e30f;
+    uint32_t best_koff = c->koff_cands[0];
+    for (uint32_t koff : c->koff_cands) {
+      ScanArgs a = scan_args(s);
+      window_fields(c->pattern.data(), c->pattern.size(), koff, &a.pat);
+      a.pat.hot = 0;
+      a.tune = 0;
+      a.ntiles = std::min<uint64_t>(a.ntiles, 65536);
+      hipError_t e = launch_scan_count(a, true, false, st);
+      if (e == hipSuccess) e = hipEventRecord(ev[0], st);
+      for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_scan_count(a, true, false, st);
+      if (e == hipSuccess) e = hipEventRecord(ev[1], st);
+      if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
+      float t = 0;
+      if (e == hipSuccess) e = hipEventElapsedTime(&t, ev[0], ev[1]);
+      if (e != hipSuccess) {
+        rc = fail(XSG_EHIP, "window probe failed: %s", hipGetErrorString(e));
+        break;
+      }
+      if (t < 0.97f * best) {  // the first candidate is the heuristic's pick; a later one must beat the best clearly
+        best = t;
+        best_koff = koff;
+      }
+    }
+    if (rc == XSG_OK) {
+      s->koff = best_koff;
+      s->koff_chosen = true;
+    }
+  }
   // A B A B, the better of the two rounds each: the first launches after a quiet spell run on ramping clocks
   for (int round = 0; round < 2 && rc == XSG_OK; ++round) {
     for (uint32_t hot = 0; hot < 2 && rc == XSG_OK; ++hot) {

@@ -398,42 +398,21 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
   if (KIND >= kLong && unit_off < koff)
     m &= koff - unit_off >= kUnit ? 0u : ~((1u << (uint32_t)(koff - unit_off)) - 1u);
   if (KIND == kLong) {
-    // Everything outside the window [koff, koff+8) against the pattern staged in LDS.  A candidate whose bytes all
-    // lie in the lane's 32-byte view (patterns up to 32 bytes whose match starts in the lane's own unit) is compared
-    // there: the view is parked in LDS once and read back at the match's own byte offset, a dword at a time, next to
-    // the pattern's dwords -- no memory access.  (Byte loads from global memory with an early exit, the first
-    // version, cost a microsecond per candidate: `detective street`, whose window recurs every ~20 KiB in the bench
-    // corpus, spent 65 % of its wave cycles in s_waitcnt.)  Other candidates read memory, 16 bytes between exits.
-    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-    uint8_t* lane_view = lds_view + (threadIdx.x * 48u);
-    if (m && P.plen <= 32u) {
-      *reinterpret_cast<uint4*>(lane_view) = make_uint4(d[0], d[1], d[2], d[3]);
-      *reinterpret_cast<uint4*>(lane_view + 16) = make_uint4(d[4], d[5], d[6], d[7]);
-    }
+    // everything outside the window [koff, koff+8): compare from memory against the pattern in LDS (rare: the
+    // 8 bytes of the window already matched).  Tried and dropped: an in-register check of the next 8 bytes (28
+    // windows live: 69-87 VGPRs), and, in round 2, comparing from the lane's 32-byte view parked in LDS as the
+    // class sequences do -- 60 VGPRs / 100 SGPRs instead of 47 / 74 cost the memory-bound long patterns an eighth
+    // of their rate (`Sherlock Holmes` 7.0 -> 6.1 TB/s) and bought `detective street` nothing: its cost is how
+    // often its window occurs (xsg_api.cpp picks the window by measurement now), not how a candidate is verified.
     uint32_t c = m;
     while (c) {
       const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
       c &= c - 1u;
-      const int32_t start = (int32_t)b - (int32_t)koff;
-      uint32_t diff = 0;
-      if (start >= 0 && (uint32_t)start + P.plen <= 32u) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if ((uint32_t)(4 * i) < P.plen) {
-            const uint32_t have = *reinterpret_cast<const u32_unaligned*>(lane_view + (uint32_t)start + 4u * (uint32_t)i);
-            const uint32_t want = reinterpret_cast<const uint32_t*>(lds_pat)[i];  // zero-padded behind the pattern
-            const uint32_t rest = P.plen - 4u * (uint32_t)i;
-            diff |= (have ^ want) & (rest >= 4u ? 0xffffffffu : (1u << (8u * rest)) - 1u);
-          }
-        }
-      } else {
-        const uint8_t* s = cbase + unit_off + b - koff;  // start of the match
-        for (uint32_t k0 = 0; k0 < P.plen && !diff; k0 += 16u) {
-          const uint32_t k1 = k0 + 16u < P.plen ? k0 + 16u : P.plen;
-          for (uint32_t k = k0; k < k1; ++k) diff |= (uint32_t)(fold(s[k], ICASE) ^ lds_pat[k]);
-        }
-      }
-      if (diff) m &= ~(1u << b);
+      const uint8_t* s = cbase + unit_off + b - koff;  // start of the match
+      bool ok = true;
+      for (uint32_t k = 0; k < koff && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
+      for (uint32_t k = koff + 8; k < P.plen && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
+      if (!ok) m &= ~(1u << b);
     }
   }
   if (KIND == kClass) {
@@ -631,8 +610,8 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         d[4] = from_next_lane(f0, fold4(e0r), lane);
         d[5] = from_next_lane(f1, fold4(e1r), lane);
       }
-      if (KIND >= kLong) {
-        // long patterns and class sequences verify their candidates in the lane's view: the rest of the neighbour's unit joins it
+      if (KIND == kClass) {
+        // class sequences verify their candidates in the lane's view: the rest of the neighbour's unit joins it
         // (raw own bytes go out -- a lane's own view of them may be cleared at the chunk end, the reader's not)
         const uint32_t e2r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
         const uint32_t e3r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.w) : nx.w;
@@ -678,7 +657,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
   __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND == kClass ? 2048 : KIND == kLong ? XSG_MAX_PATTERN : 16];
-  __shared__ __attribute__((aligned(16))) uint8_t s_view[KIND >= kLong ? kBlock * 48 : 16];  // match_mask16<kLong/kClass>
+  __shared__ __attribute__((aligned(16))) uint8_t s_view[KIND == kClass ? kBlock * 48 : 16];  // match_mask16<kClass>
 
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (tile >= A.ntiles) return;
@@ -689,8 +668,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps wbase and the branches on it scalar
 
-  if (KIND == kLong) {  // the device copy is zero-padded (XSG_MAX_PATTERN + 16 bytes): whole dwords
-    for (uint32_t k = tid; k < ((P.plen + 3u) & ~3u); k += kBlock) s_pat[k] = P.d_pat[k];
+  if (KIND == kLong) {
+    for (uint32_t k = tid; k < P.plen; k += kBlock) s_pat[k] = P.d_pat[k];
     __syncthreads();
   }
   if (KIND == kClass) {  // 256-bit set per alternative and position (at most 64 sets = 2 KiB)

@@ -77,8 +77,10 @@ struct xsg_ctx {
   DevBuf d_pat;
   uint32_t tile_bytes = xsg::kDefaultTileBytes;  // geometry new shards get (XSG_TILE_KIB)
   uint32_t tune = xsg::kTuneAuto;                  // wave stagger: per kernel variant (XSG_TUNE overrides)
+  uint64_t probe_min_bytes = 64ull << 20;          // shards below this keep the defaults (XSG_PROBE_MIN_BYTES; tests set 0)
   int hot_env = -1;                                // XSG_HOT=0|1 pins the hot filter of the window kinds; -1: measured per shard
   uint64_t pattern_serial = 0;                     // bumped by every xsg_set_pattern
+  std::vector<uint32_t> koff_cands;                // long literal patterns: filter windows worth measuring (first: the heuristic's)
   char arch[128] = "";
   int cus = 0;
   uint64_t hbm = 0;
@@ -98,6 +100,8 @@ struct xsg_shard {
   uint32_t tune = xsg::kTuneAuto;  // wave stagger chosen by xsg_shard_tune (kTuneAuto: per variant / ctx override)
   // hot filter of the window kinds for (this binding, the ctx's current pattern): measured once, see choose_hot_filter
   uint32_t hot = 0;
+  uint32_t koff = 0;  // long patterns: the filter window measured best here
+  bool koff_chosen = false;
   uint64_t hot_serial = 0;  // the ctx->pattern_serial `hot` was measured for (0: never)
 
   DevBuf d_chunks, d_tile_chunk, d_chunk_tile0;
