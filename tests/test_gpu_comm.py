@@ -125,3 +125,11 @@ def test_distributed_search_over_the_library_collective(tmp_path, blocks, oracle
         assert idx.tolist() == oracle.line_indices(data, b"Sherlock").tolist()
     finally:
         coll.close()
+
+
+def test_device_numa_placement_is_reported():
+    """the feeder threads of a job are bound to these CPUs (xsg_file.cpp: bind_thread_to_device)"""
+    node, cpus = xsg.device_numa(0)
+    assert isinstance(node, int) and node >= -1
+    if cpus:  # e.g. "0-63,128-191"
+        assert all(part.replace("-", "").isdigit() for part in cpus.split(","))

@@ -403,8 +403,9 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   if (grew) s->cnt_clean = false;
   XSG_TRY(s->d_counters.ensure(8 * XSG_NUM_COUNTERS));
   grew = false;
-  XSG_TRY(s->d_finish.ensure(8 * 3 * (size_t)kFinishBlocks + 64, &grew));
-  if (grew) HIP_TRY(hipMemsetAsync(s->d_finish.p, 0, 8 * 3 * (size_t)kFinishBlocks + 64, c->stream));  // ticket = 0
+  // k_count_finish scratch: the partial sums, then u32 words: [0] main ticket, [1] scan flags, [2..18) group tickets
+  XSG_TRY(s->d_finish.ensure(8 * 3 * (size_t)kFinishBlocks + 128, &grew));
+  if (grew) HIP_TRY(hipMemsetAsync(s->d_finish.p, 0, 8 * 3 * (size_t)kFinishBlocks + 128, c->stream));  // tickets = 0
   if (!s->h_counters) HIP_TRY(hipHostMalloc((void**)&s->h_counters, 8 * XSG_NUM_COUNTERS, hipHostMallocDefault));
   if (!s->table_ev) HIP_TRY(hipEventCreateWithFlags(&s->table_ev, hipEventDisableTiming));
   static_assert(sizeof(ChunkDev) == sizeof(xsg_chunk), "layout");
@@ -558,6 +559,7 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   xsg_ctx* c = s->ctx;
   if (!is_window_kind(c->pat.kind) || c->hot_env >= 0 || s->hot_serial == c->pattern_serial) return XSG_OK;
   s->hot = 0;
+  s->koff_chosen = false;
   s->hot_serial = c->pattern_serial;
   if (s->total_bytes < c->probe_min_bytes || s->ntiles == 0) return XSG_OK;
   XSG_TRY(ensure_tile_nl(s));
@@ -828,6 +830,10 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   float best_ms = 0;
   uint32_t best = kTuneAuto, best_hot = 0;
   const uint32_t nhot = (is_window_kind(c->pat.kind) && c->hot_env < 0) ? 2u : 1u;
+  // the probe first (it also settles a long pattern's filter window, which the loop below keeps), then both hot
+  // filters against every stagger at full size
+  s->hot_serial = 0;
+  XSG_TRY(choose_hot_filter(s, c->stream));
   for (uint32_t hot = 0; hot < nhot; ++hot) {
     s->hot = hot;
     s->hot_serial = c->pattern_serial;
@@ -838,6 +844,7 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
       if (r != XSG_OK) {
         s->tune = kTuneAuto;
         s->hot_serial = 0;
+        s->koff_chosen = false;
         return r;
       }
       if (best == kTuneAuto || ms < best_ms) best_ms = ms, best = t, best_hot = hot;

@@ -50,14 +50,6 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int s = 32; s >= 1; s >>= 1) v += (uint32_t)__shfl_xor((int)v, s);
   return v;
 }
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    uint64_t o = (uint64_t)__shfl_xor((long long)v, s);
-    v = o > v ? o : v;
-  }
-  return v;
-}
 // inclusive prefix sum over lanes
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -480,7 +472,7 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
 struct WaveState {
   uint32_t cnt = 0;       // matches found by this lane
   uint32_t nlc = 0;       // newlines counted by this lane (WANT_NL)
-  uint64_t last_end = 0;  // end of this lane's last match, chunk-local
+  uint32_t last_rel = 0;  // end of this lane's last match, relative to the TILE start (> 0 once there is one; < 2^16)
   uint32_t wsum = 0;      // line summary of the wave span so far (lane 0); 0 is the identity
   bool run_nl = false;    // the current run of match-less loads holds a newline (wave-uniform)
   uint32_t masks[4] = {0, 0, 0, 0};
@@ -493,7 +485,8 @@ struct WaveState {
 // Returns the lane's exact match-start bits (also accumulated into `st`).
 template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool CAREFUL, bool ALIGNED>
 __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, bool nx_is_vgpr, uint64_t unit_off,
-                                              uint32_t lane, uint64_t L, uint64_t limit, const PatternDev& P,
+                                              uint32_t unit_rel, uint32_t lane, uint64_t L, uint64_t limit,
+                                              const PatternDev& P,
                                               const uint8_t* cbase, const uint8_t* s_pat, uint8_t* s_view,
                                               WaveState& st) {
   // ignore_case, patterns of 4+ bytes (LAZY): the hot filter does not need the exact fold.  (x | 0x20) == (p | 0x20)
@@ -579,9 +572,9 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
           if (P.plen > 1) {
             const uint32_t hq = fl[3] ? 3u : fl[2] ? 2u : fl[1] ? 1u : 0u;  // highest dword with a match
             const uint32_t hf = fl[3] ? fl[3] : fl[2] ? fl[2] : fl[1] ? fl[1] : fl[0];
-            st.last_end = unit_off + 4u * hq + ((31u - (uint32_t)__clz(hf)) >> 3) + P.plen;
+            st.last_rel = unit_rel + 4u * hq + ((31u - (uint32_t)__clz(hf)) >> 3) + P.plen;
           } else {
-            st.last_end = unit_off + 1u;  // unused by the finish kernel, but it must stay inside the tile (tile_last's tag)
+            st.last_rel = unit_rel + 1u;  // unused by the finish kernel, but it must stay inside the tile (tile_last's tag)
           }
         }
         return 0;
@@ -626,7 +619,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
   } else {
     if (m) {
       st.cnt += (uint32_t)__popc(m);
-      st.last_end = unit_off + (31u - (uint32_t)__clz(m)) + P.plen - (KIND >= kLong ? P.koff : 0u);
+      st.last_rel = unit_rel + (31u - (uint32_t)__clz(m)) + P.plen - (KIND >= kLong ? P.koff : 0u);  // > 0: plen > koff
     }
     if (WANT_LINES) {
       // A wave-load without any match start (the common case) summarises to "has a
@@ -740,20 +733,19 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
     for (int j = 0; j < kLoads; ++j) {
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
       st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, false, ALIGNED>(
-          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit, lane, L, limit, P, cbase,
-          s_pat, s_view, st);
+          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit,
+          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st);
     }
   } else {
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
       st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, true, ALIGNED>(
-          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit, lane, L, limit, P, cbase,
-          s_pat, s_view, st);
+          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit,
+          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st);
     }
   }
   const uint32_t cnt = st.cnt, nlc = st.nlc;
-  const uint64_t last_end = st.last_end;
   uint32_t wsum = st.wsum;
   const bool run_nl = st.run_nl;
   uint32_t masks[kLoads];
@@ -773,14 +765,22 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
     // found something else write: no LDS, no barrier, no store on the common path.
     if (__any(cnt != 0)) {
       const uint32_t wc = wave_sum_u32(cnt);
-      const uint64_t wl = wave_max_u64(last_end);
+      // the end of the wave's last match, relative to the tile start: it fits 16 bits, so the reduction runs on
+      // 32-bit values (a 64-bit max costs three times the lane exchanges; a needle that is dense in the text pays
+      // this epilogue in every wave)
+      uint32_t rel = st.last_rel;
+#pragma unroll
+      for (int sft = 32; sft >= 1; sft >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)rel, sft);
+        rel = o > rel ? o : rel;
+      }
       if (lane == 0) {
         // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
         // cut dense patterns to a third)
         atomicAdd(A.tile_cnt + tile, wc);
         // end of the last match relative to the tile start (1 .. tile + plen < 2^16), tagged with this pass's
         // epoch: a word of an older pass loses the max, so the array is never reset
-        atomicMax(A.tile_last + tile, (A.epoch << 16) | (uint32_t)(wl - toff));
+        atomicMax(A.tile_last + tile, (A.epoch << 16) | rel);
       }
     }
     if (WANT_LINES) {
@@ -1112,7 +1112,19 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   if (threadIdx.x == 0) {
     A.partials[3u * blockIdx.x + 2u] = t;
     __threadfence();  // partials before the ticket
-    s_is_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1u;
+    // Two levels: up to 2048 workgroups bumping ONE word serialise at the memory side (a 50 GiB shard's finish spent
+    // most of its 48 us there); 16 group tickets (A.ticket[2..18), one per residue of the block index) take the
+    // crowd, the last arrival of each group bumps the main one.  Every word is back at zero when the kernel ends.
+    const uint32_t ngroups = gridDim.x < 16u ? gridDim.x : 16u;
+    const uint32_t g = blockIdx.x & 15u;
+    const uint32_t in_group = (gridDim.x + 15u - g) / 16u;
+    bool last = false;
+    if (atomicAdd(A.ticket + 2u + g, 1u) == in_group - 1u) {
+      A.ticket[2u + g] = 0u;
+      __threadfence();
+      last = atomicAdd(A.ticket, 1u) == ngroups - 1u;
+    }
+    s_is_last = last;
   }
   __syncthreads();
   if (!s_is_last) return;
