@@ -403,7 +403,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   if (grew) s->cnt_clean = false;
   XSG_TRY(s->d_counters.ensure(8 * XSG_NUM_COUNTERS));
   grew = false;
-  // k_count_finish scratch: the partial sums, then u32 words: [0] main ticket, [1] scan flags, [2..18) group tickets
+  // k_count_finish scratch: the partial sums, then u32 words: [0] ticket, [1] scan flags
   XSG_TRY(s->d_finish.ensure(8 * 3 * (size_t)kFinishBlocks + 128, &grew));
   if (grew) HIP_TRY(hipMemsetAsync(s->d_finish.p, 0, 8 * 3 * (size_t)kFinishBlocks + 128, c->stream));  // tickets = 0
   if (!s->h_counters) HIP_TRY(hipHostMalloc((void**)&s->h_counters, 8 * XSG_NUM_COUNTERS, hipHostMallocDefault));

@@ -103,7 +103,7 @@ struct FinishArgs {
   uint64_t* counters;       // device, XSG_NUM_COUNTERS: overwritten (no zeroing needed)
   uint64_t* host_counters;  // optional: pinned host mirror of the same four values
   uint64_t* partials;       // scratch: 3 x kFinishBlocks
-  uint32_t* ticket;         // [0] main ticket, [2..18) group tickets, all zero at rest: the last workgroup to arrive does the final sum
+  uint32_t* ticket;         // zero at rest: the last workgroup to arrive does the final sum and resets it
   uint32_t* flags;          // ScanArgs::flags: read and cleared by that workgroup; bit 0 poisons the counters (UINT64_MAX)
   uint64_t total_bytes;     // sum of the chunk lengths (host-side knowledge)
   uint32_t want_nl;

@@ -1112,19 +1112,9 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   if (threadIdx.x == 0) {
     A.partials[3u * blockIdx.x + 2u] = t;
     __threadfence();  // partials before the ticket
-    // Two levels: up to 2048 workgroups bumping ONE word serialise at the memory side (a 50 GiB shard's finish spent
-    // most of its 48 us there); 16 group tickets (A.ticket[2..18), one per residue of the block index) take the
-    // crowd, the last arrival of each group bumps the main one.  Every word is back at zero when the kernel ends.
-    const uint32_t ngroups = gridDim.x < 16u ? gridDim.x : 16u;
-    const uint32_t g = blockIdx.x & 15u;
-    const uint32_t in_group = (gridDim.x + 15u - g) / 16u;
-    bool last = false;
-    if (atomicAdd(A.ticket + 2u + g, 1u) == in_group - 1u) {
-      A.ticket[2u + g] = 0u;
-      __threadfence();
-      last = atomicAdd(A.ticket, 1u) == ngroups - 1u;
-    }
-    s_is_last = last;
+    // (one ticket word for up to 2048 workgroups is not what the kernel's time goes to: a two-level ticket, 16 group
+    // words in front of it, left the 50 GiB shard's finish at its 48 us under rocprofv3 -- measured, removed)
+    s_is_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1u;
   }
   __syncthreads();
   if (!s_is_last) return;
