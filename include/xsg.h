@@ -178,13 +178,16 @@ int xsg_shard_set_line_base(xsg_shard* shard, uint64_t line_base);
 /* Asynchronous: enqueues the scan on `stream` (a hipStream_t, NULL = the
  * ctx's own stream) and returns.  d_counters: device memory for
  * XSG_NUM_COUNTERS uint64 values, overwritten by the call.  Serves
- * XSG_COUNT_LINES for every pattern, and XSG_COUNT_MATCHES (optionally |
- * XSG_WITH_NEWLINES) for patterns that cannot overlap themselves.  A pattern
- * that can -- a literal with a border (`that`, `aa`, `abab`) or a class
- * sequence two of whose occurrences may overlap (`[a-z]{4}`, `t.e`; the test is
- * conservative) -- needs the greedy non-overlap walk over the ordered occurrence
- * list, whose size must come back to the host first: XSG_ENOTSUP here, served
- * by xsg_count / xsg_count_begin (synchronously, through the list route).
+ * XSG_COUNT_LINES and XSG_COUNT_MATCHES, each optionally | XSG_WITH_NEWLINES,
+ * with one exception.  A pattern that can overlap itself -- a literal with a
+ * border (`that`, `aa`, `abab`) or a class sequence two of whose occurrences may
+ * overlap (`[a-z]{4}`, `t.e`; the test is conservative) -- needs the greedy
+ * non-overlap walk over the ordered occurrence list.  Its XSG_COUNT_MATCHES
+ * runs that list route entirely on the device, into arrays whose capacity is
+ * twice the number of raw occurrences the last list pass on this shard saw (at
+ * least 2^20): if there are more, all four counters read UINT64_MAX and
+ * xsg_count (synchronous, sizes exactly, remembers the size) is the call to
+ * make; | XSG_WITH_NEWLINES is not served for such a pattern (XSG_ENOTSUP).
  * The first pass of a (binding, pattern) on a shard of 64 MiB or more also runs
  * the library's hot-filter probe (a few short launches and one stream sync,
  * DESIGN.md 3.1); every later call only enqueues. */

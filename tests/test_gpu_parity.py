@@ -222,11 +222,50 @@ def test_async_count_on_a_caller_stream(gs, oracle):
     assert int(got[xsg.CTR_MATCHES]) == want["count_matches"]
     assert int(got[xsg.CTR_NEWLINES]) == want["newlines"]
     assert int(got[xsg.CTR_BYTES]) == want["bytes"]
-    # bordered pattern: the async entry point refuses, the sync one answers
+    # a pattern that can overlap itself: the match count needs the greedy walk -- served on the device too
+    # (bounded list route); only the newline count next to it is the synchronous call's
     gs.ctx.set_pattern(b"abab")
     with pytest.raises(xsg.XsgError) as e:
-        gs.shard.count_async(xsg.COUNT_MATCHES, 0, ctr.data_ptr())
+        gs.shard.count_async(xsg.COUNT_MATCHES | xsg.WITH_NEWLINES, 0, ctr.data_ptr())
     assert e.value.code == xsg.ENOTSUP
+
+
+def test_async_count_of_patterns_that_overlap_themselves(gs, oracle):
+    """xsg_count_async(XSG_COUNT_MATCHES) for `aa`, `abab`, `that`, `[ab]{3}`: the greedy non-overlap count
+    (simd_search.cpp:333) without a trip to the host == the oracle == the synchronous route; more raw occurrences
+    than the arrays hold -> every counter UINT64_MAX, and the synchronous call teaches the shard the size."""
+    import torch
+    rng = np.random.default_rng(77)
+    ab = np.frombuffer(b"ab\n", dtype=np.uint8)
+    blocks = [ab[rng.integers(0, 3, size=n)].copy() for n in (70_000, 16384, 16385, 33, 0, 200_001)]
+    blocks.append(np.frombuffer(b"that thathat thathathat\nthat\n" * 3000, dtype=np.uint8).copy())
+    gs.bind(blocks)
+    ctr = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    st = torch.cuda.Stream()
+    for pat, flags in ((b"aa", 0), (b"abab", 0), (b"aba", xsg.FLAG_EXACT_TAIL), (b"that", 0), (b"THAT", xsg.FLAG_IGNORE_CASE),
+                       (b"[ab]{3}", xsg.FLAG_REGEX), (b"a", 0)):
+        gs.ctx.set_pattern(pat, flags)
+        for _ in range(2):  # twice: the pass must leave the shard as it found it
+            gs.shard.count_async(xsg.COUNT_MATCHES, st.cuda_stream, ctr.data_ptr())
+            st.synchronize()
+            got = ctr.cpu().numpy().astype(np.uint64)
+            want = gs.shard.count(xsg.COUNT_MATCHES)
+            assert int(got[xsg.CTR_MATCHES]) == int(want[xsg.CTR_MATCHES]), pat
+            assert int(got[xsg.CTR_BYTES]) == sum(b.size for b in blocks)
+        if not flags:
+            assert int(got[xsg.CTR_MATCHES]) == sum(oracle.count(b, pat, False) for b in blocks), pat
+    # 2.5 M raw occurrences of `aa` against a capacity of 2^20: refused; after xsg_count the arrays are large enough
+    run = np.full(2_500_000, ord("a"), dtype=np.uint8)
+    gs.bind([run])
+    gs.ctx.set_pattern(b"aa")
+    gs.shard.count_async(xsg.COUNT_MATCHES, st.cuda_stream, ctr.data_ptr())
+    st.synchronize()
+    assert all(int(x) == -1 for x in ctr.cpu())
+    want = int(gs.shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
+    assert want == oracle.count(run, b"aa", False)
+    gs.shard.count_async(xsg.COUNT_MATCHES, st.cuda_stream, ctr.data_ptr())
+    st.synchronize()
+    assert int(ctr[xsg.CTR_MATCHES]) == want
 
 
 @pytest.mark.parametrize("exact", [False, True])

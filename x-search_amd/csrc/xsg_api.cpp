@@ -669,6 +669,65 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   return XSG_OK;
 }
 
+// XSG_COUNT_MATCHES for a pattern that can overlap itself, without a trip to the host: the list route of xsg_count
+// (count pass, ranks, ordered emission, greedy keep, end-of-chunk walk) with the one number it used to fetch --
+// how many raw occurrences there are -- left on the device: the arrays get a CAPACITY (twice what the last such
+// pass on this shard found, at least a million), emission is bounded by it, the list kernels read the count
+// from tile_off[ntiles], and a final kernel adds up keep[] and the tail counts.  More occurrences than capacity
+// -> all four counters UINT64_MAX (like the ascii_only refusal): the caller takes xsg_count, which also teaches
+// the shard the size for next time.
+static int enqueue_count_bordered(xsg_shard* s, hipStream_t st, uint64_t* d_counters) {
+  xsg_ctx* c = s->ctx;
+  const uint64_t nchunks = s->chunks.size();
+  const uint64_t ntiles = s->ntiles;
+  XSG_TRY(choose_hot_filter(s, st));
+  XSG_TRY(prepare_tiles(s, false, st));
+  ScanArgs a = scan_args(s);
+  s->cnt_clean = false;  // the tile counts stay for the emit pass
+  HIP_TRY(launch_scan_count(a, false, false, st));
+  XSG_TRY(s->d_tile_off.ensure(8 * (ntiles + 1)));
+  const uint64_t cap = std::max<uint64_t>(1u << 20, 2 * s->last_raw_matches);
+  XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(std::max<uint64_t>(ntiles, nchunks) + 1)));
+  HIP_TRY(launch_exclusive_scan_u32(a.tile_cnt, s->d_tile_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(), st));
+  XSG_TRY(s->d_m_pos.ensure(8 * cap));
+  XSG_TRY(s->d_m_chunk.ensure(4 * cap));
+  XSG_TRY(s->d_keep.ensure(4 * cap));
+  const uint32_t tail_cap = std::max<uint32_t>(tail_max_matches(c->pat.plen), 1u);
+  XSG_TRY(s->d_chunk_shift0.ensure(8 * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_tail_cnt.ensure(4 * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_tail_pos.ensure(8 * std::max<uint64_t>(nchunks, 1) * tail_cap));
+  a.tile_off = s->d_tile_off.as<uint64_t>();
+  a.m_pos = s->d_m_pos.as<uint64_t>();
+  a.m_chunk = s->d_m_chunk.as<uint32_t>();
+  a.m_cap = cap;
+  HIP_TRY(launch_scan_emit(a, st));
+  ListArgs l{};
+  l.base = s->base;
+  l.chunks = a.chunks;
+  l.chunk_tile0 = a.chunk_tile0;
+  l.nchunks = nchunks;
+  l.pat = a.pat;
+  l.M = cap;
+  l.M_dev = a.tile_off + ntiles;
+  l.m_pos = a.m_pos;
+  l.m_chunk = a.m_chunk;
+  l.tile_off = a.tile_off;
+  l.keep = s->d_keep.as<uint32_t>();
+  l.chunk_shift0 = s->d_chunk_shift0.as<uint64_t>();
+  l.tail_cnt = s->d_tail_cnt.as<uint32_t>();
+  l.tail_pos = s->d_tail_pos.as<uint64_t>();
+  l.tail_cap = tail_cap;
+  l.line_mode = 0;
+  HIP_TRY(hipMemsetAsync(l.keep, 0, 4 * cap, st));  // entries that are not chain heads or members are written; be safe
+  HIP_TRY(launch_greedy_keep(l, st));
+  HIP_TRY(launch_chunk_shift0(l, st));
+  HIP_TRY(launch_tail_list(l, st));
+  HIP_TRY(hipMemsetAsync(d_counters, 0, 8 * XSG_NUM_COUNTERS, st));
+  HIP_TRY(launch_bordered_total(l, d_counters, s->total_bytes, a.flags, st));
+  s->last_mode = -1;
+  return XSG_OK;
+}
+
 static const char* const kNonAsciiMsg =
     "the expression uses '.', a negated class or \\D \\W \\S, which match whole code points in RE2; the data holds "
     "bytes >= 0x80, where one byte per position is not the same thing: refused, not approximated";
@@ -688,8 +747,11 @@ extern "C" int xsg_count_async(xsg_shard* s, uint32_t mode, void* stream, uint64
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
   if (m == XSG_COUNT_MATCHES) {
-    if (c->bordered)
-      return fail(XSG_ENOTSUP, "pattern can overlap itself: the greedy non-overlap count needs xsg_count()");
+    if (c->bordered) {
+      if (want_nl)
+        return fail(XSG_ENOTSUP, "pattern can overlap itself: XSG_WITH_NEWLINES next to its match count needs xsg_count()");
+      return enqueue_count_bordered(s, st, d_counters);
+    }
     return enqueue_count(s, true, false, want_nl, st, d_counters, nullptr);
   }
   if (m == XSG_COUNT_LINES) {
@@ -903,6 +965,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     return fail(XSG_ENOTSUP, "%s", kNonAsciiMsg);
   }
 
+  s->last_raw_matches = M;  // sizes the arrays of the next device-only pass (enqueue_count_bordered)
   // 3. ordered emission of every bulk occurrence
   XSG_TRY(s->d_m_pos.ensure(8 * std::max<uint64_t>(M, 1)));
   XSG_TRY(s->d_m_chunk.ensure(4 * std::max<uint64_t>(M, 1)));

@@ -20,7 +20,7 @@ constexpr uint32_t kWaveLoad = 64 * kUnit;
 // kLoads (units per lane) is a template parameter of k_scan: the tile is
 // kLoads KiB per wave x 4 waves = 16 KiB (kLoads 4) or 32 KiB (kLoads 8).
 constexpr uint32_t kDefaultTileBytes = 16384;
-constexpr uint32_t kDefaultStagger = 12;  // see k_scan / launch_scan
+constexpr uint32_t kDefaultStagger = 16;  // see k_scan / pick_stagger (round 2: xsg_shard_tune picked 16 in every 50 GiB run)
 constexpr uint32_t kTuneAuto = 0xffffffffu;  // ScanArgs::tune: let launch_scan pick the stagger per variant
 
 // Same layout as xsg_chunk (include/xsg.h).
@@ -80,6 +80,7 @@ struct ScanArgs {
   uint32_t* tile_last;                 // (epoch << 16) | max (match offset + plen) in the tile, relative to the tile start
   uint32_t* flags;                     // one word per shard, zero at rest: bit 0 = "non-ASCII byte under an ascii_only expression"
   // inputs/outputs of the emit pass
+  uint64_t m_cap;            // entries m_pos / m_chunk can hold (ranks beyond are dropped; 0 = as many as there are)
   const uint64_t* tile_off;  // exclusive prefix of tile_cnt
   uint64_t* m_pos;           // chunk-local offset of every match, ascending
   uint32_t* m_chunk;         // its chunk
@@ -131,6 +132,8 @@ struct ListArgs {
   uint64_t nchunks;
   PatternDev pat;
   uint64_t M;                // raw matches (bulk, o < limit), ascending per chunk
+  const uint64_t* M_dev;     // if set: the number lives on the device (tile_off[ntiles]); M is then the CAPACITY of the
+                             // arrays and the kernels work on min(*M_dev, M) entries (xsg_count_async, bordered patterns)
   const uint64_t* m_pos;     // chunk-local offsets
   const uint32_t* m_chunk;
   const uint64_t* tile_off;  // -> first raw index of each chunk = tile_off[chunk_tile0[c]]
@@ -156,6 +159,10 @@ hipError_t launch_keep_all(const ListArgs& a, hipStream_t s);
 hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s);
 hipError_t launch_tail_list(const ListArgs& a, hipStream_t s);
 hipError_t launch_assemble(const ListArgs& a, hipStream_t s);
+// counters[XSG_CTR_MATCHES] = sum of keep[0..M) + sum of tail_cnt, counters[XSG_CTR_BYTES] = total_bytes, the other two 0;
+// all four UINT64_MAX if *M_dev exceeds the capacity (the caller falls back to the synchronous route) or the scan
+// raised flags bit 0 (ascii_only expression on non-ASCII data).  counters must be zero on entry.
+hipError_t launch_bordered_total(const ListArgs& a, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, hipStream_t s);
 
 struct LineOutArgs {
   const uint8_t* base;

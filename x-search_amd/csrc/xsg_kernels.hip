@@ -20,6 +20,8 @@
 // nothing writes nothing (the per-tile arrays are preset by the host).
 // Everything else (exact verification, popcounts, ordered compaction, line
 // summaries) lives in a wave-uniform slow path.
+#include <algorithm>
+
 #include "xsg_internal.h"
 #include "xsg_linesum.h"
 #include "xsg_tail.h"
@@ -813,8 +815,10 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
         while (mm) {
           const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
           mm &= mm - 1u;
-          A.m_pos[r] = unit_off + b - (KIND >= kLong ? P.koff : 0u);
-          A.m_chunk[r] = c;
+          if (A.m_cap == 0 || r < A.m_cap) {  // bounded emission (xsg_count_async): what does not fit is counted, not stored
+            A.m_pos[r] = unit_off + b - (KIND >= kLong ? P.koff : 0u);
+            A.m_chunk[r] = c;
+          }
           ++r;
         }
       }
@@ -873,7 +877,7 @@ static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, b
   // memory-bound (7.0 -> 7.36 TB/s with the stagger); the other kinds measured 2-3 % slower with it
   const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo || a.pat.kind == kLong) &&
                      (!a.pat.icase || a.pat.kind == kTwo) && !want_nl && !emit;
-  return !light ? 0u : (want_lines ? 4u : kDefaultStagger);
+  return !light ? 0u : kDefaultStagger;  // count_lines too: 7.1 TB/s at 4 against 7.46-7.49 at 16 on the 50 GiB shard
 }
 
 void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap) {
@@ -1277,9 +1281,16 @@ static inline dim3 grid_for(uint64_t n) {
   return dim3((unsigned)b);
 }
 
+// number of raw entries the list kernels work on: the host's value, or the device's bounded by the arrays' capacity
+__device__ __forceinline__ uint64_t list_count(const ListArgs& A) {
+  if (!A.M_dev) return A.M;
+  const uint64_t m = *A.M_dev;
+  return m < A.M ? m : A.M;
+}
+
 __global__ void k_keep_all(const ListArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < A.M) A.keep[i] = 1u;
+  if (i < list_count(A)) A.keep[i] = 1u;
 }
 
 // Greedy non-overlap (shift = match + plen, simd_search.cpp:333 /
@@ -1288,7 +1299,8 @@ __global__ void k_keep_all(const ListArgs A) {
 // chain; the thread owning a chain head walks its chain.
 __global__ void k_greedy_keep(const ListArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= A.M) return;
+  const uint64_t M = list_count(A);
+  if (i >= M) return;
   const uint32_t plen = A.pat.plen;
   const uint32_t c = A.m_chunk[i];
   const bool head = i == 0 || A.m_chunk[i - 1] != c || A.m_pos[i] - A.m_pos[i - 1] >= plen;
@@ -1298,19 +1310,19 @@ __global__ void k_greedy_keep(const ListArgs A) {
   // The walk is a chain of dependent decisions, but not of dependent LOADS: eight entries are fetched at a time
   // (independent loads, one latency) and decided from registers -- a long chain (a run of one byte searched for
   // `aa` is one chain per chunk) moves at ~6 ns per occurrence instead of ~50.
-  for (uint64_t j = i + 1; j < A.M;) {
+  for (uint64_t j = i + 1; j < M;) {
     uint64_t p[8];
     uint32_t ch[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const uint64_t idx = j + (uint64_t)u < A.M ? j + (uint64_t)u : A.M - 1;
+      const uint64_t idx = j + (uint64_t)u < M ? j + (uint64_t)u : M - 1;
       p[u] = A.m_pos[idx];
       ch[u] = A.m_chunk[idx];
     }
     bool done = false;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (done || j + (uint64_t)u >= A.M) continue;
+      if (done || j + (uint64_t)u >= M) continue;
       if (ch[u] != c || p[u] - prev >= plen) {  // the chain ends: the next occurrence is a head of its own
         done = true;
         continue;
@@ -1354,7 +1366,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_shift0(const ListArgs A) {
   uint64_t last_end = 0;
   ChunkDev ch{};
   if (live) {
-    const uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
+    const uint64_t M = list_count(A);
+    uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
+    r0 = r0 < M ? r0 : M;  // bounded emission: entries beyond the capacity do not exist (the total is refused later)
+    r1 = r1 < M ? r1 : M;
     // last kept raw match of the chunk (kept ones are never far from the end of a chain)
     for (uint64_t i = r1; i > r0; --i) {
       if (A.keep[i - 1]) {
@@ -1419,6 +1434,38 @@ __global__ void k_assemble(const ListArgs A) {
       }
     }
   }
+}
+
+// xsg_count_async for patterns that can overlap themselves: the greedy walk's count without a trip to the host
+__global__ __launch_bounds__(kBlock) void k_bordered_total(const ListArgs A, uint64_t* counters) {
+  __shared__ uint64_t sh[kWaves];
+  const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t gsz = (uint64_t)gridDim.x * kBlock;
+  const uint64_t M = list_count(A);
+  uint64_t n = 0;
+  for (uint64_t i = gid; i < M; i += gsz) n += A.keep[i];
+  for (uint64_t c = gid; c < A.nchunks; c += gsz) n += A.tail_cnt[c];
+  const uint64_t t = block_sum_u64(n, sh);
+  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&counters[XSG_CTR_MATCHES], (unsigned long long)t);
+}
+__global__ void k_bordered_seal(const ListArgs A, uint64_t* counters, uint64_t total_bytes, uint32_t* flags) {
+  const bool overflow = A.M_dev && *A.M_dev > A.M;
+  const bool refuse = A.pat.kind == kClass && A.pat.ascii_only && (*flags & 1u);
+  *flags = 0u;
+  if (overflow || refuse) {
+    for (int k = 0; k < XSG_NUM_COUNTERS; ++k) counters[k] = UINT64_MAX;
+  } else {
+    counters[XSG_CTR_BYTES] = total_bytes;
+  }
+}
+
+hipError_t launch_bordered_total(const ListArgs& a, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, hipStream_t s) {
+  uint64_t blocks = (std::max<uint64_t>(a.M, a.nchunks) + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_bordered_total, dim3((unsigned)blocks), dim3(kBlock), 0, s, a, counters);
+  hipLaunchKernelGGL(k_bordered_seal, dim3(1), dim3(1), 0, s, a, counters, total_bytes, flags);
+  return hipGetLastError();
 }
 
 hipError_t launch_keep_all(const ListArgs& a, hipStream_t s) {

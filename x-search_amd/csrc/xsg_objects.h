@@ -133,6 +133,7 @@ struct xsg_shard {
   uint64_t begin_counters[XSG_NUM_COUNTERS] = {0, 0, 0, 0};
 
   int last_mode = -1;
+  uint64_t last_raw_matches = 0;  // raw occurrences of the last list pass (capacity hint for xsg_count_async, bordered patterns)
   uint64_t total = 0;       // elements of the last list search
   uint64_t line_bytes = 0;  // XSG_LINES: packed bytes
   uint64_t last_newlines = 0;  // XSG_LINE_INDICES: '\n' in the shard (for chaining line bases)
