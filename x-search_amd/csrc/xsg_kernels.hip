@@ -379,11 +379,11 @@ __device__ __forceinline__ uint32_t cand_mask16(const uint32_t (&d)[8], const Pa
 // Exact match bits of one unit: filter, position limit, long-pattern verify.
 // Bit b stands for the filter WINDOW at byte b of the unit; the match it belongs to
 // starts P.koff bytes earlier (koff is 0 except for long patterns).
+// m: the window filter's candidate bits of the unit (cand_mask16, or the hot filter's own compare results).
 template <int KIND, bool ICASE>
-__device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const PatternDev& P, const uint8_t* cbase,
-                                                 uint64_t unit_off, uint64_t limit, const uint8_t* lds_pat,
-                                                 uint8_t* lds_view) {
-  uint32_t m = cand_mask16<KIND>(d, P);
+__device__ __forceinline__ uint32_t match_mask16_from(uint32_t m, const uint32_t (&d)[8], const PatternDev& P,
+                                                      const uint8_t* cbase, uint64_t unit_off, uint64_t limit,
+                                                      const uint8_t* lds_pat, uint8_t* lds_view) {
   const uint32_t koff = KIND >= kLong ? P.koff : 0u;
   // the match starts at o = window - koff and must satisfy 0 <= o < limit
   const uint64_t lim_w = limit + koff;
@@ -468,6 +468,13 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
     }
   }
   return m;
+}
+
+template <int KIND, bool ICASE>
+__device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const PatternDev& P, const uint8_t* cbase,
+                                                 uint64_t unit_off, uint64_t limit, const uint8_t* lds_pat,
+                                                 uint8_t* lds_view) {
+  return match_mask16_from<KIND, ICASE>(cand_mask16<KIND>(d, P), d, P, cbase, unit_off, limit, lds_pat, lds_view);
 }
 
 // per-wave running state of k_scan
@@ -596,8 +603,26 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
     // rare in the text.  Otherwise the window filter proper (20 unaligned windows x 2 compares).  Which one runs
     // is decided per shard and pattern by measurement (xsg_api.cpp: choose_hot_filter); running both as a cascade
     // was measured slower than either (the straight-line body outgrows the instruction cache).
-    const bool any_c = (ALIGNED && (KIND == kTwo || KIND == kLong || KIND == kClass)) ? trigger_aligned<KIND>(d, Pf)
-                                                                                    : cand_any<KIND>(d, Pf);
+    constexpr bool kTrigger = ALIGNED && (KIND == kTwo || KIND == kLong || KIND == kClass);
+    // The window filter's 16 compare results are kept (as lane masks on the scalar side) and become the candidate
+    // bits of the slow path: a needle that is in most wave-loads (`that`) used to build its windows and compare them
+    // twice.  Not under LAZY (the slow path compares properly folded bytes) nor behind the aligned trigger (which
+    // has no per-position results).
+    constexpr bool kReuse = !kTrigger && !LAZY;
+    bool cb[16];
+    bool any_c;
+    if (kTrigger) {
+      any_c = trigger_aligned<KIND>(d, Pf);
+    } else {
+      uint32_t w[20];
+      windows<20>(d, w);
+      any_c = false;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        cb[b] = cand_at<KIND>(w, b, Pf);
+        any_c |= cb[b];
+      }
+    }
     if (__ballot(any_c) != 0) {
       if (LAZY) {  // now the exact view: properly folded bytes, own and neighbour's
         const uint32_t f0 = fold4(cur.x), f1 = fold4(cur.y);
@@ -613,7 +638,14 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         d[6] = from_next_lane(ICASE ? fold4(cur.z) : cur.z, ICASE ? fold4(e2r) : e2r, lane);
         d[7] = from_next_lane(ICASE ? fold4(cur.w) : cur.w, ICASE ? fold4(e3r) : e3r, lane);
       }
-      m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat, s_view);
+      if (kReuse) {
+        uint32_t m0 = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) m0 |= (uint32_t)cb[b] << b;
+        m = match_mask16_from<KIND, ICASE>(m0, d, P, cbase, unit_off, limit, s_pat, s_view);
+      } else {
+        m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat, s_view);
+      }
     }
   }
   if (EMIT) {
