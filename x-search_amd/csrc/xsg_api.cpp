@@ -172,6 +172,11 @@ static void window_fields(const uint8_t* p, size_t plen, uint32_t koff, PatternD
   P->m1 = wlen > 4 ? mask32(wlen - 4) : 0u;
   P->q0 = (P->p0 | 0x20202020u) & P->m0;
   P->q1 = (P->p1 | 0x20202020u) & P->m1;
+  // (x | 0x20) == (p | 0x20) holds exactly for x in {p, p - 32} when p is a lower-case letter (the pattern is
+  // already lowered): a window of letters only needs no second look under ignore_case
+  bool letters = true;
+  for (size_t i = 0; i < 8 && i < wlen; ++i) letters &= w[i] >= 'a' && w[i] <= 'z';
+  P->lazy_exact = letters ? 1u : 0u;
 }
 
 // Long patterns: the windows worth MEASURING on the data (choose_hot_filter): the static heuristic's pick first, then

@@ -53,6 +53,8 @@ struct PatternDev {
   uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL
   uint32_t has_newline;     // pattern contains '\n'
   uint32_t icase;           // XSG_FLAG_IGNORE_CASE: data bytes are ASCII-lowered before every compare (pattern is lowered on the host)
+  uint32_t lazy_exact;      // ignore_case: every byte of the filter window is a letter, so the hot filter on (data | 0x20) IS the
+                            // exact folded compare and its results stand (no second, properly folded pass over the window)
   uint32_t hot;             // window kinds (kTwo, kLong, kClass): 1 = aligned-dword trigger, 0 = window filter (k_scan<..., ALIGNED>)
   uint32_t nalt;            // kClass: alternatives (d_pat holds nalt x plen sets, alternative-major); 0/1 otherwise
   uint32_t ascii_only;      // kClass: the expression is exact on ASCII data only ('.', negated classes): k_scan raises

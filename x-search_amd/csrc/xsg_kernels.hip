@@ -624,7 +624,10 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
       }
     }
     if (__ballot(any_c) != 0) {
-      if (LAZY) {  // now the exact view: properly folded bytes, own and neighbour's
+      // ignore_case with a window of letters only: the hot filter's verdict on (data | 0x20) is already the exact
+      // one (PatternDev::lazy_exact) -- no refold, and its compare results stand like those of a case-sensitive search
+      const bool lazy_done = LAZY && !kTrigger && KIND != kClass && P.lazy_exact;
+      if (LAZY && !lazy_done) {  // now the exact view: properly folded bytes, own and neighbour's
         const uint32_t f0 = fold4(cur.x), f1 = fold4(cur.y);
         d[0] = fold4(r[0]), d[1] = fold4(r[1]), d[2] = fold4(r[2]), d[3] = fold4(r[3]);  // r is already cleared
         d[4] = from_next_lane(f0, fold4(e0r), lane);
@@ -638,7 +641,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         d[6] = from_next_lane(ICASE ? fold4(cur.z) : cur.z, ICASE ? fold4(e2r) : e2r, lane);
         d[7] = from_next_lane(ICASE ? fold4(cur.w) : cur.w, ICASE ? fold4(e3r) : e3r, lane);
       }
-      if (kReuse) {
+      if (kReuse || lazy_done) {
         uint32_t m0 = 0;
 #pragma unroll
         for (int b = 0; b < 16; ++b) m0 |= (uint32_t)cb[b] << b;
