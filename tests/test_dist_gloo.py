@@ -97,3 +97,24 @@ def test_chunk_ranges_partition():
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` (how the driver calls it) must spawn its two ranks itself -- before anything
+    touches a GPU -- instead of asking for torch.distributed.run.  On this GPU-less host every rank then refuses
+    loudly (there is no CPU path to bench); what is checked is that the ranks exist and that the parent relays
+    their exit."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    import torch
+    if torch.cuda.device_count() > 0:
+        import pytest
+        pytest.skip("GPU present: the real thing is scripts/gpu_r2.sh's gloo rehearsal")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    err = r.stdout + r.stderr
+    assert "launch N>1 with" not in err                      # round 1's refusal
+    assert err.count("needs an MI355X") >= 2 or "ChildFailedError" in err, err[-2000:]

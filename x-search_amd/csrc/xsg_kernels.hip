@@ -403,10 +403,18 @@ __device__ __forceinline__ uint32_t match_mask16_from(uint32_t m, const uint32_t
       const uint32_t b = (uint32_t)__ffs((int)c) - 1u;
       c &= c - 1u;
       const uint8_t* s = cbase + unit_off + b - koff;  // start of the match
-      bool ok = true;
-      for (uint32_t k = 0; k < koff && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
-      for (uint32_t k = koff + 8; k < P.plen && ok; ++k) ok = fold(s[k], ICASE) == lds_pat[k];
-      if (!ok) m &= ~(1u << b);
+      // eight bytes between exits: their loads are independent and wait once (the tile is streamed with
+      // non-temporal loads, so these come from HBM: a byte at a time with an exit after each was a chain of
+      // ~2 us stalls per candidate -- `detective street` spent 65 % of its wave cycles in s_waitcnt)
+      uint32_t diff = 0;
+      for (uint32_t k0 = 0; k0 < P.plen && !diff; k0 += 8u) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+          const uint32_t k = k0 + j;
+          if (k < P.plen && (k < koff || k >= koff + 8u)) diff |= (uint32_t)(fold(s[k], ICASE) ^ lds_pat[k]);
+        }
+      }
+      if (diff) m &= ~(1u << b);
     }
   }
   if (KIND == kClass) {
