@@ -5,6 +5,7 @@ traffic per launch against the algorithmic bytes (FETCH_SIZE x 2 x 1024 on gfx95
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 from pathlib import Path
@@ -44,7 +45,10 @@ for d in sorted(p for p in root.iterdir() if p.is_dir()):
     if want is None:
         continue
     full = "void " + want + "(xsg::ScanArgs)"
-    for f in glob.glob(str(d / "stats" / "*" / "*kernel_trace.csv")):
+    def newest(pattern):  # gpurun_out/ is merged across calls: an older run's files may still lie next to the new ones
+        fs = glob.glob(pattern)
+        return [max(fs, key=os.path.getmtime)] if fs else []
+    for f in newest(str(d / "stats" / "*" / "*kernel_trace.csv")):
         durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])) for r in csv.DictReader(open(f))
                 if r["Kernel_Name"] == full]
         if durs:
@@ -54,7 +58,7 @@ for d in sorted(p for p in root.iterdir() if p.is_dir()):
             line["avg_ms"] = round(sum(ds) / len(ds) / 1e6, 4)
             line["min_ms"] = round(min(ds) / 1e6, 4)
     acc = defaultdict(list)
-    for f in glob.glob(str(d / "sq" / "*" / "*counter_collection.csv")):
+    for f in newest(str(d / "sq" / "*" / "*counter_collection.csv")):
         rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == full]
         if rows:
             g = max(int(r["Grid_Size"]) for r in rows)
@@ -69,7 +73,7 @@ for d in sorted(p for p in root.iterdir() if p.is_dir()):
         if "SQ_WAIT_ANY" in acc and "SQ_WAVE_CYCLES" in acc:
             line["wait_share"] = round(sum(acc["SQ_WAIT_ANY"]) / sum(acc["SQ_WAVE_CYCLES"]), 3)
     fs = []
-    for f in glob.glob(str(d / "fetch" / "*" / "*counter_collection.csv")):
+    for f in newest(str(d / "fetch" / "*" / "*counter_collection.csv")):
         rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == full and r["Counter_Name"] == "FETCH_SIZE"]
         if rows:
             g = max(int(r["Grid_Size"]) for r in rows)
