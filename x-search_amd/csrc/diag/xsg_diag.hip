@@ -22,6 +22,7 @@ thread_local char g_err[256] = "";
 // VARIANT 0: tile = block index (k_scan's mapping)      1: + non-temporal loads
 //         2: XCD-contiguous (blocks b, b+8, ... walk one eighth of the span)
 //         3: waves of a block interleave their KiBs instead of owning contiguous spans
+//         4..6: variant 1 with other cache-policy bits on the load: "sc1 nt", "sc0 sc1 nt", "sc0 nt" (inline asm)
 template <int LOADS, int VARIANT>
 __global__ __launch_bounds__(kBlock) void k_read_ceiling(const uint8_t* base, uint64_t ntiles, uint32_t* sink) {
   uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
@@ -40,10 +41,18 @@ __global__ __launch_bounds__(kBlock) void k_read_ceiling(const uint8_t* base, ui
     if (VARIANT == 1) {
       const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tbase + off));
       v[j] = make_uint4(t.x, t.y, t.z, t.w);
+    } else if (VARIANT >= 4) {
+      u32x4 t;
+      const uint8_t* p = tbase + off;
+      if (VARIANT == 4) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(t) : "v"(p) : "memory");
+      if (VARIANT == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(t) : "v"(p) : "memory");
+      if (VARIANT == 6) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(t) : "v"(p) : "memory");
+      v[j] = make_uint4(t.x, t.y, t.z, t.w);
     } else {
       v[j] = *reinterpret_cast<const uint4*>(tbase + off);
     }
   }
+  if (VARIANT >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count asm loads
   uint32_t x = 0;
 #pragma unroll
   for (int j = 0; j < LOADS; ++j) x ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
@@ -89,6 +98,9 @@ void launch_rc(int variant, dim3 grid, hipStream_t s, const uint8_t* base, uint6
     case 1: hipLaunchKernelGGL((k_read_ceiling<LOADS, 1>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
     case 2: hipLaunchKernelGGL((k_read_ceiling<LOADS, 2>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
     case 3: hipLaunchKernelGGL((k_read_ceiling<LOADS, 3>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+    case 4: hipLaunchKernelGGL((k_read_ceiling<LOADS, 4>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+    case 5: hipLaunchKernelGGL((k_read_ceiling<LOADS, 5>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+    case 6: hipLaunchKernelGGL((k_read_ceiling<LOADS, 6>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
     default: hipLaunchKernelGGL((k_read_ceiling<LOADS, 0>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
   }
 }
