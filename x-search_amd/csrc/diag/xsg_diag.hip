@@ -23,6 +23,7 @@ thread_local char g_err[256] = "";
 //         2: XCD-contiguous (blocks b, b+8, ... walk one eighth of the span)
 //         3: waves of a block interleave their KiBs instead of owning contiguous spans
 //         4..6: variant 1 with other cache-policy bits on the load: "sc1 nt", "sc0 sc1 nt", "sc0 nt" (inline asm)
+//         7..8: the same through buffer loads the compiler counts: raw_buffer_load_b128 with aux 18 (sc1 nt), 19 (sc0 sc1 nt)
 template <int LOADS, int VARIANT>
 __global__ __launch_bounds__(kBlock) void k_read_ceiling(const uint8_t* base, uint64_t ntiles, uint32_t* sink) {
   uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
@@ -41,6 +42,16 @@ __global__ __launch_bounds__(kBlock) void k_read_ceiling(const uint8_t* base, ui
     if (VARIANT == 1) {
       const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tbase + off));
       v[j] = make_uint4(t.x, t.y, t.z, t.w);
+    } else if (VARIANT >= 7) {
+      // one descriptor per wave (wave-uniform base), the lane's part in voffset
+      const uint8_t* wb = tbase + (VARIANT == 3 ? 0 : (uint64_t)__builtin_amdgcn_readfirstlane(wave) * (kWaveLoad * LOADS));
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)wb);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)wb >> 32));
+      auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+      const uint32_t voff = (uint32_t)j * kWaveLoad + lane * kUnit;
+      const u32x4 t = VARIANT == 7 ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 18)
+                                   : __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 19);
+      v[j] = make_uint4(t.x, t.y, t.z, t.w);
     } else if (VARIANT >= 4) {
       u32x4 t;
       const uint8_t* p = tbase + off;
@@ -52,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void k_read_ceiling(const uint8_t* base, ui
       v[j] = *reinterpret_cast<const uint4*>(tbase + off);
     }
   }
-  if (VARIANT >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count asm loads
+  if (VARIANT >= 4 && VARIANT <= 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count asm loads
   uint32_t x = 0;
 #pragma unroll
   for (int j = 0; j < LOADS; ++j) x ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
@@ -101,6 +112,8 @@ void launch_rc(int variant, dim3 grid, hipStream_t s, const uint8_t* base, uint6
     case 4: hipLaunchKernelGGL((k_read_ceiling<LOADS, 4>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
     case 5: hipLaunchKernelGGL((k_read_ceiling<LOADS, 5>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
     case 6: hipLaunchKernelGGL((k_read_ceiling<LOADS, 6>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+    case 7: hipLaunchKernelGGL((k_read_ceiling<LOADS, 7>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
+    case 8: hipLaunchKernelGGL((k_read_ceiling<LOADS, 8>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
     default: hipLaunchKernelGGL((k_read_ceiling<LOADS, 0>), grid, dim3(kBlock), 0, s, base, ntiles, sink); break;
   }
 }
