@@ -156,6 +156,23 @@ int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint32_t* positi
  * returns the position-wise UNION of the alternatives. */
 int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* alternatives,
                    uint32_t* ascii_only, uint32_t* sets);
+/* Expressions of VARIABLE length (x* x+ x? x{n,m}, lazy forms, alternatives of different lengths) are served by a
+ * second route: the library compiles them into a forward (leftmost-first) and a reverse (longest) byte-class DFA
+ * and k_rx_scan walks every line with them (csrc/xsg_regex.h; restrictions there: no empty matches, no set that
+ * accepts '\n', no anchors).  xsg_regex_check / xsg_regex_info return XSG_OK with *positions == 0 for such an
+ * expression.  This call hands out the automata (for inspection and for the host-side tests, which drive the tables
+ * against another regex engine without a GPU): `info` always; `fwd` / `rev` (row-major, states x ncls entries, each
+ * the NEXT STATE'S ROW OFFSET = state * ncls; state 0 is dead, states >= *_first_acc hold a match) if they have room
+ * for the tables (cap_entries each).  XSG_ENOTSUP: the expression is not served by this route (it may still be a
+ * fixed-length one that xsg_regex_info describes). */
+typedef struct xsg_regex_dfa {
+  uint32_t ncls, minlen, ascii_only;
+  uint32_t fwd_states, fwd_start, fwd_first_acc;
+  uint32_t rev_states, rev_start, rev_first_acc;
+  uint8_t class_of[256];
+} xsg_regex_dfa;
+int xsg_regex_dfa_info(const void* expr, size_t n, uint32_t flags, xsg_regex_dfa* info, uint16_t* fwd, uint16_t* rev,
+                       size_t cap_entries);
 
 /* ---- shards ---------------------------------------------------------------- */
 /* d_base/capacity: device memory owned by the caller (hipMalloc, a torch

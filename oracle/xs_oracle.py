@@ -322,6 +322,140 @@ def compile_class_sequence(expr: bytes, ignore_case: bool = False) -> ClassSeq:
     return cs
 
 
+class _TreeReader(_RegexReader):
+    """The variable-length half of the syntax: x* x+ x? x{n} x{n,} x{n,m}, their lazy
+    forms, alternatives of any lengths.  RE2 is absent from the snapshot (un-vendored, unpinned submodule), so
+    `RE2::PartialMatch` is stood in for by CPython's backtracking `re`, which implements the same published
+    semantics for this syntax (leftmost match; among the matches at that offset the first in priority order:
+    greedy prefers more, lazy less, `a|b` prefers a -- RE2's "leftmost-first", re2/re2.h) by a different algorithm
+    than the product's automata.  The expression is NOT handed to `re` as written: this reader re-emits it with every
+    atom as an explicit byte class (RE2's ASCII definitions of \\d \\w \\s [:classes:], its case folding, '.' as any
+    ASCII byte but \\n), so only the operators' semantics are CPython's.
+    Every method returns (python_source, minlen, sets)."""
+
+    def __init__(self, e: bytes, ignore_case: bool = False):
+        super().__init__(e, ignore_case)
+        self.sets = []
+
+    def emit_set(self, members) -> tuple:
+        m = set(members)
+        if self.icase:  # the sets are closed under ASCII case; the data is searched as it is
+            m |= {b ^ 0x20 for b in m if 0x41 <= (b & ~0x20) <= 0x5a and b < 0x80}
+        self.sets.append(frozenset(m))
+        return b"[" + b"".join(b"\\x%02x" % b for b in sorted(m)) + b"]", 1
+
+    def t_atom(self):
+        e, c = self.e, self.peek()
+        if c == ord("("):
+            self.i += 1
+            if e[self.i:self.i + 1] == b"?":
+                if e[self.i:self.i + 2] != b"?:":
+                    raise UnsupportedRegex("(?")
+                self.i += 2
+            src, mn = self.t_alt()
+            if self.peek() != ord(")"):
+                raise UnsupportedRegex("missing )")
+            self.i += 1
+            return b"(?:" + src + b")", mn
+        if c == ord("["):
+            self.i += 1
+            return self.emit_set(self.bracket())
+        if c == ord("\\"):
+            self.i += 1
+            return self.emit_set(self.escape())
+        if c == ord("."):
+            self.i += 1
+            self.ascii_only = True
+            return self.emit_set(_ASCII - {10})
+        if c in b"*+?^${":
+            raise UnsupportedRegex(f"operator {chr(c)!r}")
+        if c >= 0x80:
+            n = 4 if c >= 0xf0 else 3 if c >= 0xe0 else 2
+            try:
+                e[self.i:self.i + n].decode("utf-8")
+            except UnicodeDecodeError:
+                raise UnsupportedRegex("pattern is not valid UTF-8")
+            parts = [self.emit_set({b})[0] for b in e[self.i:self.i + n]]
+            self.i += n
+            return b"(?:" + b"".join(parts) + b")", n
+        self.i += 1
+        return self.emit_set({c})
+
+    def t_piece(self):
+        src, mn = self.t_atom()
+        c = self.peek()
+        lo = hi = None
+        if c is not None and c in b"*+?":
+            self.i += 1
+            lo, hi = (0, None) if c == ord("*") else (1, None) if c == ord("+") else (0, 1)
+            q = bytes([c])
+        elif c == ord("{"):
+            k = self.e.find(b"}", self.i)
+            body = self.e[self.i + 1:k] if k > 0 else b""
+            parts = body.split(b",")
+            if len(parts) > 2 or not parts[0].isdigit() or len(parts[0]) > 4 or (len(parts) == 2 and parts[1] and
+                                                                                 (not parts[1].isdigit() or len(parts[1]) > 4)):
+                raise UnsupportedRegex("malformed repetition")
+            lo = int(parts[0])
+            hi = lo if len(parts) == 1 else (int(parts[1]) if parts[1] else None)
+            if (hi is not None and (hi < lo or hi == 0)) or lo > 1000 or (hi or 0) > 1000:
+                raise UnsupportedRegex("bad repetition count")
+            self.i = k + 1
+            q = b"{" + body + b"}"
+        else:
+            return src, mn
+        if self.peek() == ord("?"):
+            self.i += 1
+            q += b"?"
+        if self.peek() is not None and self.peek() in b"*+?{":
+            raise UnsupportedRegex("stacked quantifiers")
+        if mn == 0:
+            raise UnsupportedRegex("repetition of something that can match the empty string")
+        return b"(?:" + src + b")" + q, mn * lo
+
+    def t_cat(self):
+        parts, total = [], 0
+        while self.peek() is not None and self.peek() not in b"|)":
+            src, mn = self.t_piece()
+            parts.append(src)
+            total += mn
+        if not parts:
+            raise UnsupportedRegex("empty expression or alternative")
+        return b"".join(parts), total
+
+    def t_alt(self):
+        alts = [self.t_cat()]
+        while self.peek() == ord("|"):
+            self.i += 1
+            alts.append(self.t_cat())
+        if len(alts) == 1:
+            return alts[0]
+        return b"(?:" + b"|".join(a[0] for a in alts) + b")", min(a[1] for a in alts)
+
+
+class RegexProgram:
+    """A variable-length expression as the oracle searches it: `.re` (compiled CPython pattern over explicit byte
+    classes), `.ascii_only`, `.minlen`.  Raises UnsupportedRegex for what the product refuses too: expressions that
+    can match the empty string or a newline, anchors, flags."""
+
+    def __init__(self, expr: bytes, ignore_case: bool = False):
+        import re as _re
+        rd = _TreeReader(bytes(expr), ignore_case)
+        if not rd.e:
+            raise UnsupportedRegex("empty expression")
+        src, mn = rd.t_alt()
+        if rd.i < len(rd.e):
+            raise UnsupportedRegex("unmatched )" if rd.peek() == ord(")") else "trailing garbage")
+        if mn == 0:
+            raise UnsupportedRegex("the expression can match the empty string")
+        if any(10 in st for st in rd.sets):
+            raise UnsupportedRegex("a set of the expression accepts a newline")
+        self.source = src
+        self.re = _re.compile(src, _re.DOTALL)
+        self.ascii_only = rd.ascii_only
+        self.minlen = mn
+
+
 class Oracle:
     def __init__(self):
         build()
@@ -507,6 +641,68 @@ class Oracle:
         self._ascii_guard(data, cs)
         b = _Buf(data)
         return self._list(self.lib.xso_regex_line_indices, b.addr, b.len, C.byref(cs), int(line_base))
+
+    # -- regex wrappers, variable-length expressions (prog = RegexProgram(expr)): the reference's walks
+    #    (search_wrappers.h:63-87, 209-271) line by line, `prog.re.search` standing in for RE2::PartialMatch ----------
+    def rx_byte_offsets(self, data, prog, skip_to_nl=False, as_line_start=False) -> np.ndarray:
+        """_regex_byte_offsets (:63-87); as_line_start = the func of regex::byte_offsets_line (:220-225)"""
+        self._ascii_guard(data, prog)
+        d = _as_bytes(data)
+        out, pos = [], 0
+        while True:
+            m = prog.re.search(d, pos)  # :71 PartialMatch(input, pattern, &match) with input = data[pos:]
+            if m is None:
+                break
+            v = m.start()  # :72-73
+            out.append(d.rfind(b"\n", 0, v) + 1 if as_line_start else v)  # previous_new_line_offset_relative_to_match (:111-123)
+            pos = m.end()  # :74-75
+            if skip_to_nl:  # :76-84
+                nl = d.find(b"\n", pos)
+                if nl < 0:
+                    break
+                pos = nl + 1
+        return np.asarray(out, dtype=np.uint64)
+
+    def rx_count(self, data, prog, skip_to_nl=True) -> int:
+        """regex::count (:250-269): the same walk, counting"""
+        return int(self.rx_byte_offsets(data, prog, skip_to_nl).size)
+
+    def rx_lines_spans(self, data, prog):
+        """xs::lines with a regex (no wrapper in the snapshot: the literal `line` walk, :187-207, with the regex find)"""
+        self._ascii_guard(data, prog)
+        d = _as_bytes(data)
+        beg, ln, pos = [], [], 0
+        while pos < len(d):
+            m = prog.re.search(d, pos)
+            if m is None:
+                break
+            b = d.rfind(b"\n", 0, m.start()) + 1
+            e = d.find(b"\n", m.end())
+            if e < 0:
+                break
+            pos = e + 1
+            beg.append(b)
+            ln.append(e - b)
+        return np.asarray(beg, dtype=np.uint64), np.asarray(ln, dtype=np.uint64)
+
+    def rx_line_indices(self, data, prog, line_base=0) -> np.ndarray:
+        """xs::line_indices with a regex: number of newlines before the line start (inferred, as for literals)"""
+        self._ascii_guard(data, prog)
+        d = _as_bytes(data)
+        out, pos, counted_to, seen = [], 0, 0, 0
+        while pos < len(d):
+            m = prog.re.search(d, pos)
+            if m is None:
+                break
+            b = d.rfind(b"\n", 0, m.start()) + 1
+            seen += d.count(b"\n", counted_to, b)
+            counted_to = b
+            out.append(line_base + seen)
+            e = d.find(b"\n", m.end())
+            if e < 0:
+                break
+            pos = e + 1
+        return np.asarray(out, dtype=np.uint64)
 
     def count_newlines(self, data) -> int:
         b = _Buf(data)

@@ -117,8 +117,12 @@ def oracle_all_modes(oracle, blocks, pattern: bytes, exact=False, global_offsets
 
 def oracle_regex_all_modes(oracle, blocks, expr: bytes, ignore_case=False, global_offsets=None, line_bases=None):
     """oracle_all_modes for a class-sequence regex (search_wrappers.h:63-103,209-271 restated in oracle/)."""
-    from xs_oracle import compile_class_sequence
-    cs = compile_class_sequence(expr, ignore_case)
+    from xs_oracle import RegexProgram, UnsupportedRegex, compile_class_sequence
+    try:
+        cs = compile_class_sequence(expr, ignore_case)
+    except UnsupportedRegex:
+        # not a class sequence: the variable-length family (the product's automaton route); raises if that refuses too
+        return oracle_rx_all_modes(oracle, blocks, RegexProgram(expr, ignore_case), global_offsets, line_bases), True
     orig_blocks = blocks
     if ignore_case:
         blocks = [oracle.lower(b) for b in blocks]
@@ -145,3 +149,29 @@ def oracle_regex_all_modes(oracle, blocks, expr: bytes, ignore_case=False, globa
         goff += int(b.size)
         nl_before += nl
     return out, with_lines
+
+
+def oracle_rx_all_modes(oracle, blocks, prog, global_offsets=None, line_bases=None):
+    """the same dict for a variable-length expression (oracle/xs_oracle.py: RegexProgram; the sets are closed under
+    case, so the data is searched as it is)"""
+    out = {"count_matches": 0, "newlines": 0, "bytes": 0, "match_byte_offsets": [], "count_lines": 0,
+           "line_byte_offsets": [], "line_indices": [], "lines": [], "lines_offsets": []}
+    goff, nl_before = 0, 0
+    for i, b in enumerate(blocks):
+        g = goff if global_offsets is None else int(global_offsets[i])
+        lb = nl_before if line_bases is None else int(line_bases[i])
+        m = oracle.rx_byte_offsets(b, prog, False)
+        out["count_matches"] += int(m.size)
+        out["match_byte_offsets"] += [int(x) + g for x in m]
+        out["count_lines"] += oracle.rx_count(b, prog, True)
+        out["line_byte_offsets"] += [int(x) + g for x in oracle.rx_byte_offsets(b, prog, True, True)]
+        out["line_indices"] += [int(x) for x in oracle.rx_line_indices(b, prog, lb)]
+        beg, ln = oracle.rx_lines_spans(b, prog)
+        out["lines"] += [b[int(s):int(s + l)].tobytes() for s, l in zip(beg, ln)]
+        out["lines_offsets"] += [int(s) + g for s in beg]
+        nl = oracle.count_newlines(b)
+        out["newlines"] += nl
+        out["bytes"] += int(b.size)
+        goff += int(b.size)
+        nl_before += nl
+    return out

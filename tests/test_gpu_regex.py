@@ -10,6 +10,7 @@ import corpus
 import xsg
 from gpu_util import GpuSearch, oracle_all_modes, oracle_regex_all_modes
 from test_oracle_regex import ACCEPTED, REFUSED, rand_expr, rand_expr2
+from test_regex_dfa import VARIABLE, rand_var_expr
 from xs_oracle import UnsupportedRegex
 
 pytestmark = pytest.mark.gpu
@@ -30,7 +31,7 @@ def check(gs, oracle, blocks, expr, icase=False, ctx="", **kw):
         gs.ctx.set_pattern(expr, flags)
         s = gs.shard
         calls = [lambda: s.count(xsg.COUNT_MATCHES), lambda: s.search_u64(xsg.MATCH_BYTE_OFFSETS)]
-        n, sets = xsg.regex_check(expr, flags & xsg.FLAG_IGNORE_CASE)
+        n, sets = xsg.regex_check(expr, flags & xsg.FLAG_IGNORE_CASE)  # n == 0: the automaton route, never matches '\n'
         if not any((int(sets[k][0]) >> 10) & 1 for k in range(n)):  # line modes too, unless the expression can match '\n'
             calls += [lambda: s.count(xsg.COUNT_LINES), lambda: s.search_u64(xsg.LINE_INDICES), lambda: s.search_lines()]
         for call in calls:
@@ -192,3 +193,97 @@ def test_global_offsets_line_bases_and_job_api(gs, oracle, tmp_path):
     got = j.result().tolist()
     # chunks are newline-aligned, so per-chunk walks concatenate to the whole-file walk
     assert got == want["match_byte_offsets"]
+
+
+# ---- the variable-length half: k_rx_scan (csrc/xsg_rx_kernels.hip), one line per lane, two automata -----------------
+def test_variable_length_expressions_on_text(gs, oracle):
+    """operators, lazy forms and alternatives of different lengths on generated text, several chunks, all six tags"""
+    blocks = [corpus.text_block(5151, i, 1_200_000 + 4321 * i, needle_rate=1e-4) for i in range(3)]
+    blocks[2] = np.concatenate([blocks[2][:-1], np.frombuffer(b" Sherlock Holmes", dtype=np.uint8)])  # no final newline
+    gs.bind(blocks)
+    for expr in (b"Sherlock|Holmes|Dr\\. Watson", b"Sher.*mes", b"Sher.*?k", b"colou?r", b"[A-Z][a-z]+ [A-Z][a-z]+",
+                 b"lock(ed|s)?", b"\\w+ing", b"(the|The) +\\w{5,}", b"S[a-z]{3,9}k", b"o{2,}", b"[0-9]+", b"a.{0,12}?z",
+                 b"(?:st|pad)lock|str+eet"):
+        for icase in (False, True):
+            want = check(gs, oracle, blocks, expr, icase, "variable")
+            assert want is not None and (want["count_matches"] > 0 or expr == b"[0-9]+")
+
+
+def test_variable_length_expressions_on_awkward_shards(gs, oracle):
+    """chunks of 0, 1, tile and tile+-1 bytes, lines longer than a tile, lines that straddle tiles, last lines
+    without a newline, data of newlines only"""
+    rng = np.random.default_rng(77)
+    alphabet = np.frombuffer(b"aabbccxyz01 _\n", dtype=np.uint8)
+    long_line = alphabet[rng.integers(0, len(alphabet) - 1, size=50_000)].copy()  # no newline in 50 KB
+    blocks = [alphabet[rng.integers(0, len(alphabet), size=n)].copy() for n in (0, 1, 16383, 16384, 16385, 40_000)]
+    blocks += [long_line, np.full(20_000, 10, dtype=np.uint8), np.concatenate([long_line[:20_000], [10], long_line[:30_000]])]
+    gs.bind(blocks)
+    for expr in VARIABLE:
+        if b"\xc3" in expr:
+            continue
+        for icase in (False, True):
+            check(gs, oracle, blocks, expr, icase, "awkward")
+
+
+def test_variable_length_ascii_only_refusal_and_job_api(gs, oracle, tmp_path):
+    import torch
+    text = corpus.text_block(98, 0, 300_000)
+    dirty = text.copy()
+    dirty[200_001:200_003] = (0xc3, 0xa9)
+    gs.bind([text, dirty])
+    assert check(gs, oracle, [text, dirty], b"Sher.*k") is None          # '.' on non-ASCII data: refused
+    assert check(gs, oracle, [text, dirty], b"Sherlock|Holmes!*") is not None  # explicit bytes only: served
+    gs.ctx.set_pattern(b"Sher.*k", xsg.FLAG_REGEX)
+    c = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    gs.shard.count_async(xsg.COUNT_MATCHES, 0, c.data_ptr())
+    torch.cuda.synchronize()
+    assert all(int(x) == -1 for x in c.cpu())
+    gs.bind([text])
+    want = check(gs, oracle, [text], b"Sher.*k")
+    # asynchronous counts of both kinds, on the clean shard
+    gs.ctx.set_pattern(b"Sher.*k", xsg.FLAG_REGEX)
+    for mode, key, ctr in ((xsg.COUNT_MATCHES, "count_matches", xsg.CTR_MATCHES), (xsg.COUNT_LINES, "count_lines", xsg.CTR_LINES)):
+        gs.shard.count_async(mode | xsg.WITH_NEWLINES, 0, c.data_ptr())
+        torch.cuda.synchronize()
+        got = c.cpu().tolist()
+        assert got[ctr] == want[key] and got[xsg.CTR_NEWLINES] == want["newlines"]
+    # through the file pipeline
+    path = tmp_path / "t.txt"
+    text.tofile(path)
+    j = xsg.Job(b"[Tt]he +[a-z]+ly ", str(path), mode=xsg.MATCH_BYTE_OFFSETS, flags=xsg.FLAG_REGEX, chunk_bytes=65536,
+                num_threads=2, num_max_readers=2)
+    want2, _ = oracle_regex_all_modes(oracle, [text], b"[Tt]he +[a-z]+ly ")
+    assert j.result().tolist() == want2["match_byte_offsets"]
+
+
+def rx_rounds(seed, oracle, gs, rounds=12):
+    rng = np.random.default_rng(9000 + seed)
+    sizes = [0, 1, 63, 64, 65, 1023, 1024, 1025, 16383, 16384, 16385, 32769]
+    alphabets = [np.frombuffer(b"aabbccxyz01 _\n\n", dtype=np.uint8), np.frombuffer(b"ab\n", dtype=np.uint8),
+                 np.frombuffer(b"abcxyz01 _ abc\n", dtype=np.uint8)]
+    done = 0
+    for it in range(rounds):
+        alphabet = alphabets[int(rng.integers(0, len(alphabets)))]
+        blocks = []
+        for _ in range(int(rng.integers(1, 6))):
+            n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(0, 60_000))
+            b = alphabet[rng.integers(0, len(alphabet), size=n)].copy()
+            if n and rng.random() < 0.6:
+                b[-1] = 10
+            blocks.append(b)
+        gs.bind(blocks)
+        for k in range(6):
+            expr = rand_var_expr(rng)
+            icase = bool(rng.integers(0, 3) == 0)
+            try:
+                xsg.regex_check(expr, xsg.FLAG_IGNORE_CASE if icase else 0)
+            except xsg.XsgError:
+                continue
+            check(gs, oracle, blocks, expr, icase, f"seed={seed} it={it} sizes={[b.size for b in blocks]}")
+            done += 1
+    return done
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_variable_length_expressions(gs, oracle, seed):
+    assert rx_rounds(seed, oracle, gs) > 20

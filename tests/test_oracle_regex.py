@@ -16,10 +16,12 @@ from xs_oracle import UnsupportedRegex, compile_class_sequence
 
 GOLD = Path(__file__).parent / "golden"
 
-REFUSED = [b"a*", b"ab+", b"colou?r", b"^ab", b"ab$", b"x{2,3}", b"x{2,}", b"\\bab", b"(?i)ab", b"(?P<n>ab)", b"(ab)*",
+REFUSED = [b"a*", b"^ab", b"ab$", b"\\bab", b"(?i)ab", b"(?P<n>ab)", b"(ab)*",
            b"(ab)?", b"ab\\", b"[ab", b"(ab", b"ab)", b"\\pLab", b"\\Qab\\E", b"\\1", b"[\xc3\xa9]", b"\xff", b"a{0}", b"{2}",
-           b"\\x{100}", b"\\xzz", b"()", b"a" * 33, b"ab|c", b"a||b", b"|a", b"(a|bc)d", b"a{2}{3}", b"[[:nope:]]",
-           b"(ab|c)(d|ef)"]
+           b"\\x{100}", b"\\xzz", b"()", b"a||b", b"|a", b"a{2}{3}", b"[[:nope:]]"]
+# not class sequences (the oracle's class-sequence reader refuses them), served by the product's automaton route
+# (tests/test_regex_dfa.py): variable length, or more positions than the scan kernel's 32
+VARIABLE = [b"ab+", b"colou?r", b"x{2,3}", b"x{2,}", b"ab|c", b"(a|bc)d", b"(ab|c)(d|ef)", b"a" * 33]
 ACCEPTED = [b"She[r ]lock", b"(a[n|m]t)", b"[0-9]{4}-\\d\\d", b"a\\.b", b"\\w{3} \\w", b"[]a]x", b"[a\\]]x", b"[a-]x", b"[-a]x",
             b"gr[ae]y", b"((a)[bc])d", b"\\x41\\x{42}[\\x43-\\x45]", b"caf\xc3\xa9 [ab]", b"a]b}", b"\\t[ \\t]x", b"[\\d_]x",
             b"\\[a\\]", b"a{3}b{1}", b"[a-c]{32}",
@@ -98,6 +100,14 @@ def test_both_parsers_refuse(expr):
     assert "not supported" in str(ei.value)
 
 
+@pytest.mark.parametrize("expr", VARIABLE)
+def test_not_a_class_sequence_but_served(expr):
+    with pytest.raises(UnsupportedRegex):
+        compile_class_sequence(expr)
+    assert xsg.regex_check(expr)[0] == 0  # 0 positions: "variable length, the automaton route"
+    xs_oracle.RegexProgram(expr)
+
+
 @pytest.mark.parametrize("expr", ACCEPTED)
 def test_both_parsers_agree(expr):
     rng = np.random.default_rng(len(expr) * 7919 + expr[0])
@@ -106,13 +116,13 @@ def test_both_parsers_agree(expr):
 
 
 def test_product_limits_on_alternatives():
-    """more than 8 alternatives that cannot be merged, or more than 64 sets: refused by the product (the oracle,
-    which keeps up to 256 sets, would take them)"""
+    """more than 8 alternatives that cannot be merged, or more than 64 sets: too many for the scan kernel's
+    position-wise matcher (the oracle's class-sequence reader, which keeps up to 256 sets, takes them) -- the product
+    serves them through the automaton route instead (0 positions reported)"""
     for expr in (b"aa|bb|cc|dd|ee|ff|gg|hh|ii", b"|".join(bytes([97 + i]) * 9 for i in range(8))):
         compile_class_sequence(expr)
-        with pytest.raises(xsg.XsgError) as ei:
-            xsg.regex_check(expr)
-        assert ei.value.code == xsg.ENOTSUP and "alternatives" in str(ei.value)
+        assert xsg.regex_check(expr)[0] == 0
+        xsg.regex_dfa(expr)
     # eight that merge down are fine: (a|b)(c|d)(e|f) is one sequence of three classes
     assert xsg.regex_info(b"(a|b)(c|d)(e|f)")[1] == 1
 

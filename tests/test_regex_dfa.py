@@ -1,0 +1,177 @@
+"""The regex row, variable-length half: the automata the product compiles
+(x-search_amd/csrc/xsg_regex.cpp, handed out by xsg_regex_dfa_info -- host code, no GPU needed) are driven here
+exactly as k_rx_scan drives them (x-search_amd/csrc/xsg_rx_kernels.hip: one line at a time, forward automaton to the
+end of the leftmost-first match, reverse automaton back to its start) and compared with the oracle's walk
+(oracle/xs_oracle.py: RegexProgram, CPython's backtracking `re` over explicit byte classes standing in for
+RE2::PartialMatch, include/xsearch/string_search/search_wrappers.h:63-87)."""
+import re
+
+import numpy as np
+import pytest
+
+import xs_oracle
+import xsg
+from xs_oracle import RegexProgram, UnsupportedRegex
+
+VARIABLE = [b"ab+", b"colou?r", b"x{2,3}", b"x{2,}", b"ab|c", b"(a|bc)d", b"(ab|c)(d|ef)", b"Sher.*k", b"Sher.*?k",
+            b"[a-z]+ing", b"(foo|ba+r)+x", b"a{2,4}?b", b"\\d+\\.\\d*", b"[A-Z][a-z]+ [A-Z][a-z]+", b"(ab)*c", b"(ab)?c",
+            b"a(b|cd){1,3}e", b"x+?y", b"caf\xc3\xa9+", b"[[:alpha:]]+[[:digit:]]", b"\\w+@\\w+\\.com", b"a.{0,5}b",
+            b"(a|ab)(c|bcd)", b"(a+)(b+)?c", b"z{3,}"]
+REFUSED = [b"a*", b"(ab)*", b"(ab)?", b"a?b?", b"^ab+", b"ab+$", b"\\bab+", b"(?i)ab+", b"(a*)+b", b"(a?){2}b", b"a**", b"a+*",
+           b"a{2}{3}", b"x{3,2}", b"x{,3}y+", b"a+\\", b"[ab", b"(ab+", b"ab+)", b"a||b+", b"|a+", b"\\s+x", b"[^a]+b", b"a\\nb+",
+           b"x{1001}y+", b"a{0}b+", b"\\pL+"]
+
+
+def dfa_line_matches(info, fwd, rev, d: bytes, lo: int, hi: int):
+    """k_rx_scan's walk of one line d[lo, hi) (hi: its '\\n' or the end of the chunk) -> [(start, end)]"""
+    cls = bytes(info.class_of)
+    ncls = info.ncls
+    facc, racc = info.fwd_first_acc * ncls, info.rev_first_acc * ncls
+    F, R = fwd.ravel(), rev.ravel()
+    out, cur = [], lo
+    while True:
+        st, q, last_end = info.fwd_start * ncls, cur, 0
+        while q < hi + 1 and q < len(d):  # the '\n' itself is fed: it kills every state
+            st = int(F[st + cls[d[q]]])
+            if st == 0:
+                break
+            q += 1
+            if st >= facc:
+                last_end = q
+        if not last_end:
+            return out
+        rs, r, start = info.rev_start * ncls, last_end, last_end
+        while r > cur:
+            rs = int(R[rs + cls[d[r - 1]]])
+            if rs == 0:
+                break
+            r -= 1
+            if rs >= racc:
+                start = r
+        out.append((start, last_end))
+        cur = last_end
+
+
+def dfa_matches(info, fwd, rev, d: bytes):
+    out, lo = [], 0
+    while lo < len(d):
+        nl = d.find(b"\n", lo)
+        hi = nl if nl >= 0 else len(d)
+        out += dfa_line_matches(info, fwd, rev, d, lo, hi)
+        lo = hi + 1
+    return out
+
+
+def oracle_matches(prog, d: bytes):
+    out, pos = [], 0
+    while True:
+        m = prog.re.search(d, pos)
+        if m is None:
+            return out
+        out.append((m.start(), m.end()))
+        pos = m.end()
+
+
+@pytest.mark.parametrize("expr", VARIABLE)
+def test_variable_length_expressions_are_served_by_the_automaton_route(expr):
+    for icase in (False, True):
+        flags = xsg.FLAG_IGNORE_CASE if icase else 0
+        n, _ = xsg.regex_check(expr, flags)
+        assert n == 0  # "variable length"
+        info, fwd, rev = xsg.regex_dfa(expr, flags)
+        prog = RegexProgram(expr, icase)
+        assert info.minlen == prog.minlen and bool(info.ascii_only) == prog.ascii_only
+        assert info.class_of[10] not in [info.class_of[b] for b in range(256) if b != 10]  # '\n' has its own class
+        assert not fwd[:, info.class_of[10]].any() and not rev[:, info.class_of[10]].any()  # ... and kills every state
+
+
+@pytest.mark.parametrize("expr", REFUSED)
+def test_both_sides_refuse(expr):
+    with pytest.raises(UnsupportedRegex):
+        RegexProgram(expr)
+    with pytest.raises(xsg.XsgError) as ei:
+        xsg.regex_check(expr)
+    assert ei.value.code in (xsg.ENOTSUP, xsg.EINVAL) and "not supported" in str(ei.value)
+    with pytest.raises(xsg.XsgError):
+        xsg.regex_dfa(expr)
+
+
+def rand_var_expr(rng, depth=0):
+    """a random expression of the variable-length syntax (operators, alternation, groups over small alphabets)"""
+    def atom():
+        k = int(rng.integers(0, 10))
+        if k <= 3:
+            return bytes([b"abcxyz01 _"[int(rng.integers(0, 10))]])
+        if k == 4:
+            return b"."
+        if k == 5:
+            return b"[" + bytes(b"abcxyz"[int(i)] for i in rng.integers(0, 6, size=int(rng.integers(1, 4)))) + b"]"
+        if k == 6:
+            return [b"\\d", b"\\w", b"[a-c]", b"[^a\\n]", b"[^ab\\n]", b"\\S"][int(rng.integers(0, 6))]
+        if k == 7 and depth < 1:
+            return b"(" + rand_var_expr(rng, depth + 1) + b")"
+        if k == 8 and depth < 1:
+            return b"(?:" + rand_var_expr(rng, depth + 1) + b")"
+        return bytes([b"ab"[int(rng.integers(0, 2))]])
+
+    def piece():
+        a = atom()
+        k = int(rng.integers(0, 12))
+        q = [b"", b"", b"", b"", b"", b"*", b"+", b"?", b"{2}", b"{1,3}", b"{2,}", b"{0,2}"][k]
+        if q and rng.random() < 0.25:
+            q += b"?"
+        return a + q
+
+    alts = []
+    for _ in range(int(rng.integers(1, 4 - depth))):
+        alts.append(b"".join(piece() for _ in range(int(rng.integers(1, 5 - 2 * depth)))))
+    return b"|".join(alts)
+
+
+def test_automata_against_the_oracle_on_random_expressions():
+    rng = np.random.default_rng(7321)
+    alphabet = np.frombuffer(b"aabbccxyz01 _\n\n", dtype=np.uint8)
+    served = refused_both = 0
+    for it in range(1500):
+        expr = rand_var_expr(rng)
+        icase = bool(rng.integers(0, 4) == 0)
+        flags = xsg.FLAG_IGNORE_CASE if icase else 0
+        try:
+            prog = RegexProgram(expr, icase)
+        except UnsupportedRegex:
+            with pytest.raises(xsg.XsgError):
+                xsg.regex_dfa(expr, flags)
+            refused_both += 1
+            continue
+        try:
+            info, fwd, rev = xsg.regex_dfa(expr, flags)
+        except xsg.XsgError as e:
+            assert "automaton of" in str(e) or "NFA positions" in str(e), (expr, str(e))  # size limits only
+            continue
+        data = alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 600)))].tobytes()
+        if icase:
+            data = bytes(b - 32 if 97 <= b <= 122 and rng.random() < 0.4 else b for b in data)
+        assert dfa_matches(info, fwd, rev, data) == oracle_matches(prog, data), (expr, icase, data)
+        served += 1
+    assert served > 700 and refused_both > 100
+
+
+def test_cpython_reads_the_operators_as_written_too():
+    """the oracle re-emits the expression over explicit byte classes; on expressions CPython reads natively the same
+    way, searching the expression AS WRITTEN gives the same matches (guards the re-emission)"""
+    rng = np.random.default_rng(99)
+    alphabet = np.frombuffer(b"aabbccxyz01 _\n", dtype=np.uint8)
+    done = 0
+    for _ in range(400):
+        expr = rand_var_expr(rng)
+        if b"\\S" in expr or b"\\w" in expr or b"\\d" in expr:  # CPython's bytes classes agree on ASCII, but keep it literal
+            continue
+        try:
+            prog = RegexProgram(expr)
+            native = re.compile(expr)
+        except (UnsupportedRegex, re.error):
+            continue
+        data = alphabet[rng.integers(0, len(alphabet), size=300)].tobytes()
+        assert oracle_matches(prog, data) == [(m.start(), m.end()) for m in native.finditer(data)], expr
+        done += 1
+    assert done > 100

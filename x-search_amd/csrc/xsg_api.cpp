@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "xsg_classseq.h"
+#include "xsg_regex.h"
 #include "xsg_objects.h"
 #include "xsg_linesum.h"
 #include "xsg_tail.h"
@@ -196,14 +197,67 @@ static std::vector<uint32_t> window_candidates(const uint8_t* p, size_t plen) {
   return out;
 }
 
+// layout of the device copy of a RegexDfa: class_of[256], then the forward table, then (16-byte aligned) the reverse one
+static size_t rx_rev_offset(uint32_t fwd_entries) { return (256 + 2 * (size_t)fwd_entries + 15) & ~(size_t)15; }
+
+// XSG_FLAG_REGEX, second route: an expression of variable length, as a pair of byte-class DFAs for k_rx_scan
+// (xsg_regex.h).  `why_not_class`: what the class-sequence compiler said, for the message if this route refuses too.
+static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t flags, const std::string& why_not_class) {
+  xsg::RegexDfa dfa;
+  std::string err;
+  const bool icase = (flags & XSG_FLAG_IGNORE_CASE) != 0;
+  if (!xsg::compile_regex_dfa(re, n, icase, &dfa, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the GPU matchers: %s [as a fixed-length expression: %s]", err.c_str(),
+                why_not_class.c_str());
+  HIP_TRY(hipSetDevice(c->device));
+  c->pattern.assign(re, re + n);
+  c->flags = flags;
+  ++c->pattern_serial;
+  c->koff_cands.clear();
+  c->bordered = false;  // the kernel walks every line as the reference does: what it reports is already non-overlapping
+  const size_t rev_off = rx_rev_offset((uint32_t)dfa.fwd.size());
+  const size_t bytes = rev_off + 2 * dfa.rev.size() + 16;
+  std::vector<uint8_t> blob(bytes, 0);
+  memcpy(blob.data(), dfa.class_of, 256);
+  // Trigger bytes: those that move the forward automaton out of its start state (a byte that cannot begin a match
+  // leaves it there), and '\n'.  Flagged in bit 7 of the class table; k_rx_scan's walks jump from trigger to trigger.
+  const char* skip_env = getenv("XSG_RX_SKIP");
+  const bool skip = dfa.ncls <= 128 && !(skip_env && *skip_env == '0');
+  if (skip)
+    for (uint32_t b = 0; b < 256; ++b)
+      if (b == '\n' || dfa.fwd[(size_t)dfa.fwd_start * dfa.ncls + dfa.class_of[b]] != dfa.fwd_start * dfa.ncls) blob[b] |= 0x80u;
+  memcpy(blob.data() + 256, dfa.fwd.data(), 2 * dfa.fwd.size());
+  memcpy(blob.data() + rev_off, dfa.rev.data(), 2 * dfa.rev.size());
+  XSG_TRY(c->d_pat.ensure(std::max<size_t>(bytes, XSG_MAX_PATTERN + 16)));
+  HIP_TRY(hipMemcpyAsync(c->d_pat.p, blob.data(), bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  PatternDev& P = c->pat;
+  P = PatternDev{};
+  P.plen = dfa.minlen;  // what the list kernels may skip behind a match start before they look for the line's end
+  P.kind = kDfa;
+  P.d_pat = c->d_pat.as<uint8_t>();
+  P.exact_tail = 1u;
+  P.icase = 0u;  // the sets are closed under case; the data is not folded
+  P.ascii_only = dfa.ascii_only ? 1u : 0u;
+  P.has_newline = 0;  // refused at compile time
+  P.rx_ncls = dfa.ncls;
+  P.rx_fwd_n = (uint32_t)dfa.fwd.size();
+  P.rx_rev_n = (uint32_t)dfa.rev.size();
+  P.rx_fwd_start = dfa.fwd_start * dfa.ncls;
+  P.rx_fwd_acc = dfa.fwd_first_acc * dfa.ncls;
+  P.rx_rev_start = dfa.rev_start * dfa.ncls;
+  P.rx_rev_acc = dfa.rev_first_acc * dfa.ncls;
+  P.rx_skip = skip ? 1u : 0u;
+  return XSG_OK;
+}
+
 // XSG_FLAG_REGEX: a fixed-length class sequence (xsg_classseq.h).  RE2 has no lossy tail, so the
 // matching is exact up to the end of the chunk (as with XSG_FLAG_EXACT_TAIL).
 static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t flags) {
   xsg::ClassExpr ex;
   std::string err;
   const bool icase = (flags & XSG_FLAG_IGNORE_CASE) != 0;
-  if (!xsg::compile_class_expr(re, n, icase, &ex, &err))
-    return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
+  if (!xsg::compile_class_expr(re, n, icase, &ex, &err)) return set_dfa_pattern(c, re, n, flags, err);
   const size_t plen = ex.npos;
   const std::vector<xsg::ByteSet> seq = xsg::union_sets(ex);  // what the filter, the overlap and '\n' tests look at
   bool literal = ex.alts.size() == 1;
@@ -281,13 +335,43 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   return XSG_OK;
 }
 
+static int dfa_route_serves(const void* expr, size_t n, uint32_t flags, const std::string& why_not_class, xsg::RegexDfa* out) {
+  xsg::RegexDfa local;
+  std::string err;
+  if (!xsg::compile_regex_dfa(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, out ? out : &local, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the GPU matchers: %s [as a fixed-length expression: %s]", err.c_str(),
+                why_not_class.c_str());
+  return XSG_OK;
+}
+
+extern "C" int xsg_regex_dfa_info(const void* expr, size_t n, uint32_t flags, xsg_regex_dfa* info, uint16_t* fwd,
+                                  uint16_t* rev, size_t cap_entries) {
+  if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
+  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  if (!info) return fail(XSG_EINVAL, "info is null");
+  xsg::RegexDfa dfa;
+  std::string err;
+  if (!xsg::compile_regex_dfa(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &dfa, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the automaton route: %s", err.c_str());
+  info->ncls = dfa.ncls, info->minlen = dfa.minlen, info->ascii_only = dfa.ascii_only ? 1u : 0u;
+  info->fwd_states = dfa.fwd_states, info->fwd_start = dfa.fwd_start, info->fwd_first_acc = dfa.fwd_first_acc;
+  info->rev_states = dfa.rev_states, info->rev_start = dfa.rev_start, info->rev_first_acc = dfa.rev_first_acc;
+  memcpy(info->class_of, dfa.class_of, 256);
+  if (fwd && cap_entries >= dfa.fwd.size()) memcpy(fwd, dfa.fwd.data(), 2 * dfa.fwd.size());
+  if (rev && cap_entries >= dfa.rev.size()) memcpy(rev, dfa.rev.data(), 2 * dfa.rev.size());
+  return XSG_OK;
+}
+
 extern "C" int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets) {
   if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
   if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
   xsg::ClassExpr ex;
   std::string err;
-  if (!xsg::compile_class_expr(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &ex, &err))
-    return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
+  if (!xsg::compile_class_expr(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &ex, &err)) {
+    XSG_TRY(dfa_route_serves(expr, n, flags, err, nullptr));
+    if (positions) *positions = 0;  // variable length: no position-wise sets; such an expression never accepts '\n'
+    return XSG_OK;
+  }
   const std::vector<xsg::ByteSet> seq = xsg::union_sets(ex);
   if (positions) *positions = (uint32_t)seq.size();
   if (sets) memcpy(sets, seq.data(), seq.size() * sizeof(xsg::ByteSet));
@@ -300,8 +384,14 @@ extern "C" int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32
   if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
   xsg::ClassExpr ex;
   std::string err;
-  if (!xsg::compile_class_expr(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &ex, &err))
-    return fail(XSG_ENOTSUP, "regex not supported by the GPU matcher: %s", err.c_str());
+  if (!xsg::compile_class_expr(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &ex, &err)) {
+    xsg::RegexDfa dfa;
+    XSG_TRY(dfa_route_serves(expr, n, flags, err, &dfa));
+    if (positions) *positions = 0;
+    if (alternatives) *alternatives = 0;
+    if (ascii_only) *ascii_only = dfa.ascii_only ? 1u : 0u;
+    return XSG_OK;
+  }
   if (positions) *positions = ex.npos;
   if (alternatives) *alternatives = (uint32_t)ex.alts.size();
   if (ascii_only) *ascii_only = ex.ascii_only ? 1u : 0u;
@@ -638,13 +728,16 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
   XSG_TRY(choose_hot_filter(s, st));
   const uint64_t nchunks = s->chunks.size();
+  // kDfa: k_rx_scan counts matching lines directly into tile_cnt (a line is one lane's work): no line summaries
+  const bool rx_lines = want_lines && s->ctx->pat.kind == kDfa;
+  if (rx_lines) want_lines = false;
   XSG_TRY(prepare_tiles(s, want_lines, st));
   const bool scan_nl = want_nl && !s->nl_cached;  // the per-tile newline counts of this binding may already exist
   ScanArgs a = scan_args(s);
   // dirty until the finish kernel is in the queue behind the scan
   s->cnt_clean = false;
   if (want_lines) s->sum_clean = false;
-  HIP_TRY(launch_scan_count(a, scan_nl, want_lines, st));
+  HIP_TRY(launch_scan_count(a, scan_nl, want_lines || rx_lines, st));
   FinishArgs f{};
   f.base = s->base;
   f.chunks = a.chunks;
@@ -666,7 +759,8 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   f.total_bytes = s->total_bytes;
   f.want_nl = want_nl;
   f.want_lines = want_lines;
-  f.want_matches = want_matches;
+  f.want_matches = want_matches || rx_lines;
+  f.cnt_is_lines = rx_lines ? 1u : 0u;
   HIP_TRY(launch_count_finish(f, st));
   s->cnt_clean = true;
   if (want_lines) s->sum_clean = true;
@@ -893,6 +987,7 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   s->tune = kTuneAuto;
   if (chosen) *chosen = kTuneAuto;
   if (c->tune != kTuneAuto || s->total_bytes < (1ull << 30)) return XSG_OK;  // XSG_TUNE wins; too small to measure
+  if (c->pat.kind == kDfa) return XSG_OK;  // k_rx_scan has no stagger
   static const uint32_t cand[] = {0, 4, 8, 10, 12, 14, 16, 20};
   float best_ms = 0;
   uint32_t best = kTuneAuto, best_hot = 0;
@@ -962,7 +1057,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   HIP_TRY(launch_exclusive_scan_u32(a.tile_cnt, s->d_tile_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(), st));
   uint64_t M = 0;
   uint32_t scan_flags = 0;
-  if (c->pat.kind == kClass && c->pat.ascii_only)
+  if ((c->pat.kind == kClass || c->pat.kind == kDfa) && c->pat.ascii_only)
     HIP_TRY(hipMemcpyAsync(&scan_flags, a.flags, 4, hipMemcpyDeviceToHost, st));
   XSG_TRY(d2h_u64(c, s->d_tile_off.as<uint64_t>() + ntiles, &M));
   if (scan_flags & 1u) {  // non-ASCII data under an ascii_only expression

@@ -39,8 +39,10 @@ enum FilterKind : int {
   kMask2 = 2,  // plen 5..7 : one dword + one masked dword
   kTwo = 3,    // plen 8    : two dword compares (exact)
   kLong = 4,   // plen > 8  : two dword compares on the 8-byte filter window (koff), then memory for the rest
-  kClass = 5   // class sequence (xsg_classseq.h): two masked dword compares over the literal bytes of the window,
+  kClass = 5,  // class sequence (xsg_classseq.h): two masked dword compares over the literal bytes of the window,
                // then every position against its 256-bit set (d_pat holds the sets, 32 bytes per position)
+  kDfa = 6     // variable-length expression (xsg_regex.h): k_rx_scan walks every line with a byte-class DFA; d_pat holds
+               // class_of[256], the forward table, the reverse table (uint16 row offsets)
 };
 
 struct PatternDev {
@@ -59,6 +61,13 @@ struct PatternDev {
   uint32_t nalt;            // kClass: alternatives (d_pat holds nalt x plen sets, alternative-major); 0/1 otherwise
   uint32_t ascii_only;      // kClass: the expression is exact on ASCII data only ('.', negated classes): k_scan raises
                             // ScanArgs::flags bit 0 when it meets a byte >= 0x80
+  // kDfa (ascii_only as for kClass; plen = the shortest match; exact_tail = 1)
+  uint32_t rx_ncls;                // byte classes
+  uint32_t rx_fwd_n, rx_rev_n;     // table entries (states x classes) of the forward / reverse automaton
+  uint32_t rx_fwd_start, rx_fwd_acc;  // ROW OFFSETS (state x ncls): start state, first accepting state
+  uint32_t rx_rev_start, rx_rev_acc;
+  uint32_t rx_skip;                // bit 7 of every class_of[] entry flags a TRIGGER byte: one that moves the forward automaton
+                                   // out of its start state, or '\n' (needs ncls <= 128; XSG_RX_SKIP=0 switches it off)
 };
 
 // Per-tile line summaries (XSG_COUNT_LINES): see xsg_linesum.h.
@@ -112,12 +121,17 @@ struct FinishArgs {
   uint32_t want_nl;
   uint32_t want_lines;
   uint32_t want_matches;
+  uint32_t cnt_is_lines;  // kDfa, XSG_COUNT_LINES: tile_cnt holds matching lines, its sum is reported as XSG_CTR_LINES
 };
 
 // ---- launchers (xsg_kernels.hip) --------------------------------------------
 hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s);
 hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s);
 hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s);
+// kDfa (xsg_rx_kernels.hip): same ScanArgs, same per-tile outputs.  count: tile_cnt = matches (or, want_lines, matching
+// lines) of the lines that START in the tile, tile_nl if want_nl; emit: the matches at their ranks.
+hipError_t launch_rx_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s);
+hipError_t launch_rx_emit(const ScanArgs& a, hipStream_t s);
 // "xsg::k_scan<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE>" + the stagger launch_scan would use, for reports
 void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap);
 

@@ -926,6 +926,11 @@ static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, b
 void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap) {
   if (!out || !cap) return;
   const char* b[2] = {"false", "true"};
+  if (a.pat.kind == kDfa) {
+    snprintf(out, cap, "xsg::k_rx_scan<%s, %s> states=%u classes=%u", b[emit], b[emit ? 0 : want_lines],
+             a.pat.rx_ncls ? a.pat.rx_fwd_n / a.pat.rx_ncls : 0u, a.pat.rx_ncls);
+    return;
+  }
   const bool window = a.pat.kind == kTwo || a.pat.kind == kLong || a.pat.kind == kClass;
   snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s, %s> stagger=%u", (int)a.pat.kind, b[emit ? 0 : want_nl],
            b[emit ? 0 : want_lines], b[emit], b[a.pat.icase ? 1 : 0], b[window && a.pat.hot ? 1 : 0],
@@ -948,9 +953,13 @@ static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_line
 }
 
 hipError_t launch_scan_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s) {
+  if (a.pat.kind == kDfa) return launch_rx_count(a, want_nl, want_lines, s);
   return launch_scan(a, want_nl, want_lines, false, s);
 }
-hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s) { return launch_scan(a, false, false, true, s); }
+hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s) {
+  if (a.pat.kind == kDfa) return launch_rx_emit(a, s);
+  return launch_scan(a, false, false, true, s);
+}
 
 // ---------------------------------------------------------------------------
 // k_count_finish: sums the per-tile outputs, replays the reference walk over
@@ -1177,8 +1186,9 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   a2 = block_sum_u64(a2, sh);
   if (threadIdx.x == 0) {
     // an ascii_only expression met non-ASCII data: no number is handed out (all four counters read UINT64_MAX)
-    const bool refuse = A.pat.kind == kClass && A.pat.ascii_only &&
+    const bool refuse = (A.pat.kind == kClass || A.pat.kind == kDfa) && A.pat.ascii_only &&
                         (__hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0;
+    if (A.cnt_is_lines) a1 = a0, a0 = 0;  // k_rx_scan counted matching lines into tile_cnt
     const uint64_t v[XSG_NUM_COUNTERS] = {refuse ? UINT64_MAX : a0, refuse ? UINT64_MAX : a1, refuse ? UINT64_MAX : a2,
                                           refuse ? UINT64_MAX : A.total_bytes};
     for (int k = 0; k < XSG_NUM_COUNTERS; ++k) {
@@ -1493,7 +1503,7 @@ __global__ __launch_bounds__(kBlock) void k_bordered_total(const ListArgs A, uin
 }
 __global__ void k_bordered_seal(const ListArgs A, uint64_t* counters, uint64_t total_bytes, uint32_t* flags) {
   const bool overflow = A.M_dev && *A.M_dev > A.M;
-  const bool refuse = A.pat.kind == kClass && A.pat.ascii_only && (*flags & 1u);
+  const bool refuse = (A.pat.kind == kClass || A.pat.kind == kDfa) && A.pat.ascii_only && (*flags & 1u);
   *flags = 0u;
   if (overflow || refuse) {
     for (int k = 0; k < XSG_NUM_COUNTERS; ++k) counters[k] = UINT64_MAX;

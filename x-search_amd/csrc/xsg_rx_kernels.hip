@@ -1,0 +1,261 @@
+// xsg_rx_kernels.hip -- k_rx_scan: the regex walks of the reference for expressions of variable length
+// (include/xsearch/string_search/search_wrappers.h:63-87 `_regex_byte_offsets`, :250-269 `regex::count`), one LINE
+// per lane.
+//
+// The reference walks a chunk sequentially: RE2::PartialMatch from the current position, report, continue behind
+// the match (or behind the line).  The expressions served here (xsg_regex.h) cannot match '\n', so no match spans
+// two lines and the walk of a chunk is the concatenation of the walks of its lines: lines are independent units,
+// and a tile of 16 KiB of text holds a few hundred of them.  A workgroup stages its tile in LDS (coalesced 16-byte
+// loads, as k_scan reads), every lane takes the lines that START in its 64-byte segment of the tile, and walks each
+// with the two automata RE2 itself would use:
+//   forward  (leftmost-first, an any-byte loop of lowest priority in front): from the current position to the state
+//            going dead (a '\n' kills every state); the last position at which the state held a match is the END of
+//            the leftmost-first match;
+//   reverse  (longest match, anchored at that end): back to the current position; the last position at which the
+//            state held a match is the START.  Only needed where offsets are reported (EMIT).
+// A line that runs past the end of the tile is followed through global memory by the lane that owns its start.
+// Per-tile outputs are those of k_scan (tile_cnt: matches -- or matching lines -- of the lines that start in the
+// tile, nothing stored when there are none; tile_nl on request; emission at tile_off ranks), so the finish kernel
+// and the whole list pipeline behind it are shared.  The automata are tables of pre-multiplied uint16 row offsets
+// in LDS: next = fwd[state + class_of[byte]]; all of it is byte/integer work, LDS-latency-bound, no MFMA.
+#include "xsg_internal.h"
+
+namespace xsg {
+
+constexpr uint32_t kRxTile = kDefaultTileBytes;     // 16 KiB: the tile geometry of the shard's per-tile arrays
+constexpr uint32_t kRxSeg = kRxTile / kBlock;       // 64 bytes of the tile per lane
+// byte p of the tile lives at p + 4 * (p / 64): a lane's segment starts 17 dwords after its neighbour's, so the 64
+// lanes of a wave, each somewhere in its own segment, spread over all LDS banks (64-byte strides would put them on two)
+constexpr uint32_t kRxTileLds = kRxTile + 4 * kBlock;
+__device__ __forceinline__ uint32_t rx_addr(uint32_t p) { return p + ((p >> 6) << 2); }
+
+struct RxCtx {
+  const uint8_t* tile;     // LDS, swizzled (rx_addr)
+  const uint8_t* cls;      // LDS, 256 bytes: class of the byte; bit 7 (if `skip`): the byte is a TRIGGER
+  const unsigned long long* trig;  // LDS, one word per 64-byte segment of the tile: bit i <=> byte i is a trigger
+  uint32_t skip, cmask;    // skip: trigger bits exist; cmask: 0x7f then, else 0xff
+  const uint16_t* fwd;     // LDS
+  const uint16_t* rev;     // global (EMIT only: read for reported matches, not per scanned byte)
+  const uint8_t* cbase;    // the chunk in global memory
+  uint64_t toff;           // chunk-relative offset of the tile
+  uint64_t L;              // chunk length
+  uint32_t fwd_start, fwd_acc, rev_start, rev_acc;
+};
+
+__device__ __forceinline__ uint32_t rx_byte(const RxCtx& X, uint64_t q) {  // q < L
+  const uint64_t rel = q - X.toff;
+  return rel < kRxTile ? X.tile[rx_addr((uint32_t)rel)] : X.cbase[q];
+}
+
+// One line, from its start `cur` (chunk-relative): the reference's walk restricted to the line.  Returns the number
+// of matches (LINES: 1 if there is any).  EMITTING: their start offsets go to m_pos[rank...], rank advances.
+template <bool EMITTING, bool LINES>
+__device__ __forceinline__ uint32_t rx_walk_line(const RxCtx& X, uint64_t cur, const ScanArgs& A, uint32_t chunk,
+                                                 uint64_t& rank) {
+  uint32_t n = 0;
+  for (;;) {
+    uint32_t st = X.fwd_start;
+    uint64_t q = cur, last_end = 0;  // a match ends behind at least one byte: 0 = none yet
+    while (q < X.L) {
+      // In its start state the automaton only waits for a byte that can begin a match: every other byte leaves it
+      // where it is.  Those bytes (and '\n') are the tile's TRIGGERS, found for all 16 KiB at once in the staging
+      // phase; the walk jumps from one to the next on the bit masks instead of stepping through the text.
+      if (X.skip && st == X.fwd_start) {
+        const uint64_t rel = q - X.toff;
+        if (rel < kRxTile) {
+          uint32_t w = (uint32_t)rel >> 6;
+          unsigned long long m = X.trig[w] & (~0ull << ((uint32_t)rel & 63u));
+          while (!m && ++w < (uint32_t)kBlock) m = X.trig[w];
+          q = X.toff + (m ? w * kRxSeg + (uint32_t)__builtin_ctzll(m) : kRxTile);
+          if (q >= X.L) break;
+        }
+      }
+      st = X.fwd[st + (X.cls[rx_byte(X, q)] & X.cmask)];
+      if (st == 0) break;  // dead: the line ended, or nothing can outrank the match already seen
+      ++q;
+      if (st >= X.fwd_acc) {
+        last_end = q;
+        if (LINES) break;  // any match makes the line a matching line
+      }
+    }
+    if (!last_end) break;  // no (further) match in this line
+    ++n;
+    if (LINES) break;
+    if (EMITTING) {
+      uint32_t rs = X.rev_start;
+      uint64_t r = last_end, start = last_end;
+      while (r > cur) {
+        rs = X.rev[rs + (X.cls[rx_byte(X, r - 1)] & X.cmask)];
+        if (rs == 0) break;
+        --r;
+        if (rs >= X.rev_acc) start = r;
+      }
+      if (A.m_cap == 0 || rank < A.m_cap) {  // bounded emission, as k_scan
+        A.m_pos[rank] = start;
+        A.m_chunk[rank] = chunk;
+      }
+      ++rank;
+    }
+    cur = last_end;
+  }
+  return n;
+}
+
+__device__ __forceinline__ uint32_t rx_wave_sum(uint32_t v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += (uint32_t)__shfl_xor((int)v, s);
+  return v;
+}
+
+template <bool EMIT, bool LINES>
+__global__ __launch_bounds__(kBlock) void k_rx_scan(const ScanArgs A, const uint32_t want_nl) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // the forward table
+  __shared__ __attribute__((aligned(16))) uint8_t s_tile[kRxTileLds];
+  __shared__ uint8_t s_cls[256];
+  __shared__ unsigned long long s_trig[kBlock];
+  __shared__ uint32_t s_w[kWaves];
+
+  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+  if (tile >= A.ntiles) return;
+  if (EMIT && A.tile_cnt[tile] == 0) return;
+  const PatternDev P = A.pat;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t c = A.tile_chunk ? A.tile_chunk[tile] : 0u;
+  const ChunkDev ch = A.chunks[c];
+  const uint8_t* cbase = A.base + ch.offset;
+  const uint64_t L = ch.length;
+  const uint64_t Lr = (L + 15u) & ~(uint64_t)15u;
+  const uint64_t toff = (tile - A.chunk_tile0[c]) * (uint64_t)kRxTile;
+
+  // ---- stage: class map, forward table, the tile (bytes at or beyond L read as '\n': every line ends in one)
+  s_cls[tid] = P.d_pat[tid];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.d_pat + 256);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
+    for (uint32_t k = tid; k < (P.rx_fwd_n + 1u) / 2u; k += kBlock) dst[k] = src[k];
+  }
+  uint32_t hi = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = ((uint32_t)j * kBlock + tid) * kUnit;  // tile-relative
+    const uint64_t off = toff + p;
+    uint32_t d[4] = {0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au};
+    if (off < Lr) {
+      const uint4 v = *reinterpret_cast<const uint4*>(cbase + off);
+      d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+      if (off + kUnit > L) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint64_t o = off + 4u * q;
+          const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+          d[q] = (d[q] & keep) | (0x0a0a0a0au & ~keep);
+        }
+      }
+    }
+    hi |= d[0] | d[1] | d[2] | d[3];
+    uint32_t* w = reinterpret_cast<uint32_t*>(s_tile + rx_addr(p));
+    w[0] = d[0], w[1] = d[1], w[2] = d[2], w[3] = d[3];
+  }
+  if (P.ascii_only && __any((hi & 0x80808080u) != 0) && lane == 0) atomicOr(A.flags, 1u);  // the search must refuse
+  __syncthreads();
+
+  // ---- the line starts of this lane's segment: a position is one iff it is < L and follows a '\n' (or opens the chunk)
+  const uint32_t seg = tid * kRxSeg;
+  unsigned long long nlm = 0, tgm = 0;
+  {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(s_tile + rx_addr(seg));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t d = w[k];
+      const uint32_t x = d ^ 0x0a0a0a0au;
+      const uint32_t f = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu) >> 7;  // bit 0, 8, 16, 24 <=> byte is '\n'
+      const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
+      nlm |= (unsigned long long)nib << (4 * k);
+      if (P.rx_skip) {  // the trigger flag of every byte: 64 independent table reads per lane, nothing waits on a state
+        const uint32_t t = ((uint32_t)(s_cls[d & 0xffu] >> 7)) | ((uint32_t)(s_cls[(d >> 8) & 0xffu] >> 7) << 1) |
+                           ((uint32_t)(s_cls[(d >> 16) & 0xffu] >> 7) << 2) | ((uint32_t)(s_cls[d >> 24] >> 7) << 3);
+        tgm |= (unsigned long long)t << (4 * k);
+      }
+    }
+  }
+  if (P.rx_skip) {
+    s_trig[tid] = tgm | nlm;
+    __syncthreads();
+  }
+  const uint64_t seg_off = toff + seg;
+  const uint32_t nvalid = seg_off >= L ? 0u : (L - seg_off >= kRxSeg ? kRxSeg : (uint32_t)(L - seg_off));
+  const unsigned long long valid = nvalid >= 64u ? ~0ull : ((1ull << nvalid) - 1ull);
+  bool prev_nl;
+  if (tid == 0) prev_nl = toff == 0 || cbase[toff - 1] == '\n';
+  else prev_nl = s_tile[rx_addr(seg - 1u)] == '\n';
+  const unsigned long long starts = ((nlm << 1) | (prev_nl ? 1ull : 0ull)) & valid;
+
+  RxCtx X;
+  X.tile = s_tile, X.cls = s_cls, X.fwd = reinterpret_cast<const uint16_t*>(s_dyn);
+  X.trig = s_trig, X.skip = P.rx_skip, X.cmask = P.rx_skip ? 0x7fu : 0xffu;
+  X.rev = reinterpret_cast<const uint16_t*>(P.d_pat + ((256u + 2u * (size_t)P.rx_fwd_n + 15u) & ~(size_t)15u));
+  X.cbase = cbase, X.toff = toff, X.L = L;
+  X.fwd_start = P.rx_fwd_start, X.fwd_acc = P.rx_fwd_acc, X.rev_start = P.rx_rev_start, X.rev_acc = P.rx_rev_acc;
+
+  uint32_t cnt = 0;
+  uint64_t rank = 0;
+  for (unsigned long long m = starts; m; m &= m - 1ull)
+    cnt += rx_walk_line<false, LINES>(X, seg_off + (uint32_t)__builtin_ctzll(m), A, c, rank);
+
+  if (!EMIT) {
+    // as k_scan: tile_cnt is zero at rest and only a wave that found something writes
+    if (__any(cnt != 0)) {
+      const uint32_t wc = rx_wave_sum(cnt);
+      if (lane == 0) atomicAdd(A.tile_cnt + tile, wc);
+    }
+    if (want_nl) {
+      const uint32_t wn = rx_wave_sum((uint32_t)__popcll(nlm & valid));
+      if (lane == 0) s_w[wave] = wn;
+      __syncthreads();
+      if (tid == 0) A.tile_nl[tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    }
+  } else {
+    // ranks: lanes own ascending segments, a lane's lines ascend, a line's matches ascend
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, s);
+      if (lane >= (uint32_t)s) incl += o;
+    }
+    if (lane == 63u) s_w[wave] = incl;
+    __syncthreads();
+    rank = A.tile_off[tile] + (incl - cnt);
+    for (uint32_t w = 0; w < wave; ++w) rank += s_w[w];
+    if (cnt)
+      for (unsigned long long m = starts; m; m &= m - 1ull)
+        (void)rx_walk_line<true, false>(X, seg_off + (uint32_t)__builtin_ctzll(m), A, c, rank);
+  }
+}
+
+static dim3 rx_grid(uint64_t ntiles) {
+  const uint64_t maxx = 1u << 30;
+  if (ntiles <= maxx) return dim3((unsigned)ntiles, 1, 1);
+  return dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx), 1);
+}
+
+static size_t rx_dyn_lds(const ScanArgs& a) { return ((size_t)a.pat.rx_fwd_n * 2u + 15u) & ~(size_t)15u; }
+
+hipError_t launch_rx_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s) {
+  if (a.ntiles == 0) return hipSuccess;
+  if (a.tile_bytes != kRxTile) return hipErrorInvalidValue;
+  const dim3 grid = rx_grid(a.ntiles);
+  if (want_lines)
+    hipLaunchKernelGGL((k_rx_scan<false, true>), grid, dim3(kBlock), rx_dyn_lds(a), s, a, want_nl ? 1u : 0u);
+  else
+    hipLaunchKernelGGL((k_rx_scan<false, false>), grid, dim3(kBlock), rx_dyn_lds(a), s, a, want_nl ? 1u : 0u);
+  return hipGetLastError();
+}
+
+hipError_t launch_rx_emit(const ScanArgs& a, hipStream_t s) {
+  if (a.ntiles == 0) return hipSuccess;
+  if (a.tile_bytes != kRxTile) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_rx_scan<true, false>), rx_grid(a.ntiles), dim3(kBlock), rx_dyn_lds(a), s, a, 0u);
+  return hipGetLastError();
+}
+
+}  // namespace xsg

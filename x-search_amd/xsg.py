@@ -51,6 +51,13 @@ class JobStats(C.Structure):
                 ("seconds_device", C.c_double), ("newlines", C.c_uint64), ("plan_chunks", C.c_uint64)]
 
 
+class RegexDfaInfo(C.Structure):
+    _fields_ = [("ncls", C.c_uint32), ("minlen", C.c_uint32), ("ascii_only", C.c_uint32),
+                ("fwd_states", C.c_uint32), ("fwd_start", C.c_uint32), ("fwd_first_acc", C.c_uint32),
+                ("rev_states", C.c_uint32), ("rev_start", C.c_uint32), ("rev_first_acc", C.c_uint32),
+                ("class_of", C.c_uint8 * 256)]
+
+
 class XsgError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"xsg error {code}: {msg}")
@@ -101,6 +108,7 @@ def load():
         "xsg_set_pattern": (ci, [vp, C.c_char_p, sz, u32]),
         "xsg_regex_check": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32)]),
         "xsg_regex_info": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+        "xsg_regex_dfa_info": (ci, [C.c_char_p, sz, u32, C.POINTER(RegexDfaInfo), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), sz]),
         "xsg_shard_create": (ci, [vp, vp, u64, vp, u64, C.POINTER(vp)]),
         "xsg_shard_rebind": (ci, [vp, vp, u64, vp, u64]),
         "xsg_shard_destroy": (None, [vp]),
@@ -168,7 +176,7 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_host_offsets", "xsg_host_lines", "xsg_scan_kernel_name", "xsg_shard_tune", "xsg_count_begin",
            "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
            "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
-           "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info",
+           "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info", "xsg_regex_dfa_info",
            "xsg_result_u64_view"]
 
 
@@ -194,6 +202,20 @@ def regex_info(expr: bytes, flags: int = 0):
     _check(lib.xsg_regex_info(expr, len(expr), flags, C.byref(n), C.byref(na), C.byref(ao),
                               sets.ctypes.data_as(C.POINTER(C.c_uint32))))
     return int(n.value), int(na.value), bool(ao.value), sets[:n.value * na.value].reshape(na.value, n.value, 8).copy()
+
+
+def regex_dfa(expr: bytes, flags: int = 0):
+    """The automata of a variable-length expression (include/xsg.h: xsg_regex_dfa_info) -> (info, fwd, rev): the
+    tables as uint16 arrays [states, ncls] of pre-multiplied row offsets.  Raises XsgError if the route refuses."""
+    lib = load()
+    info = RegexDfaInfo()
+    cap = 16384
+    fwd = np.zeros(cap, dtype=np.uint16)
+    rev = np.zeros(cap, dtype=np.uint16)
+    _check(lib.xsg_regex_dfa_info(expr, len(expr), flags, C.byref(info), fwd.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                  rev.ctypes.data_as(C.POINTER(C.c_uint16)), cap))
+    return (info, fwd[:info.fwd_states * info.ncls].reshape(info.fwd_states, info.ncls).copy(),
+            rev[:info.rev_states * info.ncls].reshape(info.rev_states, info.ncls).copy())
 
 
 def device_count() -> int:
