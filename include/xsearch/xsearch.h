@@ -154,8 +154,9 @@ inline uint64_t count_chunks(const std::string& file_path, const char* meta, uin
 
 // The reference decides per pattern whether it is a regular expression: it is one
 // iff the pattern, read as a regex, does not match itself (utils/utils.h:17-25; an
-// invalid regex counts as plain text).  Such a pattern goes to the kernel's class-sequence
-// matcher when that can decide it (xsg_regex_check) and is refused loudly otherwise, never
+// invalid regex counts as plain text).  Such a pattern goes to the GPU matchers -- the scan
+// kernel's class-sequence matcher, or the automaton route for expressions of variable length --
+// when one of them can decide it (xsg_regex_check) and is refused loudly otherwise, never
 // searched as a literal with different results.  XS_FORCE_LITERAL=1 overrides.
 inline bool reference_routes_to_regex(const std::string& pattern) {
   try {

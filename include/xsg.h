@@ -95,10 +95,21 @@ enum xsg_mode {
  * any ASCII byte but '\n'); RE2 matches whole code points there, so a search with
  * such an expression REFUSES data that holds a byte >= 0x80 (XSG_ENOTSUP from the
  * search call; xsg_count_async hands out UINT64_MAX in all four counters) rather
- * than decide it differently.  Everything of variable length (* + ? {n,m}), anchors
- * and (?flags) return XSG_ENOTSUP from xsg_set_pattern: refused, never
- * approximated.  No tail quirk applies (RE2 is exact); XSG_FLAG_IGNORE_CASE folds
- * ASCII letters in the data and in every class, as for literals. */
+ * than decide it differently.
+ * Expressions of VARIABLE length -- x* x+ x? x{n,} x{n,m}, the lazy forms, alternatives
+ * of different lengths, more than 32 positions or 8 alternatives -- take a second
+ * route: a forward leftmost-first DFA and a reverse longest-match DFA (what RE2
+ * itself runs for such a search), compiled on the host, and a kernel that walks every
+ * line of the shard with them, one line per lane (csrc/xsg_regex.h,
+ * csrc/xsg_rx_kernels.hip).  All six tags; same refusal of non-ASCII data for '.'
+ * and negated classes.  An expression of this kind whose sets accept '\n' (\s+,
+ * [^,]*) can match across lines: it is walked chunk by chunk, one lane per chunk
+ * (slow), and serves XSG_COUNT_MATCHES / XSG_MATCH_BYTE_OFFSETS only.  Refused on
+ * this route (XSG_ENOTSUP from xsg_set_pattern, never approximated): expressions
+ * that can match the empty string, automata over 16384 table entries.  Refused on both routes: anchors ^ $ \b \A \z, (?flags), \p, \C.
+ * No tail quirk applies (RE2 is exact); XSG_FLAG_IGNORE_CASE folds ASCII letters in
+ * the data and in every class, as for literals (automaton route: the classes are
+ * closed under case instead, the same thing). */
 #define XSG_FLAG_REGEX 0x4u
 
 #define XSG_MAX_PATTERN 1024u
@@ -140,7 +151,7 @@ int xsg_device_count(int* count);
 int xsg_ctx_create(int device, xsg_ctx** out);
 void xsg_ctx_destroy(xsg_ctx* ctx);
 /* Literal pattern, 1..XSG_MAX_PATTERN bytes, any byte values (or, with
- * XSG_FLAG_REGEX, a class-sequence expression).  Patterns that can match a
+ * XSG_FLAG_REGEX, a regular expression of the families above).  Patterns that can match a
  * '\n' are accepted for XSG_COUNT_MATCHES / XSG_MATCH_BYTE_OFFSETS only (the
  * line modes return XSG_ENOTSUP for them). */
 int xsg_set_pattern(xsg_ctx* ctx, const void* pattern, size_t plen, uint32_t flags);
@@ -158,8 +169,8 @@ int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32_t* positio
                    uint32_t* ascii_only, uint32_t* sets);
 /* Expressions of VARIABLE length (x* x+ x? x{n,m}, lazy forms, alternatives of different lengths) are served by a
  * second route: the library compiles them into a forward (leftmost-first) and a reverse (longest) byte-class DFA
- * and k_rx_scan walks every line with them (csrc/xsg_regex.h; restrictions there: no empty matches, no set that
- * accepts '\n', no anchors).  xsg_regex_check / xsg_regex_info return XSG_OK with *positions == 0 for such an
+ * and k_rx_scan walks every line with them (csrc/xsg_regex.h; restrictions there: no empty matches, no anchors; an
+ * expression with a set that accepts '\n' is walked chunk by chunk instead and serves the match tags only).  xsg_regex_check / xsg_regex_info return XSG_OK with *positions == 0 for such an
  * expression.  This call hands out the automata (for inspection and for the host-side tests, which drive the tables
  * against another regex engine without a GPU): `info` always; `fwd` / `rev` (row-major, states x ncls entries, each
  * the NEXT STATE'S ROW OFFSET = state * ncls; state 0 is dead, states >= *_first_acc hold a match) if they have room
@@ -167,6 +178,7 @@ int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32_t* positio
  * fixed-length one that xsg_regex_info describes). */
 typedef struct xsg_regex_dfa {
   uint32_t ncls, minlen, ascii_only;
+  uint32_t multiline; /* a set accepts '\n': matches may span lines; the match tags only, one lane per chunk */
   uint32_t fwd_states, fwd_start, fwd_first_acc;
   uint32_t rev_states, rev_start, rev_first_acc;
   uint8_t class_of[256];

@@ -435,8 +435,8 @@ class _TreeReader(_RegexReader):
 
 class RegexProgram:
     """A variable-length expression as the oracle searches it: `.re` (compiled CPython pattern over explicit byte
-    classes), `.ascii_only`, `.minlen`.  Raises UnsupportedRegex for what the product refuses too: expressions that
-    can match the empty string or a newline, anchors, flags."""
+    classes), `.ascii_only`, `.minlen`, `.multiline`.  Raises UnsupportedRegex for what the product refuses too:
+    expressions that can match the empty string, anchors, flags."""
 
     def __init__(self, expr: bytes, ignore_case: bool = False):
         import re as _re
@@ -448,8 +448,9 @@ class RegexProgram:
             raise UnsupportedRegex("unmatched )" if rd.peek() == ord(")") else "trailing garbage")
         if mn == 0:
             raise UnsupportedRegex("the expression can match the empty string")
-        if any(10 in st for st in rd.sets):
-            raise UnsupportedRegex("a set of the expression accepts a newline")
+        # a set that accepts '\n' lets a match span lines: the match walks only (the line walks are refused, as for a
+        # literal pattern that contains '\n')
+        self.multiline = any(10 in st for st in rd.sets)
         self.source = src
         self.re = _re.compile(src, _re.DOTALL)
         self.ascii_only = rd.ascii_only

@@ -6,7 +6,7 @@ set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$REPO/gpurun_out
 TAG=${1:-r02}; shift
-CASES=${*:-count_nl_Sherlock lines_e icase_that long_detective_street class_She_r_lock class_The_az3 mask1_e}
+CASES=${*:-count_nl_Sherlock lines_e icase_that long_detective_street class_She_r_lock class_The_az3 mask1_e rx_none rx_alt rx_dotstar rx_word}
 mkdir -p $OUT/variants_$TAG
 cd $REPO
 timeout -k 10 600 python scripts/variant_profile.py --case all --gib 50 > $OUT/variants_$TAG/sweep.jsonl 2> $OUT/variants_$TAG/sweep.err || { echo "sweep failed"; tail -5 $OUT/variants_$TAG/sweep.err; exit 1; }

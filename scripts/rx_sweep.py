@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--out", type=str, default=str(ROOT / "gpurun_out" / "rx_sweep.jsonl"))
     ap.add_argument("--exprs", type=str, default="")
+    ap.add_argument("--cases", type=str, default="rx", help="rx: the automaton route; class: class sequences in k_scan")
     a = ap.parse_args()
     import torch
     import corpus
@@ -56,6 +57,9 @@ def main():
         "Sherlock|Holmes", "Sher.*mes", "Sher.*?k", "colou?r", "lock(ed|s)?", "[A-Z][a-z]+ [A-Z][a-z]+", "\\w+ing",
         "[0-9]+", "(the|The) +\\w{5,}", "S[a-z]{3,9}k", "zzz+"]
     cases = [("Sherlock", 0), ("She[r ]lock", xsg.FLAG_REGEX)] + [(e, xsg.FLAG_REGEX) for e in exprs]
+    if a.cases == "class":
+        cases = [(e, xsg.FLAG_REGEX) for e in ("She[r ]lock", "[Ss]herlock", "[Tt]he [a-z]{3} ", "[0-9]{4}-[0-9]{2}",
+                                               "Sherlock|She lock", "S.erlock")]
     for expr, flags in cases:
         ctx.set_pattern(expr.encode(), flags)
         for mode, name in ((xsg.COUNT_MATCHES, "count"), (xsg.COUNT_LINES, "count_lines")):

@@ -32,6 +32,14 @@ CASES = {
     "class_Ss_herlock": ("[Ss]herlock", "regex", "count"),
     "class_digits": ("[0-9]{4}-[0-9]{2}", "regex", "count"),
     "class_The_az3": ("[Tt]he [a-z]{3} ", "regex", "count"),
+    # the automaton route (k_rx_scan): no trigger in the text, rare triggers, a match in most lines, a trigger at
+    # every word (no skipping), and the matching-lines count
+    "rx_none": ("zzz+", "regex", "count"),
+    "rx_alt": ("Sherlock|Holmes", "regex", "count"),
+    "rx_dotstar": ("Sher.*mes", "regex", "count"),
+    "rx_optional": ("lock(ed|s)?", "regex", "count"),
+    "rx_word": ("\\w+ing", "regex", "count"),
+    "rx_lines_alt": ("Sherlock|Holmes", "regex", "count_lines"),
 }
 
 

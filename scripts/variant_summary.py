@@ -40,17 +40,17 @@ for d in sorted(p for p in root.iterdir() if p.is_dir()):
                 j = json.loads(l)
                 line["bytes"] = j["bytes"]
                 line["hip_event_ms"] = j["ms"]
-                want = j["kernel"].split(" stagger")[0]
+                want = j["kernel"].split(" stagger")[0].split(" states")[0]
                 line["kernel"] = j["kernel"]
     if want is None:
         continue
-    full = "void " + want + "(xsg::ScanArgs)"
+    full = "void " + want + "("  # k_scan(ScanArgs), k_rx_scan(ScanArgs, unsigned int)
     def newest(pattern):  # gpurun_out/ is merged across calls: an older run's files may still lie next to the new ones
         fs = glob.glob(pattern)
         return [max(fs, key=os.path.getmtime)] if fs else []
     for f in newest(str(d / "stats" / "*" / "*kernel_trace.csv")):
         durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])) for r in csv.DictReader(open(f))
-                if r["Kernel_Name"] == full]
+                if r["Kernel_Name"].startswith(full)]
         if durs:
             g = max(x[1] for x in durs)
             ds = [x[0] for x in durs if x[1] == g]  # full-shard launches only
@@ -59,7 +59,7 @@ for d in sorted(p for p in root.iterdir() if p.is_dir()):
             line["min_ms"] = round(min(ds) / 1e6, 4)
     acc = defaultdict(list)
     for f in newest(str(d / "sq" / "*" / "*counter_collection.csv")):
-        rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == full]
+        rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(full)]
         if rows:
             g = max(int(r["Grid_Size"]) for r in rows)
             for r in rows:
@@ -74,7 +74,7 @@ for d in sorted(p for p in root.iterdir() if p.is_dir()):
             line["wait_share"] = round(sum(acc["SQ_WAIT_ANY"]) / sum(acc["SQ_WAVE_CYCLES"]), 3)
     fs = []
     for f in newest(str(d / "fetch" / "*" / "*counter_collection.csv")):
-        rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == full and r["Counter_Name"] == "FETCH_SIZE"]
+        rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(full) and r["Counter_Name"] == "FETCH_SIZE"]
         if rows:
             g = max(int(r["Grid_Size"]) for r in rows)
             fs += [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == g]

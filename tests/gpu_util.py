@@ -122,7 +122,8 @@ def oracle_regex_all_modes(oracle, blocks, expr: bytes, ignore_case=False, globa
         cs = compile_class_sequence(expr, ignore_case)
     except UnsupportedRegex:
         # not a class sequence: the variable-length family (the product's automaton route); raises if that refuses too
-        return oracle_rx_all_modes(oracle, blocks, RegexProgram(expr, ignore_case), global_offsets, line_bases), True
+        prog = RegexProgram(expr, ignore_case)
+        return oracle_rx_all_modes(oracle, blocks, prog, global_offsets, line_bases), not prog.multiline
     orig_blocks = blocks
     if ignore_case:
         blocks = [oracle.lower(b) for b in blocks]
@@ -163,15 +164,20 @@ def oracle_rx_all_modes(oracle, blocks, prog, global_offsets=None, line_bases=No
         m = oracle.rx_byte_offsets(b, prog, False)
         out["count_matches"] += int(m.size)
         out["match_byte_offsets"] += [int(x) + g for x in m]
+        nl = oracle.count_newlines(b)
+        out["newlines"] += nl
+        out["bytes"] += int(b.size)
+        goff += int(b.size)
+        nl_before += nl
+        if prog.multiline:
+            continue
         out["count_lines"] += oracle.rx_count(b, prog, True)
         out["line_byte_offsets"] += [int(x) + g for x in oracle.rx_byte_offsets(b, prog, True, True)]
         out["line_indices"] += [int(x) for x in oracle.rx_line_indices(b, prog, lb)]
         beg, ln = oracle.rx_lines_spans(b, prog)
         out["lines"] += [b[int(s):int(s + l)].tobytes() for s, l in zip(beg, ln)]
         out["lines_offsets"] += [int(s) + g for s in beg]
-        nl = oracle.count_newlines(b)
-        out["newlines"] += nl
-        out["bytes"] += int(b.size)
-        goff += int(b.size)
-        nl_before += nl
+    if prog.multiline:
+        for k in ("count_lines", "line_byte_offsets", "line_indices", "lines", "lines_offsets"):
+            out.pop(k)
     return out

@@ -254,15 +254,17 @@ def test_xsgrep_equals_gnu_grep(tmp_path):
         gc = subprocess.run([str(exe), "-c", *args, str(p)], capture_output=True, env=env, timeout=120).stdout
         assert gc == wc, args
     # regular expressions of the class-sequence family: grep reads them as basic regexes the same way
-    for args in (["She[r ]lock"], ["-i", "she[r ]lock"], ["[Hh]olmes[ ,.]"], ["[0-9][0-9]*"]):
+    # ... and of the variable-length family (the automaton route), which grep -E reads the same way
+    for args in (["She[r ]lock"], ["-i", "she[r ]lock"], ["[Hh]olmes[ ,.]"], ["^She"], ["Sher.*mes"], ["lock(ed|s)? "],
+                 ["-i", "holmes +[a-z]+ed"], ["[A-Z][a-z]+ [A-Z][a-z]+"]):
         got = subprocess.run([str(exe), "-j", "2", *args, str(p)], capture_output=True, env=env, timeout=120)
-        if args == ["[0-9][0-9]*"]:  # not fixed-length: refused, not searched as text
+        if args == ["^She"]:  # an anchor: refused, not searched as text
             assert got.returncode == 1 and b"does not serve" in got.stderr
             continue
-        want = subprocess.run(["grep", *args, str(p)], capture_output=True, env=env).stdout
+        want = subprocess.run(["grep", "-E", *args, str(p)], capture_output=True, env=env).stdout
         assert got.returncode == 0, got.stderr.decode()
         assert got.stdout == want and len(want) > 0, args
-        wc = subprocess.run(["grep", "-c", *args, str(p)], capture_output=True, env=env).stdout
+        wc = subprocess.run(["grep", "-E", "-c", *args, str(p)], capture_output=True, env=env).stdout
         gc = subprocess.run([str(exe), "-c", *args, str(p)], capture_output=True, env=env, timeout=120).stdout
         assert gc == wc, args
 
@@ -374,7 +376,8 @@ def test_concurrent_jobs_and_early_destroy(files):
 def test_regex_routing_of_extern_search(files, oracle):
     """'She[r ]lock' is a regex for the reference (utils/utils.h:17-25; 53 matches in its goldens,
     xsearchTest.cpp:19): xs::extern_search serves it through the kernel's class-sequence matcher, for every
-    tag, with and without ignore_case; a regex outside that family is refused loudly, never searched as text."""
+    tag, with and without ignore_case; expressions of variable length through the automaton route; a regex outside
+    both families is refused loudly, never searched as text."""
     from gpu_util import oracle_regex_all_modes
     data = np.fromfile(files["txt"], dtype=np.uint8)
     plan = xsg.plan_chunks(files["txt"], CHUNK)
@@ -394,7 +397,27 @@ def test_regex_routing_of_extern_search(files, oracle):
                 assert [int(x) for x in r.stdout.split()] == want[KEY[tag]], (tag, icase)
     r = run_cli("count", "join", "She[r ]lock", files["txt"], env={"XS_FORCE_LITERAL": "1"})
     assert r.returncode == 0 and int(r.stdout) == 0
-    for expr in ("Sherlock|Holmes", "Sher?lock", "^Sherlock", "She[^r]+lock"):
+    # expressions of variable length take the automaton route (k_rx_scan), every tag
+    for expr in ("Sherlock|Holmes", "Sher?lock", "Sher.*?k +[a-z]+"):
+        want, _ = oracle_regex_all_modes(oracle, chunks, expr.encode(), False)
+        assert want["count_matches"] > 0
+        for tag in TAGS:
+            r = run_cli(tag, "join", expr, files["txt"])
+            assert r.returncode == 0, r.stderr
+            if tag in ("count", "count_lines"):
+                assert int(r.stdout) == want[KEY[tag]], (expr, tag)
+            elif tag == "lines":
+                assert r.stdout.split(b"\n")[:-1] == want["lines"], expr
+            else:
+                assert [int(x) for x in r.stdout.split()] == want[KEY[tag]], (expr, tag)
+    # a set that accepts '\n' under a repetition: matches may span lines -- the match tags are served, the line tags refuse
+    want, with_lines = oracle_regex_all_modes(oracle, chunks, b"She[^r]+lock", False)
+    assert not with_lines
+    r = run_cli("count", "join", "She[^r]+lock", files["txt"])
+    assert r.returncode == 0 and int(r.stdout) == want["count_matches"], r.stderr
+    r = run_cli("count_lines", "join", "She[^r]+lock", files["txt"])
+    assert r.returncode == 1 and b"\\n" in r.stderr, r.stderr
+    for expr in ("^Sherlock", "Sher\\b", "(Sher)*"):
         r = run_cli("count", "join", expr, files["txt"])
         assert r.returncode == 1 and b"regular expression" in r.stderr and b"does not serve" in r.stderr, (expr, r.stderr)
     for expr in ("a.b", "She.*lock"):  # these match themselves as regexes -> plain text for the reference too

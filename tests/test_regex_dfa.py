@@ -17,8 +17,9 @@ VARIABLE = [b"ab+", b"colou?r", b"x{2,3}", b"x{2,}", b"ab|c", b"(a|bc)d", b"(ab|
             b"[a-z]+ing", b"(foo|ba+r)+x", b"a{2,4}?b", b"\\d+\\.\\d*", b"[A-Z][a-z]+ [A-Z][a-z]+", b"(ab)*c", b"(ab)?c",
             b"a(b|cd){1,3}e", b"x+?y", b"caf\xc3\xa9+", b"[[:alpha:]]+[[:digit:]]", b"\\w+@\\w+\\.com", b"a.{0,5}b",
             b"(a|ab)(c|bcd)", b"(a+)(b+)?c", b"z{3,}"]
+MULTILINE = [b"\\s+x", b"[^a]+b", b"a\\nb+", b"x\\s*y", b"[^a-z ]{2,}", b"(a|\\n)+b"]  # a set accepts '\n': chunk-sequential route
 REFUSED = [b"a*", b"(ab)*", b"(ab)?", b"a?b?", b"^ab+", b"ab+$", b"\\bab+", b"(?i)ab+", b"(a*)+b", b"(a?){2}b", b"a**", b"a+*",
-           b"a{2}{3}", b"x{3,2}", b"x{,3}y+", b"a+\\", b"[ab", b"(ab+", b"ab+)", b"a||b+", b"|a+", b"\\s+x", b"[^a]+b", b"a\\nb+",
+           b"a{2}{3}", b"x{3,2}", b"x{,3}y+", b"a+\\", b"[ab", b"(ab+", b"ab+)", b"a||b+", b"|a+",
            b"x{1001}y+", b"a{0}b+", b"\\pL+"]
 
 
@@ -53,6 +54,8 @@ def dfa_line_matches(info, fwd, rev, d: bytes, lo: int, hi: int):
 
 
 def dfa_matches(info, fwd, rev, d: bytes):
+    if info.multiline:  # k_rx_chunk: the chunk is one unit
+        return dfa_line_matches(info, fwd, rev, d, 0, len(d))
     out, lo = [], 0
     while lo < len(d):
         nl = d.find(b"\n", lo)
@@ -80,9 +83,23 @@ def test_variable_length_expressions_are_served_by_the_automaton_route(expr):
         assert n == 0  # "variable length"
         info, fwd, rev = xsg.regex_dfa(expr, flags)
         prog = RegexProgram(expr, icase)
-        assert info.minlen == prog.minlen and bool(info.ascii_only) == prog.ascii_only
+        assert info.minlen == prog.minlen and bool(info.ascii_only) == prog.ascii_only and not info.multiline
         assert info.class_of[10] not in [info.class_of[b] for b in range(256) if b != 10]  # '\n' has its own class
         assert not fwd[:, info.class_of[10]].any() and not rev[:, info.class_of[10]].any()  # ... and kills every state
+
+
+@pytest.mark.parametrize("expr", MULTILINE)
+def test_expressions_that_can_match_a_newline_take_the_chunk_route(expr):
+    rng = np.random.default_rng(len(expr))
+    alphabet = np.frombuffer(b"aabbxy \n\n,Z", dtype=np.uint8)
+    for icase in (False, True):
+        flags = xsg.FLAG_IGNORE_CASE if icase else 0
+        info, fwd, rev = xsg.regex_dfa(expr, flags)
+        prog = RegexProgram(expr, icase)
+        assert info.multiline and prog.multiline
+        for _ in range(20):
+            data = alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 400)))].tobytes()
+            assert dfa_matches(info, fwd, rev, data) == oracle_matches(prog, data), (expr, icase, data)
 
 
 @pytest.mark.parametrize("expr", REFUSED)
@@ -107,7 +124,7 @@ def rand_var_expr(rng, depth=0):
         if k == 5:
             return b"[" + bytes(b"abcxyz"[int(i)] for i in rng.integers(0, 6, size=int(rng.integers(1, 4)))) + b"]"
         if k == 6:
-            return [b"\\d", b"\\w", b"[a-c]", b"[^a\\n]", b"[^ab\\n]", b"\\S"][int(rng.integers(0, 6))]
+            return [b"\\d", b"\\w", b"[a-c]", b"[^a\\n]", b"[^ab\\n]", b"\\S", b"\\s", b"[^ab]"][int(rng.integers(0, 8))]
         if k == 7 and depth < 1:
             return b"(" + rand_var_expr(rng, depth + 1) + b")"
         if k == 8 and depth < 1:
@@ -118,6 +135,8 @@ def rand_var_expr(rng, depth=0):
         a = atom()
         k = int(rng.integers(0, 12))
         q = [b"", b"", b"", b"", b"", b"*", b"+", b"?", b"{2}", b"{1,3}", b"{2,}", b"{0,2}"][k]
+        if q in (b"*", b"+", b"{2,}") and (b"*" in a or b"+" in a or b",}" in a):
+            q = b"{1,3}"  # an unbounded loop around an unbounded loop: exponential for the ORACLE's backtracking engine
         if q and rng.random() < 0.25:
             q += b"?"
         return a + q

@@ -1031,6 +1031,11 @@ static int job_start_impl(const void* pattern, size_t plen, const char* file_pat
     XSG_TRY(xsg_regex_check(pattern, plen, opts->pattern_flags & XSG_FLAG_IGNORE_CASE, &npos, sets.data()));
     for (uint32_t k = 0; line_mode && k < npos; ++k)
       if (sets[8 * k] & (1u << '\n')) return fail(XSG_ENOTSUP, "line modes do not accept a pattern that can match '\\n'");
+    if (line_mode && npos == 0) {  // the automaton route: does a set of the expression accept '\n'?
+      xsg_regex_dfa info;
+      XSG_TRY(xsg_regex_dfa_info(pattern, plen, opts->pattern_flags & XSG_FLAG_IGNORE_CASE, &info, nullptr, nullptr, 0));
+      if (info.multiline) return fail(XSG_ENOTSUP, "line modes do not accept a pattern that can match '\\n'");
+    }
   } else if (line_mode && memchr(pattern, '\n', plen) != nullptr) {
     return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
   }

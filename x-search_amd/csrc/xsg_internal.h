@@ -41,6 +41,8 @@ enum FilterKind : int {
   kLong = 4,   // plen > 8  : two dword compares on the 8-byte filter window (koff), then memory for the rest
   kClass = 5,  // class sequence (xsg_classseq.h): two masked dword compares over the literal bytes of the window,
                // then every position against its 256-bit set (d_pat holds the sets, 32 bytes per position)
+  kClassFast = 7,  // instantiation only (PatternDev::kind stays kClass): a class sequence whose window takes the exact
+                   // 16 + 32 bit compare (PatternDev::cls_fast), window filter
   kDfa = 6     // variable-length expression (xsg_regex.h): k_rx_scan walks every line with a byte-class DFA; d_pat holds
                // class_of[256], the forward table, the reverse table (uint16 row offsets)
 };
@@ -58,6 +60,7 @@ struct PatternDev {
   uint32_t lazy_exact;      // ignore_case: every byte of the filter window is a letter, so the hot filter on (data | 0x20) IS the
                             // exact folded compare and its results stand (no second, properly folded pass over the window)
   uint32_t hot;             // window kinds (kTwo, kLong, kClass): 1 = aligned-dword trigger, 0 = window filter (k_scan<..., ALIGNED>)
+  uint32_t cls_fast;        // kClass: m1 is all ones and the low half of m0 too: the window filter compares 16 + 32 exact bits
   uint32_t nalt;            // kClass: alternatives (d_pat holds nalt x plen sets, alternative-major); 0/1 otherwise
   uint32_t ascii_only;      // kClass: the expression is exact on ASCII data only ('.', negated classes): k_scan raises
                             // ScanArgs::flags bit 0 when it meets a byte >= 0x80
@@ -66,6 +69,7 @@ struct PatternDev {
   uint32_t rx_fwd_n, rx_rev_n;     // table entries (states x classes) of the forward / reverse automaton
   uint32_t rx_fwd_start, rx_fwd_acc;  // ROW OFFSETS (state x ncls): start state, first accepting state
   uint32_t rx_rev_start, rx_rev_acc;
+  uint32_t rx_multiline;           // a set of the expression accepts '\n': the chunk, not the line, is the unit (k_rx_chunk)
   uint32_t rx_skip;                // bit 7 of every class_of[] entry flags a TRIGGER byte: one that moves the forward automaton
                                    // out of its start state, or '\n' (needs ncls <= 128; XSG_RX_SKIP=0 switches it off)
 };
@@ -78,6 +82,7 @@ struct ScanArgs {
   const uint32_t* tile_chunk;   // tile -> chunk (null when the shard has one chunk)
   const uint64_t* chunk_tile0;  // first tile of every chunk (nchunks + 1 entries)
   uint64_t ntiles;
+  uint64_t nchunks;             // entries of `chunks` (k_rx_chunk: one lane per chunk)
   uint32_t tile_bytes;          // 16384 (selects the k_scan instantiation)
   uint32_t tune;                // bits 0-7: wave stagger in units of s_sleep(1) = 64 clocks; kTuneAuto = per variant (XSG_TUNE overrides)
   uint32_t epoch;               // 1..0xffff: tag of this pass in the upper half of the tile_last words

@@ -30,6 +30,8 @@ namespace xsg {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+__host__ __device__ constexpr bool is_cls(int kind) { return kind == kClass || kind == kClassFast; }
+
 // ---------------------------------------------------------------------------
 // cross-lane helpers (wave64)
 // ---------------------------------------------------------------------------
@@ -315,7 +317,7 @@ __device__ __forceinline__ void windows(const uint32_t (&d)[8], uint32_t (&w)[N]
 template <int KIND>
 __device__ __forceinline__ bool cand_at(const uint32_t (&w)[20], int b, const PatternDev& P) {
   if (KIND == kMask1) return (w[b] & P.m0) == P.p0;
-  if (KIND == kClass) return ((w[b] & P.m0) == P.p0) & ((w[b + 4] & P.m1) == P.p1);
+  if (is_cls(KIND)) return ((w[b] & P.m0) == P.p0) & ((w[b + 4] & P.m1) == P.p1);
   if (KIND == kOne) return w[b] == P.p0;
   if (KIND == kMask2) return (w[b] == P.p0) & ((w[b + 4] & P.m1) == P.p1);
   return (w[b] == P.p0) & (w[b + 4] == P.p1);
@@ -348,7 +350,7 @@ __device__ __forceinline__ bool trigger_aligned(const uint32_t (&d)[8], const Pa
   const uint64_t w = ((uint64_t)P.p1 << 32) | P.p0;
   const uint32_t a1 = (uint32_t)(w >> 8), a2 = (uint32_t)(w >> 16), a3 = (uint32_t)(w >> 24);
   bool t = false;
-  if (KIND == kClass) {  // masked: a position of the window pins only the bits its set agrees on
+  if (is_cls(KIND)) {  // masked: a position of the window pins only the bits its set agrees on
     const uint64_t mw = ((uint64_t)P.m1 << 32) | P.m0;
     const uint32_t m1 = (uint32_t)(mw >> 8), m2 = (uint32_t)(mw >> 16), m3 = (uint32_t)(mw >> 24);
 #pragma unroll
@@ -417,7 +419,7 @@ __device__ __forceinline__ uint32_t match_mask16_from(uint32_t m, const uint32_t
       if (diff) m &= ~(1u << b);
     }
   }
-  if (KIND == kClass) {
+  if (is_cls(KIND)) {
     // The window compare saw only the bits the members of each set agree on: now every position of the candidate
     // against its 256-bit set in LDS (8 dwords per position).  A candidate whose bytes all lie in the lane's
     // 32-byte view (own unit + the next one, d[0..8)) is decided without touching memory and without an early
@@ -540,7 +542,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
   d[4] = from_next_lane(own0, e0, lane);
   d[5] = from_next_lane(own1, e1, lane);
   const uint32_t(&nlsrc)[8] = LAZY ? r : d;  // own bytes as the newline tests must see them
-  if (KIND == kClass) {
+  if (is_cls(KIND)) {
     if (P.ascii_only) st.hi |= r[0] | r[1] | r[2] | r[3];  // own bytes (beyond the chunk end: cleared); folding keeps bit 7
   }
 
@@ -611,16 +613,42 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
     // rare in the text.  Otherwise the window filter proper (20 unaligned windows x 2 compares).  Which one runs
     // is decided per shard and pattern by measurement (xsg_api.cpp: choose_hot_filter); running both as a cascade
     // was measured slower than either (the straight-line body outgrows the instruction cache).
-    constexpr bool kTrigger = ALIGNED && (KIND == kTwo || KIND == kLong || KIND == kClass);
+    constexpr bool kTrigger = ALIGNED && (KIND == kTwo || KIND == kLong || KIND == kClass);  // (kClassFast: never ALIGNED)
     // The window filter's 16 compare results are kept (as lane masks on the scalar side) and become the candidate
     // bits of the slow path: a needle that is in most wave-loads (`that`) used to build its windows and compare them
     // twice.  Not under LAZY (the slow path compares properly folded bytes) nor behind the aligned trigger (which
     // has no per-position results).
     constexpr bool kReuse = !kTrigger && !LAZY;
+    // (Round 2 also tried the class sequences' masked compares in two stages with a wave-wide exit in between -- the
+    // high dword of the window for all 16 positions, the low dword only if some lane passed -- to save the second
+    // 32 operations in wave-loads that hold no piece of the window: slower everywhere on the bench corpus, `She[r ]lock`
+    // 2.77 against 3.87 TB/s, `[Ss]herlock` 3.4 against 5.6 on the same box -- as with the trigger cascade, straight-
+    // line code beats a cheaper expected path with a ballot and a branch in it.  Removed.)
     bool cb[16];
     bool any_c;
+    unsigned long long cmk[16];        // cls_fast: the filter's results as lane masks
+    unsigned long long fast_any = 0;   // ... and their OR
     if (kTrigger) {
       any_c = trigger_aligned<KIND>(d, Pf);
+    } else if (KIND == kClassFast) {
+      // A class sequence whose window pins its upper four positions and its first two completely (`She[r ]lock`:
+      // "Sh", then a position and a class, then "lock"): the filter drops the two positions in between -- a superset,
+      // every candidate is verified against all sets anyway -- and becomes two EXACT compares per position, a 16-bit
+      // and a 32-bit one, no `and`: 47 operations per 16 bytes like a literal of 8 bytes, instead of 79.  The
+      // compiler widens a 16-bit equality to and + compare, so the compare is spelled out; its results are lane
+      // masks in scalar registers and stay there (combined on the scalar unit) until a wave-load enters the slow path.
+      uint32_t w[20];
+      windows<20>(d, w);
+      fast_any = 0;
+      const uint32_t lo16 = Pf.p0 & 0xffffu;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        unsigned long long a16;
+        asm("v_cmp_eq_u16_e64 %0, %1, %2" : "=s"(a16) : "v"(w[b]), "s"(lo16));
+        cmk[b] = a16 & __builtin_amdgcn_uicmp(w[b + 4], Pf.p1, 32 /* eq */);
+        fast_any |= cmk[b];
+      }
+      any_c = false;
     } else {
       uint32_t w[20];
       windows<20>(d, w);
@@ -631,17 +659,17 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         any_c |= cb[b];
       }
     }
-    if (__ballot(any_c) != 0) {
+    if (KIND == kClassFast ? fast_any != 0 : __ballot(any_c) != 0) {
       // ignore_case with a window of letters only: the hot filter's verdict on (data | 0x20) is already the exact
       // one (PatternDev::lazy_exact) -- no refold, and its compare results stand like those of a case-sensitive search
-      const bool lazy_done = LAZY && !kTrigger && KIND != kClass && P.lazy_exact;
+      const bool lazy_done = LAZY && !kTrigger && !is_cls(KIND) && P.lazy_exact;
       if (LAZY && !lazy_done) {  // now the exact view: properly folded bytes, own and neighbour's
         const uint32_t f0 = fold4(cur.x), f1 = fold4(cur.y);
         d[0] = fold4(r[0]), d[1] = fold4(r[1]), d[2] = fold4(r[2]), d[3] = fold4(r[3]);  // r is already cleared
         d[4] = from_next_lane(f0, fold4(e0r), lane);
         d[5] = from_next_lane(f1, fold4(e1r), lane);
       }
-      if (KIND == kClass) {
+      if (is_cls(KIND)) {
         // class sequences verify their candidates in the lane's view: the rest of the neighbour's unit joins it
         // (raw own bytes go out -- a lane's own view of them may be cleared at the chunk end, the reader's not)
         const uint32_t e2r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.z) : nx.z;
@@ -649,7 +677,16 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         d[6] = from_next_lane(ICASE ? fold4(cur.z) : cur.z, ICASE ? fold4(e2r) : e2r, lane);
         d[7] = from_next_lane(ICASE ? fold4(cur.w) : cur.w, ICASE ? fold4(e3r) : e3r, lane);
       }
-      if (kReuse || lazy_done) {
+      if (KIND == kClassFast && kReuse) {
+        uint32_t m0 = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {  // this lane's bits of the masks
+          uint32_t t;
+          asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(t) : "s"(cmk[b]));
+          m0 |= t << b;
+        }
+        m = match_mask16_from<KIND, ICASE>(m0, d, P, cbase, unit_off, limit, s_pat, s_view);
+      } else if (kReuse || lazy_done) {
         uint32_t m0 = 0;
 #pragma unroll
         for (int b = 0; b < 16; ++b) m0 |= (uint32_t)cb[b] << b;
@@ -694,8 +731,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   constexpr uint32_t kTile = kWaveSpan * kWaves;         // bytes per workgroup
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
-  __shared__ __attribute__((aligned(16))) uint8_t s_pat[KIND == kClass ? 2048 : KIND == kLong ? XSG_MAX_PATTERN : 16];
-  __shared__ __attribute__((aligned(16))) uint8_t s_view[KIND == kClass ? kBlock * 48 : 16];  // match_mask16<kClass>
+  __shared__ __attribute__((aligned(16))) uint8_t s_pat[is_cls(KIND) ? 2048 : KIND == kLong ? XSG_MAX_PATTERN : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_view[is_cls(KIND) ? kBlock * 48 : 16];  // match_mask16<kClass>
 
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (tile >= A.ntiles) return;
@@ -708,11 +745,6 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
 
   if (KIND == kLong) {
     for (uint32_t k = tid; k < P.plen; k += kBlock) s_pat[k] = P.d_pat[k];
-    __syncthreads();
-  }
-  if (KIND == kClass) {  // 256-bit set per alternative and position (at most 64 sets = 2 KiB)
-    for (uint32_t k = tid; k < P.plen * P.nalt * 8u; k += kBlock)
-      reinterpret_cast<uint32_t*>(s_pat)[k] = reinterpret_cast<const uint32_t*>(P.d_pat)[k];
     __syncthreads();
   }
 
@@ -769,6 +801,14 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   // keep every load ahead of the first use of any of them (otherwise the
   // scheduler sinks a copy of load 0 between the loads and stalls the issue)
   __builtin_amdgcn_sched_barrier(0);
+  if (is_cls(KIND)) {
+    // The sets (256 bits per alternative and position, at most 64 sets = 2 KiB) go to LDS BEHIND the tile's loads:
+    // only the slow path reads them, and staged first -- a load, a store and a barrier in front of everything --
+    // they held back the moment the workgroup's 16 KiB are requested.
+    for (uint32_t k = tid; k < P.plen * P.nalt * 8u; k += kBlock)
+      reinterpret_cast<uint32_t*>(s_pat)[k] = reinterpret_cast<const uint32_t*>(P.d_pat)[k];
+    __syncthreads();
+  }
 
   // The loop body exists twice: a wave whose whole span lies inside the chunk (all
   // but the last tile of a chunk) skips every end-of-chunk check.
@@ -798,7 +838,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
   for (int j = 0; j < kLoads; ++j) masks[j] = st.masks[j < 4 ? j : 0];
   if (WANT_LINES && !EMIT && run_nl) wsum = sum_combine(wsum, kSumNl);
 
-  if (KIND == kClass) {
+  if (is_cls(KIND)) {
     if (P.ascii_only && __any((st.hi & 0x80808080u) != 0) && lane == 0) atomicOr(A.flags, 1u);  // the search must refuse
   }
   if (!EMIT) {
@@ -932,7 +972,8 @@ void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, 
     return;
   }
   const bool window = a.pat.kind == kTwo || a.pat.kind == kLong || a.pat.kind == kClass;
-  snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s, %s> stagger=%u", (int)a.pat.kind, b[emit ? 0 : want_nl],
+  const int kind = (a.pat.kind == kClass && a.pat.cls_fast && !a.pat.hot) ? (int)kClassFast : (int)a.pat.kind;
+  snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s, %s> stagger=%u", kind, b[emit ? 0 : want_nl],
            b[emit ? 0 : want_lines], b[emit], b[a.pat.icase ? 1 : 0], b[window && a.pat.hot ? 1 : 0],
            pick_stagger(a, want_nl, want_lines, emit));
 }
@@ -947,7 +988,10 @@ static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_line
     case kOne: return launch_scan_loads<kOne>(a, want_nl, want_lines, emit, grid, s);
     case kMask2: return launch_scan_loads<kMask2>(a, want_nl, want_lines, emit, grid, s);
     case kTwo: return launch_scan_loads<kTwo>(a, want_nl, want_lines, emit, grid, s);
-    case kClass: return launch_scan_loads<kClass>(a, want_nl, want_lines, emit, grid, s);
+    case kClass:
+      // a window that takes the exact 16 + 32 bit filter has its own instantiation (window filter only)
+      if (a.pat.cls_fast && !a.pat.hot) return launch_scan_loads<kClassFast>(a, want_nl, want_lines, emit, grid, s);
+      return launch_scan_loads<kClass>(a, want_nl, want_lines, emit, grid, s);
     default: return launch_scan_loads<kLong>(a, want_nl, want_lines, emit, grid, s);
   }
 }

@@ -421,12 +421,10 @@ bool compile_regex_dfa(const uint8_t* re, size_t n, bool ignore_case, RegexDfa* 
       if (nd.kind == Node::kSet)
         for (uint32_t b = 'a'; b <= 'z'; ++b)
           if (set_has(nd.set, b) || set_has(nd.set, b - 32)) set_add(nd.set, b), set_add(nd.set, b - 32);
+  // A set that accepts '\n' (\s, a negated class) lets a match span lines: then the unit of the walk is the chunk,
+  // not the line (k_rx_chunk), and the line tags do not apply -- as for a literal that contains '\n'.
   for (const Node& nd : p.pool)
-    if (nd.kind == Node::kSet && set_has(nd.set, '\n')) {
-      *err = "a variable-length expression whose sets accept '\\n' (\\s, a negated class) could match across lines: "
-             "not supported by the line-parallel matcher";
-      return false;
-    }
+    if (nd.kind == Node::kSet && set_has(nd.set, '\n')) out->multiline = true;
 
   // forward: any-byte loop of lowest priority in front of the expression (RE2's unanchored search)
   Nfa f;
@@ -434,7 +432,7 @@ bool compile_regex_dfa(const uint8_t* re, size_t n, bool ignore_case, RegexDfa* 
   const int fentry = emit(p.pool, root, fmatch, false, &f);
   ByteSet any{};
   for (uint32_t b = 0; b < 256; ++b)
-    if (b != '\n') set_add(any, b);
+    if (b != '\n' || out->multiline) set_add(any, b);
   const int floop_set = f.add(Inst::kSet, f.set_id(any), -1, -1);
   const int fstart = f.add(Inst::kSplit, -1, fentry, floop_set);
   Nfa r;

@@ -22,8 +22,10 @@
 // Restrictions, all refused at compile time, never approximated:
 //   * the expression, and every sub-expression under a repetition operator, must not match the empty string (the
 //     reference's walk would not advance on an empty match, search_wrappers.h:75-76);
-//   * no set may contain '\n': then no match spans two lines, and lines are what the kernel hands to its lanes
-//     (a line is walked sequentially, as the reference walks a chunk; lines are independent);
+//   * (not a refusal, a slower route) if no set contains '\n', no match spans two lines, and lines are what the
+//     kernel hands to its lanes (a line is walked sequentially, as the reference walks a chunk; lines are
+//     independent).  An expression with a set that accepts '\n' (\s+, [^,]*) is `multiline`: its unit of sequential
+//     work is the chunk (k_rx_chunk: one lane per chunk), and only the match tags apply to it;
 //   * ^ $ \b \B \A \z (they read the context of a re-sliced input in the reference), (?flags), \p, \C, back-refs;
 //   * automata over kRxMaxEntries table entries.
 #pragma once
@@ -39,7 +41,7 @@ constexpr uint32_t kRxMaxEntries = 16384;  // states x classes per automaton: 32
 constexpr uint32_t kRxMaxNfa = 4096;       // NFA positions (x{n,m} is expanded)
 
 struct RegexDfa {
-  uint32_t ncls = 0;     // byte classes; class_of['\n'] is a class of its own that leads to the dead state everywhere
+  uint32_t ncls = 0;     // byte classes; class_of['\n'] is a class of its own (unless multiline: leading to the dead state everywhere)
   uint8_t class_of[256];
   // Row-major transition tables, entries PRE-MULTIPLIED: entry = next_state * ncls.  State 0 is dead (its row is
   // all 0); states [1, first_acc) hold no match, states [first_acc, nstates) do.
@@ -48,6 +50,7 @@ struct RegexDfa {
   uint32_t rev_states = 0, rev_start = 0, rev_first_acc = 0;
   uint32_t minlen = 0;       // shortest match, >= 1
   bool ascii_only = false;   // as ClassExpr::ascii_only: a search refuses data with a byte >= 0x80
+  bool multiline = false;    // some set accepts '\n': matches may span lines ('\n' is then an ordinary byte for the automata)
 };
 
 // ignore_case: every set is closed under ASCII case (the data is NOT folded on this route).

@@ -18,6 +18,8 @@
 // tile, nothing stored when there are none; tile_nl on request; emission at tile_off ranks), so the finish kernel
 // and the whole list pipeline behind it are shared.  The automata are tables of pre-multiplied uint16 row offsets
 // in LDS: next = fwd[state + class_of[byte]]; all of it is byte/integer work, LDS-latency-bound, no MFMA.
+// The staged tile is translated to class codes in place (one table read per byte, off every dependency chain), the
+// walks read four codes at a time, and a walk in the start state skips from trigger byte to trigger byte.
 #include "xsg_internal.h"
 
 namespace xsg {
@@ -30,8 +32,8 @@ constexpr uint32_t kRxTileLds = kRxTile + 4 * kBlock;
 __device__ __forceinline__ uint32_t rx_addr(uint32_t p) { return p + ((p >> 6) << 2); }
 
 struct RxCtx {
-  const uint8_t* tile;     // LDS, swizzled (rx_addr)
-  const uint8_t* cls;      // LDS, 256 bytes: class of the byte; bit 7 (if `skip`): the byte is a TRIGGER
+  const uint32_t* tilew;   // LDS, swizzled (rx_addr): the tile as CLASS CODES, one per byte (bit 7, if `skip`: trigger)
+  const uint8_t* cls;      // LDS, 256 bytes: class of a byte, same encoding (for bytes read from global memory)
   const unsigned long long* trig;  // LDS, one word per 64-byte segment of the tile: bit i <=> byte i is a trigger
   uint32_t skip, cmask;    // skip: trigger bits exist; cmask: 0x7f then, else 0xff
   const uint16_t* fwd;     // LDS
@@ -42,9 +44,14 @@ struct RxCtx {
   uint32_t fwd_start, fwd_acc, rev_start, rev_acc;
 };
 
-__device__ __forceinline__ uint32_t rx_byte(const RxCtx& X, uint64_t q) {  // q < L
+// class code of the byte at q (< L), wherever it lives
+__device__ __forceinline__ uint32_t rx_class(const RxCtx& X, uint64_t q) {
   const uint64_t rel = q - X.toff;
-  return rel < kRxTile ? X.tile[rx_addr((uint32_t)rel)] : X.cbase[q];
+  if (rel < kRxTile) {
+    const uint32_t r = (uint32_t)rel;
+    return (X.tilew[rx_addr(r & ~3u) >> 2] >> (8u * (r & 3u))) & X.cmask;
+  }
+  return X.cls[X.cbase[q]] & X.cmask;
 }
 
 // One line, from its start `cur` (chunk-relative): the reference's walk restricted to the line.  Returns the number
@@ -56,27 +63,53 @@ __device__ __forceinline__ uint32_t rx_walk_line(const RxCtx& X, uint64_t cur, c
   for (;;) {
     uint32_t st = X.fwd_start;
     uint64_t q = cur, last_end = 0;  // a match ends behind at least one byte: 0 = none yet
-    while (q < X.L) {
+    bool stop = false;               // the state died, or (LINES) a match was seen
+    while (!stop && q < X.L) {
+      const uint64_t rel64 = q - X.toff;
+      if (rel64 >= kRxTile) {  // the line has left the tile: byte by byte through global memory
+        st = X.fwd[st + (X.cls[X.cbase[q]] & X.cmask)];
+        if (st == 0) break;
+        ++q;
+        if (st >= X.fwd_acc) {
+          last_end = q;
+          if (LINES) break;
+        }
+        continue;
+      }
+      uint32_t rel = (uint32_t)rel64;
       // In its start state the automaton only waits for a byte that can begin a match: every other byte leaves it
-      // where it is.  Those bytes (and '\n') are the tile's TRIGGERS, found for all 16 KiB at once in the staging
+      // where it is.  Those bytes (and '\n') are the tile's TRIGGERS, flagged for all 16 KiB at once in the staging
       // phase; the walk jumps from one to the next on the bit masks instead of stepping through the text.
       if (X.skip && st == X.fwd_start) {
-        const uint64_t rel = q - X.toff;
-        if (rel < kRxTile) {
-          uint32_t w = (uint32_t)rel >> 6;
-          unsigned long long m = X.trig[w] & (~0ull << ((uint32_t)rel & 63u));
-          while (!m && ++w < (uint32_t)kBlock) m = X.trig[w];
-          q = X.toff + (m ? w * kRxSeg + (uint32_t)__builtin_ctzll(m) : kRxTile);
-          if (q >= X.L) break;
+        uint32_t w = rel >> 6;
+        unsigned long long m = X.trig[w] & (~0ull << (rel & 63u));
+        while (!m && ++w < (uint32_t)kBlock) m = X.trig[w];
+        if (!m) {  // none left in the tile (the line runs on behind it)
+          q = X.toff + kRxTile;
+          continue;
         }
+        rel = w * kRxSeg + (uint32_t)__builtin_ctzll(m);
+        q = X.toff + rel;
       }
-      st = X.fwd[st + (X.cls[rx_byte(X, q)] & X.cmask)];
-      if (st == 0) break;  // dead: the line ended, or nothing can outrank the match already seen
-      ++q;
-      if (st >= X.fwd_acc) {
-        last_end = q;
-        if (LINES) break;  // any match makes the line a matching line
-      }
+      // the class codes of four bytes with one read; bytes at or beyond L are '\n' here, which kills every state
+      const uint32_t cw = X.tilew[rx_addr(rel & ~3u) >> 2];
+      uint32_t sh = 8u * (rel & 3u);
+      do {
+        st = X.fwd[st + ((cw >> sh) & X.cmask)];
+        if (st == 0) {
+          stop = true;  // dead: the line ended, or nothing can outrank the match already seen
+          break;
+        }
+        ++q;
+        sh += 8u;
+        if (st >= X.fwd_acc) {
+          last_end = q;
+          if (LINES) {
+            stop = true;  // any match makes the line a matching line
+            break;
+          }
+        }
+      } while (sh < 32u && !(X.skip && st == X.fwd_start));
     }
     if (!last_end) break;  // no (further) match in this line
     ++n;
@@ -85,7 +118,7 @@ __device__ __forceinline__ uint32_t rx_walk_line(const RxCtx& X, uint64_t cur, c
       uint32_t rs = X.rev_start;
       uint64_t r = last_end, start = last_end;
       while (r > cur) {
-        rs = X.rev[rs + (X.cls[rx_byte(X, r - 1)] & X.cmask)];
+        rs = X.rev[rs + rx_class(X, r - 1)];
         if (rs == 0) break;
         --r;
         if (rs >= X.rev_acc) start = r;
@@ -112,6 +145,7 @@ __global__ __launch_bounds__(kBlock) void k_rx_scan(const ScanArgs A, const uint
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // the forward table
   __shared__ __attribute__((aligned(16))) uint8_t s_tile[kRxTileLds];
   __shared__ uint8_t s_cls[256];
+  __shared__ uint8_t s_lastnl[kBlock];  // does the lane's segment end in '\n'?  (the next lane's first byte is a line start then)
   __shared__ unsigned long long s_trig[kBlock];
   __shared__ uint32_t s_w[kWaves];
 
@@ -159,39 +193,53 @@ __global__ __launch_bounds__(kBlock) void k_rx_scan(const ScanArgs A, const uint
   if (P.ascii_only && __any((hi & 0x80808080u) != 0) && lane == 0) atomicOr(A.flags, 1u);  // the search must refuse
   __syncthreads();
 
-  // ---- the line starts of this lane's segment: a position is one iff it is < L and follows a '\n' (or opens the chunk)
+  // ---- this lane's 64-byte segment: where its lines start (a position < L that follows a '\n' or opens the chunk),
+  // and its bytes translated to CLASS CODES in place -- the automata only ever ask for the class of a byte, so the
+  // table read is done once per byte here, 64 reads per lane that depend on nothing but the data and are issued in
+  // batches of 16, instead of once per step inside a walk, where it sits on the state's dependency chain.  With
+  // `skip`, bit 7 of a class code flags a trigger byte, and the flags of the segment become its trigger word.
   const uint32_t seg = tid * kRxSeg;
   unsigned long long nlm = 0, tgm = 0;
   {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(s_tile + rx_addr(seg));
+    uint32_t* w = reinterpret_cast<uint32_t*>(s_tile + rx_addr(seg));
+    uint32_t d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = w[k];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const uint32_t d = w[k];
-      const uint32_t x = d ^ 0x0a0a0a0au;
+      const uint32_t x = d[k] ^ 0x0a0a0a0au;
       const uint32_t f = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu) >> 7;  // bit 0, 8, 16, 24 <=> byte is '\n'
       const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
       nlm |= (unsigned long long)nib << (4 * k);
-      if (P.rx_skip) {  // the trigger flag of every byte: 64 independent table reads per lane, nothing waits on a state
-        const uint32_t t = ((uint32_t)(s_cls[d & 0xffu] >> 7)) | ((uint32_t)(s_cls[(d >> 8) & 0xffu] >> 7) << 1) |
-                           ((uint32_t)(s_cls[(d >> 16) & 0xffu] >> 7) << 2) | ((uint32_t)(s_cls[d >> 24] >> 7) << 3);
-        tgm |= (unsigned long long)t << (4 * k);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint32_t t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = s_cls[(d[4 * g + (i >> 2)] >> (8 * (i & 3))) & 0xffu];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t cw = t[4 * j] | (t[4 * j + 1] << 8) | (t[4 * j + 2] << 16) | (t[4 * j + 3] << 24);
+        w[4 * g + j] = cw;
+        const uint32_t f = (cw >> 7) & 0x01010101u;
+        const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
+        tgm |= (unsigned long long)nib << (4 * (4 * g + j));
       }
     }
   }
-  if (P.rx_skip) {
-    s_trig[tid] = tgm | nlm;
-    __syncthreads();
-  }
+  s_lastnl[tid] = (uint8_t)(nlm >> 63);
+  s_trig[tid] = tgm;  // '\n' is a trigger by construction (xsg_api.cpp); all zero without `skip`, never read then
+  __syncthreads();
   const uint64_t seg_off = toff + seg;
   const uint32_t nvalid = seg_off >= L ? 0u : (L - seg_off >= kRxSeg ? kRxSeg : (uint32_t)(L - seg_off));
   const unsigned long long valid = nvalid >= 64u ? ~0ull : ((1ull << nvalid) - 1ull);
   bool prev_nl;
   if (tid == 0) prev_nl = toff == 0 || cbase[toff - 1] == '\n';
-  else prev_nl = s_tile[rx_addr(seg - 1u)] == '\n';
+  else prev_nl = s_lastnl[tid - 1u] != 0;
   const unsigned long long starts = ((nlm << 1) | (prev_nl ? 1ull : 0ull)) & valid;
 
   RxCtx X;
-  X.tile = s_tile, X.cls = s_cls, X.fwd = reinterpret_cast<const uint16_t*>(s_dyn);
+  X.tilew = reinterpret_cast<const uint32_t*>(s_tile), X.cls = s_cls, X.fwd = reinterpret_cast<const uint16_t*>(s_dyn);
   X.trig = s_trig, X.skip = P.rx_skip, X.cmask = P.rx_skip ? 0x7fu : 0xffu;
   X.rev = reinterpret_cast<const uint16_t*>(P.d_pat + ((256u + 2u * (size_t)P.rx_fwd_n + 15u) & ~(size_t)15u));
   X.cbase = cbase, X.toff = toff, X.L = L;
@@ -232,6 +280,109 @@ __global__ __launch_bounds__(kBlock) void k_rx_scan(const ScanArgs A, const uint
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_rx_chunk: expressions whose sets accept '\n' (`\s+`, `[^,]*`).  A match may span lines, so the only unit that
+// is independent of its neighbours is the CHUNK -- the unit of the reference's own walk (Searcher.h:100-120 hands a
+// chunk to _regex_byte_offsets).  One lane walks one chunk, start to end, with the same two automata, reading its
+// bytes through the caches; parallelism is the number of chunks, so this route is slow (tens of MB/s per chunk) and
+// exists so that such an expression is served at all.  Match tags only.  The count of a chunk goes to the tile_cnt
+// word of the chunk's first tile (the ranks of the emit pass follow from the same prefix sum as everywhere else).
+// ---------------------------------------------------------------------------
+template <bool EMIT>
+__global__ __launch_bounds__(kBlock) void k_rx_chunk(const ScanArgs A, const uint64_t nchunks) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // the forward table
+  __shared__ uint8_t s_cls[256];
+  const PatternDev P = A.pat;
+  const uint32_t tid = threadIdx.x;
+  s_cls[tid] = P.d_pat[tid];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.d_pat + 256);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
+    for (uint32_t k = tid; k < (P.rx_fwd_n + 1u) / 2u; k += kBlock) dst[k] = src[k];
+  }
+  __syncthreads();
+  const uint64_t c = (uint64_t)blockIdx.x * kBlock + tid;
+  if (c >= nchunks) return;
+  const uint64_t t0 = A.chunk_tile0[c];
+  if (t0 == A.chunk_tile0[c + 1]) return;  // empty chunk: no tile, no word
+  if (EMIT && A.tile_cnt[t0] == 0) return;
+  const ChunkDev ch = A.chunks[c];
+  const uint8_t* d = A.base + ch.offset;
+  const uint64_t L = ch.length;
+  const uint16_t* fwd = reinterpret_cast<const uint16_t*>(s_dyn);
+  const uint16_t* rev = reinterpret_cast<const uint16_t*>(P.d_pat + ((256u + 2u * (size_t)P.rx_fwd_n + 15u) & ~(size_t)15u));
+  uint64_t rank = EMIT ? A.tile_off[t0] : 0;
+  uint32_t n = 0, hi = 0;
+  uint64_t cur = 0;
+  for (;;) {
+    uint32_t st = P.rx_fwd_start;
+    uint64_t q = cur, last_end = 0;
+    while (q < L) {
+      const uint32_t b = d[q];
+      hi |= b;
+      st = fwd[st + s_cls[b]];
+      if (st == 0) break;
+      ++q;
+      if (st >= P.rx_fwd_acc) last_end = q;
+    }
+    if (!last_end) break;
+    ++n;
+    if (EMIT) {
+      uint32_t rs = P.rx_rev_start;
+      uint64_t r = last_end, start = last_end;
+      while (r > cur) {
+        rs = rev[rs + s_cls[d[r - 1]]];
+        if (rs == 0) break;
+        --r;
+        if (rs >= P.rx_rev_acc) start = r;
+      }
+      if (A.m_cap == 0 || rank < A.m_cap) {
+        A.m_pos[rank] = start;
+        A.m_chunk[rank] = (uint32_t)c;
+      }
+      ++rank;
+    }
+    cur = last_end;
+  }
+  if (!EMIT) {
+    if (n) A.tile_cnt[t0] = n;  // one writer per word; zero at rest
+    // the bytes behind the last match were all read by the final forward scan, so `hi` has seen the whole chunk
+    if (P.ascii_only && (hi & 0x80u)) atomicOr(A.flags, 1u);
+  }
+}
+
+// newline counts per tile on their own (k_rx_chunk has no tile loop to fold them into)
+__global__ __launch_bounds__(kBlock) void k_rx_newlines(const ScanArgs A) {
+  __shared__ uint32_t s_w[kWaves];
+  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+  if (tile >= A.ntiles) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t c = A.tile_chunk ? A.tile_chunk[tile] : 0u;
+  const ChunkDev ch = A.chunks[c];
+  const uint8_t* cbase = A.base + ch.offset;
+  const uint64_t L = ch.length, Lr = (L + 15u) & ~(uint64_t)15u;
+  const uint64_t toff = (tile - A.chunk_tile0[c]) * (uint64_t)kRxTile;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t off = toff + ((uint64_t)j * kBlock + tid) * kUnit;
+    if (off >= Lr) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(cbase + off);
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint64_t o = off + 4u * q;
+      const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+      const uint32_t x = (d[q] & keep) ^ 0x0a0a0a0au;  // bytes beyond L read as 0, which is not '\n'
+      cnt += (uint32_t)__popc(~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu));
+    }
+  }
+  const uint32_t wn = rx_wave_sum(cnt);
+  if (lane == 0) s_w[wave] = wn;
+  __syncthreads();
+  if (tid == 0) A.tile_nl[tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
 static dim3 rx_grid(uint64_t ntiles) {
   const uint64_t maxx = 1u << 30;
   if (ntiles <= maxx) return dim3((unsigned)ntiles, 1, 1);
@@ -244,6 +395,14 @@ hipError_t launch_rx_count(const ScanArgs& a, bool want_nl, bool want_lines, hip
   if (a.ntiles == 0) return hipSuccess;
   if (a.tile_bytes != kRxTile) return hipErrorInvalidValue;
   const dim3 grid = rx_grid(a.ntiles);
+  if (a.pat.rx_multiline) {
+    if (want_lines) return hipErrorInvalidValue;  // refused upstream (has_newline)
+    if (want_nl) hipLaunchKernelGGL(k_rx_newlines, grid, dim3(kBlock), 0, s, a);
+    const uint64_t nchunks = a.nchunks;
+    hipLaunchKernelGGL((k_rx_chunk<false>), dim3((unsigned)((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), rx_dyn_lds(a), s,
+                       a, nchunks);
+    return hipGetLastError();
+  }
   if (want_lines)
     hipLaunchKernelGGL((k_rx_scan<false, true>), grid, dim3(kBlock), rx_dyn_lds(a), s, a, want_nl ? 1u : 0u);
   else
@@ -254,6 +413,12 @@ hipError_t launch_rx_count(const ScanArgs& a, bool want_nl, bool want_lines, hip
 hipError_t launch_rx_emit(const ScanArgs& a, hipStream_t s) {
   if (a.ntiles == 0) return hipSuccess;
   if (a.tile_bytes != kRxTile) return hipErrorInvalidValue;
+  if (a.pat.rx_multiline) {
+    const uint64_t nchunks = a.nchunks;
+    hipLaunchKernelGGL((k_rx_chunk<true>), dim3((unsigned)((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), rx_dyn_lds(a), s, a,
+                       nchunks);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((k_rx_scan<true, false>), rx_grid(a.ntiles), dim3(kBlock), rx_dyn_lds(a), s, a, 0u);
   return hipGetLastError();
 }

@@ -52,7 +52,7 @@ class JobStats(C.Structure):
 
 
 class RegexDfaInfo(C.Structure):
-    _fields_ = [("ncls", C.c_uint32), ("minlen", C.c_uint32), ("ascii_only", C.c_uint32),
+    _fields_ = [("ncls", C.c_uint32), ("minlen", C.c_uint32), ("ascii_only", C.c_uint32), ("multiline", C.c_uint32),
                 ("fwd_states", C.c_uint32), ("fwd_start", C.c_uint32), ("fwd_first_acc", C.c_uint32),
                 ("rev_states", C.c_uint32), ("rev_start", C.c_uint32), ("rev_first_acc", C.c_uint32),
                 ("class_of", C.c_uint8 * 256)]
