@@ -178,13 +178,21 @@ int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32_t* positio
  * fixed-length one that xsg_regex_info describes). */
 typedef struct xsg_regex_dfa {
   uint32_t ncls, minlen, ascii_only;
-  uint32_t multiline; /* a set accepts '\n': matches may span lines; the match tags only, one lane per chunk */
+  uint32_t multiline; /* a set accepts '\n': matches may span lines; the match tags only */
+  /* PREFILTER: if prefix_positions != 0, every match starts with that many bytes accepted by one of
+   * prefix_alternatives class sequences; the synchronous entry points (xsg_count, xsg_search, the jobs) then find
+   * candidate positions with the scan kernel's class-sequence matcher and run the automaton at candidates only. */
+  uint32_t prefix_positions, prefix_alternatives;
   uint32_t fwd_states, fwd_start, fwd_first_acc;
   uint32_t rev_states, rev_start, rev_first_acc;
   uint8_t class_of[256];
 } xsg_regex_dfa;
 int xsg_regex_dfa_info(const void* expr, size_t n, uint32_t flags, xsg_regex_dfa* info, uint16_t* fwd, uint16_t* rev,
                        size_t cap_entries);
+/* The prefilter of such an expression in the layout of xsg_regex_info (room for 64 x 8 uint32, alternative-major):
+ * every match starts with *positions bytes that one of the *alternatives class sequences accepts.  *positions == 0:
+ * the expression has no selective start, every entry point walks all lines (k_rx_scan). */
+int xsg_regex_prefix(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* alternatives, uint32_t* sets);
 
 /* ---- shards ---------------------------------------------------------------- */
 /* d_base/capacity: device memory owned by the caller (hipMalloc, a torch

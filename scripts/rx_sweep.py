@@ -5,6 +5,7 @@ Writes JSON lines to gpurun_out/rx_sweep.jsonl."""
 import argparse
 import json
 import sys
+import time
 from pathlib import Path
 
 import numpy as np
@@ -65,8 +66,13 @@ def main():
         for mode, name in ((xsg.COUNT_MATCHES, "count"), (xsg.COUNT_LINES, "count_lines")):
             ms = sh.time_scan_kernel(mode, a.iters)
             c = sh.count(mode)
+            t0 = time.perf_counter()  # the synchronous call, whatever route it takes (prefilter: candidates + automaton)
+            for _ in range(a.iters):
+                c = sh.count(mode)
+            call_ms = (time.perf_counter() - t0) * 1e3 / a.iters
             emit(pattern=expr, mode=name, kernel=sh.scan_kernel_name(mode), ms=ms, gbs=shard_bytes / ms / 1e6,
-                 result=int(c[xsg.CTR_MATCHES if mode == xsg.COUNT_MATCHES else xsg.CTR_LINES]), bytes=shard_bytes)
+                 result=int(c[xsg.CTR_MATCHES if mode == xsg.COUNT_MATCHES else xsg.CTR_LINES]), bytes=shard_bytes,
+                 count_call_ms=call_ms, count_call_gbs=shard_bytes / call_ms / 1e6)
     out.close()
 
 

@@ -308,3 +308,22 @@ def test_expressions_that_can_match_a_newline(gs, oracle):
         with pytest.raises(xsg.XsgError) as ei:
             call()
         assert ei.value.code == xsg.ENOTSUP
+
+
+def test_both_routes_of_the_automaton_family_agree(gs, oracle, monkeypatch):
+    """an expression with a selective start is searched two ways: candidates by the scan kernel's class-sequence
+    matcher + the anchored automaton at candidates (xsg_count / xsg_search / the jobs), or every line walked by
+    k_rx_scan (xsg_count_async; XSG_RX_PRE=0 forces it everywhere).  Same oracle, same answers."""
+    blocks = [corpus.text_block(777, i, 900_000 + 1111 * i, needle_rate=2e-4) for i in range(3)]
+    blocks.append(np.frombuffer(b"Sherlock Holmes locked the lock\nSher", dtype=np.uint8).copy())  # ends inside a prefix
+    gs.bind(blocks)
+    for expr in (b"Sher.*mes", b"Sherlock|Holmes", b"lock(ed|s)?", b"(the|The) +\\w{5,}", b"[Tt]he +[a-z]+ly ",
+                 b"She\\s+lock", b"(?:st|pad)lock|str+eet", b"Sher.*?k"):
+        assert xsg.regex_prefix(expr)[0] >= 3
+        for icase in (False, True):
+            res = []
+            for pre in ("1", "0"):
+                monkeypatch.setenv("XSG_RX_PRE", pre)
+                res.append(check(gs, oracle, blocks, expr, icase, f"pre={pre}"))
+            assert res[0] == res[1] and res[0] is not None
+    monkeypatch.delenv("XSG_RX_PRE")

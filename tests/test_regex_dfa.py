@@ -194,3 +194,44 @@ def test_cpython_reads_the_operators_as_written_too():
         assert oracle_matches(prog, data) == [(m.start(), m.end()) for m in native.finditer(data)], expr
         done += 1
     assert done > 100
+
+
+def prefix_accepts(sets, s: bytes) -> bool:
+    return any(all((int(alt[k][b >> 5]) >> (b & 31)) & 1 for k, b in enumerate(s)) for alt in sets)
+
+
+def test_prefilter_of_known_expressions():
+    """the first bytes of every match, as alternatives of class sequences (xsg_regex.h: RegexDfa::prefix)"""
+    n, sets = xsg.regex_prefix(b"Sher.*mes")
+    assert n == 4 and len(sets) == 1 and prefix_accepts(sets, b"Sher") and not prefix_accepts(sets, b"sher")
+    n, sets = xsg.regex_prefix(b"Sher.*mes", xsg.FLAG_IGNORE_CASE)
+    assert n == 4 and prefix_accepts(sets, b"sHEr")
+    n, sets = xsg.regex_prefix(b"Sherlock|Holmes")
+    assert n == 6 and prefix_accepts(sets, b"Sherlo") and prefix_accepts(sets, b"Holmes") and not prefix_accepts(sets, b"Holmlo")
+    n, sets = xsg.regex_prefix(b"colou?r")
+    assert n == 5 and prefix_accepts(sets, b"colou") and prefix_accepts(sets, b"color")
+    for expr in (b"\\w+ing", b"[a-z]+ing", b"[A-Z][a-z]+ [A-Z][a-z]+", b"ab+", b"x{2,}"):  # nothing selective, or too short
+        assert xsg.regex_prefix(expr)[0] == 0, expr
+
+
+def test_every_match_starts_with_the_prefilter():
+    rng = np.random.default_rng(31337)
+    alphabet = np.frombuffer(b"aabbccxyz01 _\n\n", dtype=np.uint8)
+    with_prefix = 0
+    for it in range(1200):
+        expr = rand_var_expr(rng)
+        icase = bool(rng.integers(0, 4) == 0)
+        flags = xsg.FLAG_IGNORE_CASE if icase else 0
+        try:
+            prog = RegexProgram(expr, icase)
+            n, sets = xsg.regex_prefix(expr, flags)
+        except (UnsupportedRegex, xsg.XsgError):
+            continue
+        if n == 0:
+            continue
+        assert 3 <= n <= min(prog.minlen, 8)
+        data = alphabet[rng.integers(0, len(alphabet), size=600)].tobytes()
+        for a, b in oracle_matches(prog, data):
+            assert prefix_accepts(sets, data[a:a + n]), (expr, icase, data[a:b])
+        with_prefix += 1
+    assert with_prefix > 50

@@ -115,6 +115,7 @@ extern "C" void xsg_ctx_destroy(xsg_ctx* c) {
     (void)hipStreamDestroy(c->stream);
   }
   c->d_pat.release();
+  c->d_pre.release();
   delete c;
 }
 
@@ -197,6 +198,71 @@ static std::vector<uint32_t> window_candidates(const uint8_t* p, size_t plen) {
   return out;
 }
 
+// The window-filter fields of a class expression and the device image of its sets (alternative-major, 32 bytes per
+// set) -- for a pattern of its own (set_class_pattern) and for the prefilter of the automaton route (set_dfa_pattern).
+static void class_fields(const xsg::ClassExpr& ex, bool icase, PatternDev* Pout, std::vector<uint8_t>* blob) {
+  const size_t plen = ex.npos;
+  const std::vector<xsg::ByteSet> seq = xsg::union_sets(ex);
+  // What the window compare can know about a position: the bits all members of its set agree on (a literal: all
+  // eight; [Ss]: seven; [0-9]: the upper four; [a-z]: the upper three).  (x & agree) == (member & agree) holds for
+  // every member x, so it is a superset filter at no cost -- the compare is masked per byte anyway -- and the
+  // exact decision against the sets follows for the rare candidate.  With several alternatives the sets are the
+  // position-wise unions.
+  std::vector<uint8_t> agree(plen), value(plen);
+  for (size_t k = 0; k < plen; ++k) {
+    int first = -1;
+    uint32_t diff = 0;
+    for (uint32_t b = 0; b < 256; ++b)
+      if (xsg::set_has(seq[k], b)) {
+        if (first < 0) first = (int)b;
+        diff |= b ^ (uint32_t)first;
+      }
+    agree[k] = (uint8_t)~diff;
+    value[k] = (uint8_t)((uint32_t)first & ~diff);
+  }
+  // the window that pins the most bits (rarer literal bytes break ties)
+  uint32_t koff = 0;
+  int best = -1;
+  for (size_t k = 0; k < plen; ++k) {
+    int score = 0;
+    for (int i = 0; i < 8 && k + i < plen; ++i) {
+      score += 16 * __builtin_popcount(agree[k + i]);
+      if (agree[k + i] == 0xff) score += byte_rarity(value[k + i], i);
+    }
+    // a window whose positions 0, 1 and 4..7 are single bytes takes the exact 16 + 32 bit filter (PatternDev::cls_fast)
+    if (k + 8 <= plen && agree[k] == 0xff && agree[k + 1] == 0xff && agree[k + 4] == 0xff && agree[k + 5] == 0xff &&
+        agree[k + 6] == 0xff && agree[k + 7] == 0xff)
+      score += 48;
+    if (score > best) best = score, koff = (uint32_t)k;
+  }
+  uint32_t pw[2] = {0, 0}, mw[2] = {0, 0};
+  for (int i = 0; i < 8 && koff + i < plen; ++i) {
+    pw[i >> 2] |= (uint32_t)value[koff + i] << (8 * (i & 3));
+    mw[i >> 2] |= (uint32_t)agree[koff + i] << (8 * (i & 3));
+  }
+  constexpr size_t kSetBytes = xsg::kMaxAltSets * sizeof(xsg::ByteSet);
+  blob->assign(std::max<size_t>(XSG_MAX_PATTERN, kSetBytes) + 16, 0);
+  for (size_t a = 0; a < ex.alts.size(); ++a)
+    memcpy(blob->data() + a * plen * sizeof(xsg::ByteSet), ex.alts[a].data(), plen * sizeof(xsg::ByteSet));
+  PatternDev& P = *Pout;
+  P = PatternDev{};
+  P.plen = (uint32_t)plen;
+  P.kind = kClass;
+  P.koff = koff;
+  P.p0 = pw[0], P.m0 = mw[0], P.p1 = pw[1], P.m1 = mw[1];
+  P.q0 = (P.p0 | 0x20202020u) & P.m0, P.q1 = (P.p1 | 0x20202020u) & P.m1;
+  {
+    const char* cf = getenv("XSG_CLS_FAST");
+    P.cls_fast = (P.m1 == 0xffffffffu && (P.m0 & 0xffffu) == 0xffffu && !(cf && *cf == '0')) ? 1u : 0u;
+  }
+  P.exact_tail = 1u;
+  P.icase = icase ? 1u : 0u;
+  P.nalt = (uint32_t)ex.alts.size();
+  P.ascii_only = ex.ascii_only ? 1u : 0u;
+  P.has_newline = 0;
+  for (const xsg::ByteSet& st : seq) P.has_newline |= xsg::set_has(st, '\n') ? 1u : 0u;
+}
+
 // layout of the device copy of a RegexDfa: class_of[256], then the forward table, then (16-byte aligned) the reverse one
 static size_t rx_rev_offset(uint32_t fwd_entries) { return (256 + 2 * (size_t)fwd_entries + 15) & ~(size_t)15; }
 
@@ -216,8 +282,10 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   c->koff_cands.clear();
   c->bordered = false;  // the kernel walks every line as the reference does: what it reports is already non-overlapping
   const size_t rev_off = rx_rev_offset((uint32_t)dfa.fwd.size());
-  const size_t bytes = rev_off + 2 * dfa.rev.size() + 16;
+  const size_t anc_off = (rev_off + 2 * dfa.rev.size() + 15) & ~(size_t)15;
+  const size_t bytes = anc_off + 2 * dfa.anc.size() + 16;
   std::vector<uint8_t> blob(bytes, 0);
+  memcpy(blob.data() + anc_off, dfa.anc.data(), 2 * dfa.anc.size());
   memcpy(blob.data(), dfa.class_of, 256);
   // Trigger bytes: those that move the forward automaton out of its start state (a byte that cannot begin a match
   // leaves it there), and '\n'.  Flagged in bit 7 of the class table; k_rx_scan's walks jump from trigger to trigger.
@@ -257,6 +325,22 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   P.rx_rev_start = dfa.rev_start * dfa.ncls;
   P.rx_rev_acc = dfa.rev_first_acc * dfa.ncls;
   P.rx_skip = skip ? 1u : 0u;
+  P.rx_anc_n = (uint32_t)dfa.anc.size();
+  P.rx_anc_start = dfa.anc_start * dfa.ncls;
+  P.rx_anc_acc = dfa.anc_first_acc * dfa.ncls;
+  // A selective start: the synchronous entry points find candidates with the class-sequence matcher and verify them
+  // (rx_pre_matches); xsg_count_async, which may not wait for the host, keeps k_rx_scan.  XSG_RX_PRE=0 switches it off.
+  const char* pre_env = getenv("XSG_RX_PRE");
+  c->rx_pre = dfa.prefix.npos != 0 && !(pre_env && *pre_env == '0');
+  if (c->rx_pre) {
+    std::vector<uint8_t> pblob;
+    class_fields(dfa.prefix, false, &c->pre_pat, &pblob);  // the sets are closed under case already: no folding
+    XSG_TRY(c->d_pre.ensure(pblob.size()));
+    HIP_TRY(hipMemcpyAsync(c->d_pre.p, pblob.data(), pblob.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->pre_pat.d_pat = c->d_pre.as<uint8_t>();
+    c->pre_pat.ascii_only = P.ascii_only;  // the candidate scan reads every byte: it raises the refusal flag
+  }
   return XSG_OK;
 }
 
@@ -285,70 +369,15 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   ++c->pattern_serial;
   c->koff_cands.clear();
   c->bordered = xsg::sequence_can_overlap(seq);
-  // What the window compare can know about a position: the bits all members of its set agree on (a literal: all
-  // eight; [Ss]: seven; [0-9]: the upper four; [a-z]: the upper three).  (x & agree) == (member & agree) holds for
-  // every member x, so it is a superset filter at no cost -- the compare is masked per byte anyway -- and the
-  // exact decision against the sets follows for the rare candidate.  With several alternatives the sets are the
-  // position-wise unions.
-  std::vector<uint8_t> agree(plen), value(plen);
-  for (size_t k = 0; k < plen; ++k) {
-    int first = -1;
-    uint32_t diff = 0;
-    for (uint32_t b = 0; b < 256; ++b)
-      if (xsg::set_has(seq[k], b)) {
-        if (first < 0) first = (int)b;
-        diff |= b ^ (uint32_t)first;
-      }
-    agree[k] = (uint8_t)~diff;
-    value[k] = (uint8_t)((uint32_t)first & ~diff);
-  }
-  // the window that pins the most bits (rarer literal bytes break ties)
-  uint32_t koff = 0;
-  int best = -1;
-  for (size_t k = 0; k < plen; ++k) {
-    int score = 0;
-    for (int i = 0; i < 8 && k + i < plen; ++i) {
-      score += 16 * __builtin_popcount(agree[k + i]);
-      if (agree[k + i] == 0xff) score += byte_rarity(value[k + i], i);
-    }
-    // a window whose positions 0, 1 and 4..7 are single bytes takes the exact 16 + 32 bit filter (PatternDev::cls_fast)
-    if (k + 8 <= plen && agree[k] == 0xff && agree[k + 1] == 0xff && agree[k + 4] == 0xff && agree[k + 5] == 0xff &&
-        agree[k + 6] == 0xff && agree[k + 7] == 0xff)
-      score += 48;
-    if (score > best) best = score, koff = (uint32_t)k;
-  }
-  uint32_t pw[2] = {0, 0}, mw[2] = {0, 0};
-  for (int i = 0; i < 8 && koff + i < plen; ++i) {
-    pw[i >> 2] |= (uint32_t)value[koff + i] << (8 * (i & 3));
-    mw[i >> 2] |= (uint32_t)agree[koff + i] << (8 * (i & 3));
-  }
-  // device copy: the alternatives' sets, alternative-major ([alt][position], 32 bytes each)
-  constexpr size_t kSetBytes = xsg::kMaxAltSets * sizeof(xsg::ByteSet);
-  XSG_TRY(c->d_pat.ensure(std::max<size_t>(XSG_MAX_PATTERN, kSetBytes) + 16));
-  std::vector<uint8_t> padded(std::max<size_t>(XSG_MAX_PATTERN, kSetBytes) + 16, 0);
-  for (size_t a = 0; a < ex.alts.size(); ++a)
-    memcpy(padded.data() + a * plen * sizeof(xsg::ByteSet), ex.alts[a].data(), plen * sizeof(xsg::ByteSet));
-  HIP_TRY(hipMemcpyAsync(c->d_pat.p, padded.data(), padded.size(), hipMemcpyHostToDevice, c->stream));
+  std::vector<uint8_t> blob;
+  PatternDev P;
+  class_fields(ex, icase, &P, &blob);
+  XSG_TRY(c->d_pat.ensure(blob.size()));
+  HIP_TRY(hipMemcpyAsync(c->d_pat.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-
-  PatternDev& P = c->pat;
-  P = PatternDev{};
-  P.plen = (uint32_t)plen;
-  P.kind = kClass;
-  P.koff = koff;
-  P.p0 = pw[0], P.m0 = mw[0], P.p1 = pw[1], P.m1 = mw[1];
-  P.q0 = (P.p0 | 0x20202020u) & P.m0, P.q1 = (P.p1 | 0x20202020u) & P.m1;
-  {
-    const char* cf = getenv("XSG_CLS_FAST");
-    P.cls_fast = (P.m1 == 0xffffffffu && (P.m0 & 0xffffu) == 0xffffu && !(cf && *cf == '0')) ? 1u : 0u;
-  }
   P.d_pat = c->d_pat.as<uint8_t>();
-  P.exact_tail = 1u;
-  P.icase = icase ? 1u : 0u;
-  P.nalt = (uint32_t)ex.alts.size();
-  P.ascii_only = ex.ascii_only ? 1u : 0u;
-  P.has_newline = 0;
-  for (const xsg::ByteSet& st : seq) P.has_newline |= xsg::set_has(st, '\n') ? 1u : 0u;
+  c->pat = P;
+  c->rx_pre = false;
   return XSG_OK;
 }
 
@@ -372,11 +401,29 @@ extern "C" int xsg_regex_dfa_info(const void* expr, size_t n, uint32_t flags, xs
     return fail(XSG_ENOTSUP, "regex not supported by the automaton route: %s", err.c_str());
   info->ncls = dfa.ncls, info->minlen = dfa.minlen, info->ascii_only = dfa.ascii_only ? 1u : 0u;
   info->multiline = dfa.multiline ? 1u : 0u;
+  info->prefix_positions = dfa.prefix.npos;
+  info->prefix_alternatives = (uint32_t)dfa.prefix.alts.size();
   info->fwd_states = dfa.fwd_states, info->fwd_start = dfa.fwd_start, info->fwd_first_acc = dfa.fwd_first_acc;
   info->rev_states = dfa.rev_states, info->rev_start = dfa.rev_start, info->rev_first_acc = dfa.rev_first_acc;
   memcpy(info->class_of, dfa.class_of, 256);
   if (fwd && cap_entries >= dfa.fwd.size()) memcpy(fwd, dfa.fwd.data(), 2 * dfa.fwd.size());
   if (rev && cap_entries >= dfa.rev.size()) memcpy(rev, dfa.rev.data(), 2 * dfa.rev.size());
+  return XSG_OK;
+}
+
+extern "C" int xsg_regex_prefix(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* alternatives,
+                                uint32_t* sets) {
+  if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
+  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  xsg::RegexDfa dfa;
+  std::string err;
+  if (!xsg::compile_regex_dfa(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &dfa, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the automaton route: %s", err.c_str());
+  if (positions) *positions = dfa.prefix.npos;
+  if (alternatives) *alternatives = (uint32_t)dfa.prefix.alts.size();
+  if (sets)
+    for (size_t a = 0; a < dfa.prefix.alts.size(); ++a)
+      memcpy(sets + a * dfa.prefix.npos * 8, dfa.prefix.alts[a].data(), dfa.prefix.npos * sizeof(xsg::ByteSet));
   return XSG_OK;
 }
 
@@ -454,6 +501,7 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   P.plen = (uint32_t)plen;
   window_fields(p, plen, pick_filter_window(p, plen), &P);  // koff 0 unless plen > 8
   c->koff_cands = window_candidates(p, plen);
+  c->rx_pre = false;
   P.kind = plen < 4 ? kMask1 : plen == 4 ? kOne : plen < 8 ? kMask2 : plen == 8 ? kTwo : kLong;
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;
@@ -888,6 +936,23 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   if (m != XSG_COUNT_MATCHES && m != XSG_COUNT_LINES) return fail(XSG_EINVAL, "mode %u is not a count mode", m);
+  if (c->pat.kind == kDfa && c->rx_pre) {
+    // the prefilter route of the automaton family: candidates, verification and the walk produce the list; its
+    // length is the count (the newline total, if asked for, comes from the cached per-tile counts)
+    if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
+    if (m == XSG_COUNT_LINES && c->pat.has_newline)
+      return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+    s->want_nl_total = (mode & XSG_WITH_NEWLINES) != 0;
+    const int r = run_list(s, m == XSG_COUNT_MATCHES ? XSG_MATCH_BYTE_OFFSETS : XSG_LINE_BYTE_OFFSETS, false);
+    s->want_nl_total = false;
+    XSG_TRY(r);
+    memset(counters, 0, 8 * XSG_NUM_COUNTERS);
+    counters[m == XSG_COUNT_MATCHES ? XSG_CTR_MATCHES : XSG_CTR_LINES] = s->total;
+    counters[XSG_CTR_BYTES] = s->total_bytes;
+    if (mode & XSG_WITH_NEWLINES) counters[XSG_CTR_NEWLINES] = s->last_newlines;
+    s->last_mode = -1;
+    return XSG_OK;
+  }
   if (m == XSG_COUNT_MATCHES && c->bordered) {
     // greedy non-overlap needs the ordered occurrence list
     XSG_TRY(run_list(s, XSG_MATCH_BYTE_OFFSETS, false));
@@ -926,7 +991,7 @@ extern "C" int xsg_count_begin(xsg_shard* s, uint32_t mode) {
   if (m != XSG_COUNT_MATCHES && m != XSG_COUNT_LINES) return fail(XSG_EINVAL, "mode %u is not a count mode", m);
   if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
   s->begin_sync_result = false;
-  if (m == XSG_COUNT_MATCHES && c->bordered) {  // needs the ordered list: done synchronously, handed out by _end
+  if ((m == XSG_COUNT_MATCHES && c->bordered) || (c->pat.kind == kDfa && c->rx_pre)) {  // needs the ordered list: done synchronously, handed out by _end
     XSG_TRY(xsg_count(s, mode, s->begin_counters));
     s->begin_sync_result = true;
     return XSG_OK;
@@ -991,7 +1056,15 @@ extern "C" int xsg_scan_kernel_name(xsg_shard* s, uint32_t mode, char* out, size
   const bool list = m >= XSG_MATCH_BYTE_OFFSETS;
   // what the FIRST pass of this mode launches on this shard right now (newline counts already cached -> plain kernel)
   const bool want_nl = ((mode & XSG_WITH_NEWLINES) != 0 || m == XSG_LINE_INDICES) && !s->nl_cached;
-  const ScanArgs a = scan_args(s);
+  ScanArgs a = scan_args(s);
+  if (a.pat.kind == kDfa && s->ctx->rx_pre) {  // what xsg_count / xsg_search launch: the candidate scan, then the automaton at candidates
+    a.pat = s->ctx->pre_pat;
+    a.pat.hot = 0;
+    char inner[160];
+    describe_scan(a, want_nl, false, false, inner, sizeof inner);
+    snprintf(out, cap, "%s + xsg::k_rx_verify (prefilter route; xsg_count_async: k_rx_scan)", inner);
+    return XSG_OK;
+  }
   describe_scan(a, want_nl, !list && m == XSG_COUNT_LINES, false, out, cap);
   return XSG_OK;
 }
@@ -1050,7 +1123,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   xsg_ctx* c = s->ctx;
   hipStream_t st = c->stream;
   const bool line_mode = mode != XSG_MATCH_BYTE_OFFSETS;
-  const bool want_nl = mode == XSG_LINE_INDICES;
+  const bool want_nl = mode == XSG_LINE_INDICES || s->want_nl_total;
   const uint64_t nchunks = s->chunks.size();
   const uint64_t ntiles = s->ntiles;
   if (line_mode && c->pat.has_newline)
@@ -1065,6 +1138,11 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   XSG_TRY(choose_hot_filter(s, st));
   XSG_TRY(prepare_tiles(s, false, st));
   ScanArgs a = scan_args(s);
+  const bool pre = c->pat.kind == kDfa && c->rx_pre;  // candidates by the class-sequence matcher, then the automaton
+  if (pre) {
+    a.pat = c->pre_pat;
+    a.pat.hot = 0;
+  }
   s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them
   const bool scan_nl = want_nl && !s->nl_cached;  // newline counts per tile: once per binding, whatever the pattern
   HIP_TRY(launch_scan_count(a, scan_nl, false, st));
@@ -1078,6 +1156,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   uint32_t scan_flags = 0;
   if ((c->pat.kind == kClass || c->pat.kind == kDfa) && c->pat.ascii_only)
     HIP_TRY(hipMemcpyAsync(&scan_flags, a.flags, 4, hipMemcpyDeviceToHost, st));
+
   XSG_TRY(d2h_u64(c, s->d_tile_off.as<uint64_t>() + ntiles, &M));
   if (scan_flags & 1u) {  // non-ASCII data under an ascii_only expression
     HIP_TRY(hipMemsetAsync(a.flags, 0, 4, st));
@@ -1086,12 +1165,51 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
 
   s->last_raw_matches = M;  // sizes the arrays of the next device-only pass (enqueue_count_bordered)
   // 3. ordered emission of every bulk occurrence
-  XSG_TRY(s->d_m_pos.ensure(8 * std::max<uint64_t>(M, 1)));
-  XSG_TRY(s->d_m_chunk.ensure(4 * std::max<uint64_t>(M, 1)));
   a.tile_off = s->d_tile_off.as<uint64_t>();
-  a.m_pos = s->d_m_pos.as<uint64_t>();
-  a.m_chunk = s->d_m_chunk.as<uint32_t>();
-  if (M) HIP_TRY(launch_scan_emit(a, st));
+  if (!pre) {
+    XSG_TRY(s->d_m_pos.ensure(8 * std::max<uint64_t>(M, 1)));
+    XSG_TRY(s->d_m_chunk.ensure(4 * std::max<uint64_t>(M, 1)));
+    a.m_pos = s->d_m_pos.as<uint64_t>();
+    a.m_chunk = s->d_m_chunk.as<uint32_t>();
+    if (M) HIP_TRY(launch_scan_emit(a, st));
+  } else {
+    // M candidates so far: emit them, run the anchored automaton at each, walk every chunk's occurrences as the
+    // reference does, pack what it reports -- then M is the number of matches and the list is what the emit pass
+    // of k_rx_scan would have written
+    const uint64_t Mc = M;
+    XSG_TRY(s->d_c_pos.ensure(8 * std::max<uint64_t>(Mc, 1)));
+    XSG_TRY(s->d_c_chunk.ensure(4 * std::max<uint64_t>(Mc, 1)));
+    XSG_TRY(s->d_c_len.ensure(4 * std::max<uint64_t>(Mc, 1)));
+    XSG_TRY(s->d_c_keep.ensure(4 * std::max<uint64_t>(Mc, 1)));
+    XSG_TRY(s->d_c_pre.ensure(8 * (Mc + 1)));
+    XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(std::max<uint64_t>(Mc, std::max<uint64_t>(ntiles, nchunks)) + 1)));
+    a.m_pos = s->d_c_pos.as<uint64_t>();
+    a.m_chunk = s->d_c_chunk.as<uint32_t>();
+    if (Mc) HIP_TRY(launch_scan_emit(a, st));
+    RxPreArgs r{};
+    r.base = s->base;
+    r.chunks = a.chunks;
+    r.chunk_tile0 = a.chunk_tile0;
+    r.nchunks = nchunks;
+    r.pat = c->pat;
+    r.n = Mc;
+    r.tile_off = a.tile_off;
+    r.c_pos = a.m_pos;
+    r.c_chunk = a.m_chunk;
+    r.c_len = s->d_c_len.as<uint32_t>();
+    r.c_keep = s->d_c_keep.as<uint32_t>();
+    r.c_pre = s->d_c_pre.as<uint64_t>();
+    HIP_TRY(launch_rx_verify_keep(r, st));
+    HIP_TRY(launch_exclusive_scan_u32(r.c_keep, s->d_c_pre.as<uint64_t>(), Mc, s->d_scan_tmp.as<uint64_t>(), st));
+    XSG_TRY(d2h_u64(c, s->d_c_pre.as<uint64_t>() + Mc, &M));
+    XSG_TRY(s->d_m_pos.ensure(8 * std::max<uint64_t>(M, 1)));
+    XSG_TRY(s->d_m_chunk.ensure(4 * std::max<uint64_t>(M, 1)));
+    r.m_pos = s->d_m_pos.as<uint64_t>();
+    r.m_chunk = s->d_m_chunk.as<uint32_t>();
+    HIP_TRY(launch_rx_compact(r, st));
+    a.m_pos = r.m_pos;
+    a.m_chunk = r.m_chunk;
+  }
 
   // 4. which occurrences the reference walk reports
   XSG_TRY(s->d_keep.ensure(4 * std::max<uint64_t>(M, 1)));
@@ -1143,6 +1261,17 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   HIP_TRY(hipStreamSynchronize(st));
   const uint64_t total = kept + tails;
   s->total = total;
+  if (s->want_nl_total) {  // xsg_count(... | XSG_WITH_NEWLINES) on the prefilter route: the sum of the per-tile counts
+    bool grew = false;
+    XSG_TRY(s->d_tile_nl_off.ensure(8 * (ntiles + 1), &grew));
+    if (grew) s->nl_off_cached = false;
+    XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(ntiles + 1)));
+    if (!s->nl_off_cached) {
+      HIP_TRY(launch_exclusive_scan_u32(a.tile_nl, s->d_tile_nl_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(), st));
+      s->nl_off_cached = true;
+    }
+    XSG_TRY(d2h_u64(c, s->d_tile_nl_off.as<uint64_t>() + ntiles, &s->last_newlines));
+  }
   if (!outputs) return XSG_OK;
 
   // 6. final list, in file order

@@ -205,6 +205,19 @@ void merge_alternatives(std::vector<std::vector<ByteSet>>* alts) {
 
 }  // namespace
 
+bool class_expr_from_alternatives(std::vector<std::vector<ByteSet>> alts, ClassExpr* out) {
+  *out = ClassExpr{};
+  if (alts.empty() || alts[0].empty()) return false;
+  const size_t len = alts[0].size();
+  for (const auto& a : alts)
+    if (a.size() != len) return false;
+  merge_alternatives(&alts);
+  if (len > kMaxClassSeq || alts.size() > kMaxAlt || alts.size() * len > kMaxAltSets) return false;
+  out->npos = (uint32_t)len;
+  out->alts = std::move(alts);
+  return true;
+}
+
 bool compile_class_expr(const uint8_t* re, size_t n, bool ignore_case, ClassExpr* out, std::string* err) {
   *out = ClassExpr{};
   Parser p;

@@ -53,6 +53,9 @@ struct ClassExpr {
 // ignore_case: the sets come back folded (every 'A'..'Z' member replaced by its lower-case letter: the kernel lowers
 // the data), negated classes having been closed under case BEFORE the complement, as RE2's (?i) does.
 bool compile_class_expr(const uint8_t* re, size_t n, bool ignore_case, ClassExpr* out, std::string* err);
+// the same structure from alternatives given as sets (all of one length): merged, bounded by kMaxAlt / kMaxAltSets;
+// false if they do not fit.  (The automaton route builds its prefilter this way, xsg_regex.cpp.)
+bool class_expr_from_alternatives(std::vector<std::vector<ByteSet>> alts, ClassExpr* out);
 // position-wise union of the alternatives (what a filter or a '\n' / overlap test may look at: a superset)
 std::vector<ByteSet> union_sets(const ClassExpr& e);
 

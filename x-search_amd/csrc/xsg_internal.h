@@ -69,6 +69,7 @@ struct PatternDev {
   uint32_t rx_fwd_n, rx_rev_n;     // table entries (states x classes) of the forward / reverse automaton
   uint32_t rx_fwd_start, rx_fwd_acc;  // ROW OFFSETS (state x ncls): start state, first accepting state
   uint32_t rx_rev_start, rx_rev_acc;
+  uint32_t rx_anc_n, rx_anc_start, rx_anc_acc;  // the ANCHORED forward automaton (behind the reverse table in d_pat): k_rx_verify
   uint32_t rx_multiline;           // a set of the expression accepts '\n': the chunk, not the line, is the unit (k_rx_chunk)
   uint32_t rx_skip;                // bit 7 of every class_of[] entry flags a TRIGGER byte: one that moves the forward automaton
                                    // out of its start state, or '\n' (needs ncls <= 128; XSG_RX_SKIP=0 switches it off)
@@ -137,6 +138,25 @@ hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s);
 // lines) of the lines that START in the tile, tile_nl if want_nl; emit: the matches at their ranks.
 hipError_t launch_rx_count(const ScanArgs& a, bool want_nl, bool want_lines, hipStream_t s);
 hipError_t launch_rx_emit(const ScanArgs& a, hipStream_t s);
+// the prefilter route of kDfa (xsg_rx_kernels.hip): candidates of the scan kernel -> verified, walked, packed
+struct RxPreArgs {
+  const uint8_t* base;
+  const ChunkDev* chunks;
+  const uint64_t* chunk_tile0;
+  uint64_t nchunks;
+  PatternDev pat;            // the kDfa pattern (tables in d_pat)
+  uint64_t n;                // candidates, ascending per chunk
+  const uint64_t* tile_off;  // their ranks by tile: a chunk's candidates are [tile_off[tile0[c]], tile_off[tile0[c+1]])
+  const uint64_t* c_pos;
+  const uint32_t* c_chunk;
+  uint32_t* c_len;           // length of the match that starts at the candidate, 0: none
+  uint32_t* c_keep;          // reported by the reference's walk
+  const uint64_t* c_pre;     // exclusive prefix of c_keep
+  uint64_t* m_pos;           // the reported ones, packed
+  uint32_t* m_chunk;
+};
+hipError_t launch_rx_verify_keep(const RxPreArgs& a, hipStream_t s);
+hipError_t launch_rx_compact(const RxPreArgs& a, hipStream_t s);
 // "xsg::k_scan<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE>" + the stagger launch_scan would use, for reports
 void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap);
 

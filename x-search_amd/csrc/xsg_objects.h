@@ -75,6 +75,10 @@ struct xsg_ctx {
   bool bordered = false;  // the pattern can overlap itself
   xsg::PatternDev pat{};
   DevBuf d_pat;
+  // kDfa with a selective start (xsg_regex.h: RegexDfa::prefix): the class-sequence pattern that finds the candidates
+  bool rx_pre = false;
+  xsg::PatternDev pre_pat{};
+  DevBuf d_pre;
   uint32_t tile_bytes = xsg::kDefaultTileBytes;  // geometry new shards get (XSG_TILE_KIB)
   uint32_t tune = xsg::kTuneAuto;                  // wave stagger: per kernel variant (XSG_TUNE overrides)
   uint64_t probe_min_bytes = 64ull << 20;          // shards below this keep the defaults (XSG_PROBE_MIN_BYTES; tests set 0)
@@ -111,6 +115,7 @@ struct xsg_shard {
   DevBuf d_m_pos, d_m_chunk, d_m_ls, d_keep, d_keep_pre;
   DevBuf d_chunk_shift0, d_tail_cnt, d_tail_pos, d_tail_pre;
   DevBuf d_f_pos, d_f_match, d_f_chunk, d_out_u64, d_line_len, d_line_off, d_line_bytes;
+  DevBuf d_c_pos, d_c_chunk, d_c_len, d_c_keep, d_c_pre;  // prefilter route of kDfa: the candidates
 
   // State of the per-tile arrays between passes (host-side bookkeeping; see ScanArgs).  A count pass leaves
   // tile_cnt / tile_sum clean (k_count_finish zeroes what it read); a list pass or a timing loop leaves them
@@ -132,6 +137,7 @@ struct xsg_shard {
   bool begin_sync_result = false;  // xsg_count_begin had to run synchronously: _end hands out begin_counters
   uint64_t begin_counters[XSG_NUM_COUNTERS] = {0, 0, 0, 0};
 
+  bool want_nl_total = false;  // run_list: also leave the shard's newline total in last_newlines (xsg_count on the prefilter route)
   int last_mode = -1;
   uint64_t last_raw_matches = 0;  // raw occurrences of the last list pass (capacity hint for xsg_count_async, bordered patterns)
   uint64_t total = 0;       // elements of the last list search
@@ -143,7 +149,8 @@ struct xsg_shard {
     DevBuf* all[] = {&d_chunks, &d_tile_chunk, &d_chunk_tile0, &d_tile_cnt, &d_tile_nl, &d_tile_sum, &d_tile_last,
                      &d_counters, &d_finish, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls,
                      &d_keep, &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
-                     &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes};
+                     &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes, &d_c_pos, &d_c_chunk, &d_c_len, &d_c_keep,
+                     &d_c_pre};
     for (DevBuf* b : all) b->release();
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_counters) (void)hipHostFree(h_counters);

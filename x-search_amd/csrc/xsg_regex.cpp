@@ -403,6 +403,71 @@ bool flatten(const Dfa& d, uint32_t ncls, std::vector<uint16_t>* table, uint32_t
   return true;
 }
 
+// The first k bytes of every match, as alternatives of class sequences: the paths of length k through the anchored
+// automaton, the edges out of a state grouped by their target (k <= the shortest match, so no path ends early).
+// Among k = 3 .. kmax the one whose alternatives look rarest in text wins (a position that accepts s byte values is
+// priced at s/64; a longer prefix must at least halve the estimate to be worth its extra alternatives: `Sher.*mes`
+// keeps `Sher`, `colou?r` takes `colo[ur]` + ...).  Gives up (npos = 0) if the alternatives do not fit the scan
+// kernel's matcher or do not look selective: every alternative must have at least three positions that accept at
+// most two byte values (`Sher`, `[Ss][Hh][Ee]`; not `\\w\\w\\w`), or a hot filter on them would fire everywhere.
+void find_prefix(const Dfa& ad, const std::vector<uint8_t>& rep, const uint8_t (&class_of)[256], uint32_t kmax, ClassExpr* out) {
+  *out = ClassExpr{};
+  const uint32_t ncls = (uint32_t)rep.size();
+  std::vector<ByteSet> class_bytes(ncls, ByteSet{});
+  for (uint32_t b = 0; b < 256; ++b) set_add(class_bytes[class_of[b]], b);
+  double best = 1e300;
+  for (uint32_t k = 3; k <= kmax; ++k) {
+    struct Path {
+      uint32_t state;
+      std::vector<ByteSet> seq;
+    };
+    std::vector<Path> paths{{ad.start, {}}};
+    bool ok = true;
+    for (uint32_t depth = 0; depth < k && ok; ++depth) {
+      std::vector<Path> next;
+      for (const Path& pa : paths) {
+        std::map<uint32_t, ByteSet> by_target;
+        for (uint32_t c = 0; c < ncls; ++c) {
+          const uint32_t t = ad.rows[pa.state][c];
+          if (t == 0) continue;
+          ByteSet& bs = by_target[t];
+          for (int q = 0; q < 8; ++q) bs[q] |= class_bytes[c][q];
+        }
+        for (const auto& kv : by_target) {
+          Path np{kv.first, pa.seq};
+          np.seq.push_back(kv.second);
+          next.push_back(std::move(np));
+        }
+        if (next.size() > 64) {
+          ok = false;
+          break;
+        }
+      }
+      paths.swap(next);
+    }
+    if (!ok || paths.empty()) break;  // longer prefixes only have more paths
+    std::vector<std::vector<ByteSet>> alts;
+    for (const Path& pa : paths) alts.push_back(pa.seq);
+    ClassExpr ex;
+    if (!class_expr_from_alternatives(std::move(alts), &ex)) continue;
+    bool selective = true;
+    double rate = 0;
+    for (const auto& a : ex.alts) {
+      uint32_t narrow = 0;
+      double pr = 1;
+      for (const ByteSet& st : a) {
+        narrow += set_size(st) <= 2;
+        pr *= std::min(1.0, set_size(st) / 64.0);
+      }
+      selective = selective && narrow >= 3;
+      rate += pr;
+    }
+    if (!selective || rate > 0.5 * best) continue;
+    best = rate;
+    *out = std::move(ex);
+  }
+}
+
 }  // namespace
 
 bool compile_regex_dfa(const uint8_t* re, size_t n, bool ignore_case, RegexDfa* out, std::string* err) {
@@ -460,11 +525,14 @@ bool compile_regex_dfa(const uint8_t* re, size_t n, bool ignore_case, RegexDfa* 
   }
   out->ncls = (uint32_t)rep.size();
 
-  Dfa fd, rd;
+  Dfa fd, rd, ad;
   if (!determinise(f, fstart, rep, true, &fd, err)) return false;
   if (!determinise(r, rentry, rep, false, &rd, err)) return false;
+  if (!determinise(f, fentry, rep, true, &ad, err)) return false;  // anchored: the expression without the loop in front
   if (!flatten(fd, out->ncls, &out->fwd, &out->fwd_states, &out->fwd_start, &out->fwd_first_acc, err)) return false;
   if (!flatten(rd, out->ncls, &out->rev, &out->rev_states, &out->rev_start, &out->rev_first_acc, err)) return false;
+  if (!flatten(ad, out->ncls, &out->anc, &out->anc_states, &out->anc_start, &out->anc_first_acc, err)) return false;
+  find_prefix(ad, rep, out->class_of, (uint32_t)std::min<uint64_t>(p.pool[root].minlen, 8), &out->prefix);
   out->minlen = (uint32_t)std::min<uint64_t>(p.pool[root].minlen, 0xffffffffu);
   out->ascii_only = p.ascii_only;
   return true;

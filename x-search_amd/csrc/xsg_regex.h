@@ -34,6 +34,8 @@
 #include <string>
 #include <vector>
 
+#include "xsg_classseq.h"
+
 namespace xsg {
 
 constexpr uint32_t kRxMaxStates = 4096;    // per automaton, before the table bound below
@@ -49,6 +51,16 @@ struct RegexDfa {
   uint32_t fwd_states = 0, fwd_start = 0, fwd_first_acc = 0;  // start / first_acc as STATE numbers
   uint32_t rev_states = 0, rev_start = 0, rev_first_acc = 0;
   uint32_t minlen = 0;       // shortest match, >= 1
+  // The ANCHORED forward automaton (no any-byte loop in front): from a position at which a match may start, it dies
+  // at once or runs to the end of the leftmost-first match that starts exactly there.  Same classes, same encoding.
+  std::vector<uint16_t> anc;
+  uint32_t anc_states = 0, anc_start = 0, anc_first_acc = 0;
+  // PREFILTER: every match starts with `prefix.npos` bytes that one of these class sequences accepts (read off the
+  // anchored automaton: its paths of that length, edges grouped by target state).  Empty (npos == 0) if the
+  // expression has no selective start (`\\w+ing`) or too many.  When present, the synchronous entry points find the
+  // candidate positions with the scan kernel's class-sequence matcher at streaming speed and run the anchored
+  // automaton at candidates only (csrc/xsg_rx_kernels.hip: k_rx_verify).
+  ClassExpr prefix;
   bool ascii_only = false;   // as ClassExpr::ascii_only: a search refuses data with a byte >= 0x80
   bool multiline = false;    // some set accepts '\n': matches may span lines ('\n' is then an ordinary byte for the automata)
 };

@@ -383,6 +383,88 @@ __global__ __launch_bounds__(kBlock) void k_rx_newlines(const ScanArgs A) {
   if (tid == 0) A.tile_nl[tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
+// ---------------------------------------------------------------------------
+// The prefilter route (xsg_regex.h: RegexDfa::prefix).  Every match starts with one of a few class sequences, so the
+// scan kernel's class-sequence matcher finds the CANDIDATE positions at streaming speed (k_scan<kClass>, count +
+// emit, xsg_api.cpp: rx_pre_matches) and the automaton only looks at those:
+//   k_rx_verify   one lane per candidate: the ANCHORED forward automaton from the candidate -> the length of the
+//                 leftmost-first match that starts exactly there, or 0.  (No reverse automaton: the start is known.)
+//   k_rx_keep     the reference's walk over the occurrences of a chunk (shift = match + match.size(),
+//                 search_wrappers.h:72-75): an occurrence is reported iff it starts at or behind the end of the
+//                 last reported one.  One lane per chunk, sequential -- occurrences are sparse where this route
+//                 is taken.
+//   k_rx_compact  the reported occurrences, packed: from here on the list is what k_rx_scan's emit pass would
+//                 have produced, and the shared list pipeline takes over.
+// Works for expressions that can match a newline as well (the chunk is the unit of the walk, which k_rx_keep is).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_rx_verify(const RxPreArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // the anchored table
+  __shared__ uint8_t s_cls[256];
+  const PatternDev P = A.pat;
+  const uint32_t tid = threadIdx.x;
+  s_cls[tid] = P.d_pat[tid] & (P.rx_skip ? 0x7fu : 0xffu);
+  {
+    const size_t rev_off = (256u + 2u * (size_t)P.rx_fwd_n + 15u) & ~(size_t)15u;
+    const size_t anc_off = (rev_off + 2u * (size_t)P.rx_rev_n + 15u) & ~(size_t)15u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.d_pat + anc_off);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
+    for (uint32_t k = tid; k < (P.rx_anc_n + 1u) / 2u; k += kBlock) dst[k] = src[k];
+  }
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + tid;
+  if (i >= A.n) return;
+  const ChunkDev ch = A.chunks[A.c_chunk[i]];
+  const uint8_t* d = A.base + ch.offset;
+  const uint16_t* anc = reinterpret_cast<const uint16_t*>(s_dyn);
+  const uint64_t p0 = A.c_pos[i];
+  uint64_t q = p0, end = 0;
+  uint32_t st = P.rx_anc_start;
+  while (q < ch.length) {
+    st = anc[st + s_cls[d[q]]];
+    if (st == 0) break;
+    ++q;
+    if (st >= P.rx_anc_acc) end = q;
+  }
+  A.c_len[i] = end ? (uint32_t)(end - p0 > 0xffffffffull ? 0xffffffffull : end - p0) : 0u;
+}
+
+__global__ void k_rx_keep(const RxPreArgs A) {
+  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= A.nchunks) return;
+  uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
+  r0 = r0 < A.n ? r0 : A.n;
+  r1 = r1 < A.n ? r1 : A.n;
+  uint64_t last_end = 0;
+  for (uint64_t i = r0; i < r1; ++i) {
+    const uint32_t len = A.c_len[i];
+    const uint64_t p = A.c_pos[i];
+    const bool k = len != 0 && p >= last_end;
+    A.c_keep[i] = k ? 1u : 0u;
+    if (k) last_end = p + len;
+  }
+}
+
+__global__ void k_rx_compact(const RxPreArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.n || !A.c_keep[i]) return;
+  const uint64_t dst = A.c_pre[i];
+  A.m_pos[dst] = A.c_pos[i];
+  A.m_chunk[dst] = A.c_chunk[i];
+}
+
+hipError_t launch_rx_verify_keep(const RxPreArgs& a, hipStream_t s) {
+  if (a.n) {
+    const size_t dyn = ((size_t)a.pat.rx_anc_n * 2u + 15u) & ~(size_t)15u;
+    hipLaunchKernelGGL(k_rx_verify, dim3((unsigned)((a.n + kBlock - 1) / kBlock)), dim3(kBlock), dyn, s, a);
+    hipLaunchKernelGGL(k_rx_keep, dim3((unsigned)((a.nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_rx_compact(const RxPreArgs& a, hipStream_t s) {
+  if (a.n) hipLaunchKernelGGL(k_rx_compact, dim3((unsigned)((a.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
 static dim3 rx_grid(uint64_t ntiles) {
   const uint64_t maxx = 1u << 30;
   if (ntiles <= maxx) return dim3((unsigned)ntiles, 1, 1);
