@@ -235,3 +235,37 @@ def test_every_match_starts_with_the_prefilter():
             assert prefix_accepts(sets, data[a:a + n]), (expr, icase, data[a:b])
         with_prefix += 1
     assert with_prefix > 50
+
+
+def test_walk_over_occurrences_by_heads_and_chains():
+    """the argument behind k_rx_heads / k_rx_chains (csrc/xsg_rx_kernels.hip), on a model: occurrences (start, length)
+    ascending by start; the sequential walk reports an occurrence iff it starts at or behind the end of the last
+    reported one.  In parallel: an occurrence that starts at or behind the end of EVERY earlier occurrence is a head
+    (reported, and nothing before it matters any more); each head's chain -- up to the next head -- is walked alone."""
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        n = int(rng.integers(0, 60))
+        pos = np.sort(rng.choice(400, size=n, replace=False)) if n else np.zeros(0, dtype=np.int64)
+        ln = rng.integers(0, 12, size=n) * (rng.random(n) < 0.8)  # 0 = the automaton found no match there
+        want, last = [], 0
+        for p, l in zip(pos, ln):
+            k = l > 0 and p >= last
+            want.append(bool(k))
+            if k:
+                last = p + l
+        ends = [int(p + l) if l else 0 for p, l in zip(pos, ln)]
+        run, head = 0, []
+        for p, e in zip(pos, ends):
+            head.append(e != 0 and p >= run)
+            run = max(run, e)
+        got = [False] * n
+        for i in range(n):
+            if not head[i]:
+                continue
+            got[i], last = True, ends[i]
+            j = i + 1
+            while j < n and not head[j]:
+                if ends[j] and pos[j] >= last:
+                    got[j], last = True, ends[j]
+                j += 1
+        assert got == want

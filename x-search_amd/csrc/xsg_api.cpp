@@ -1199,6 +1199,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     r.c_len = s->d_c_len.as<uint32_t>();
     r.c_keep = s->d_c_keep.as<uint32_t>();
     r.c_pre = s->d_c_pre.as<uint64_t>();
+    r.scan_tmp = s->d_scan_tmp.as<uint64_t>();
     HIP_TRY(launch_rx_verify_keep(r, st));
     HIP_TRY(launch_exclusive_scan_u32(r.c_keep, s->d_c_pre.as<uint64_t>(), Mc, s->d_scan_tmp.as<uint64_t>(), st));
     XSG_TRY(d2h_u64(c, s->d_c_pre.as<uint64_t>() + Mc, &M));

@@ -151,6 +151,7 @@ struct RxPreArgs {
   const uint32_t* c_chunk;
   uint32_t* c_len;           // length of the match that starts at the candidate, 0: none
   uint32_t* c_keep;          // reported by the reference's walk
+  uint64_t* scan_tmp;        // n / 2048 + 1 words
   const uint64_t* c_pre;     // exclusive prefix of c_keep
   uint64_t* m_pos;           // the reported ones, packed
   uint32_t* m_chunk;

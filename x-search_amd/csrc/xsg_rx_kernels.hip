@@ -389,10 +389,9 @@ __global__ __launch_bounds__(kBlock) void k_rx_newlines(const ScanArgs A) {
 // emit, xsg_api.cpp: rx_pre_matches) and the automaton only looks at those:
 //   k_rx_verify   one lane per candidate: the ANCHORED forward automaton from the candidate -> the length of the
 //                 leftmost-first match that starts exactly there, or 0.  (No reverse automaton: the start is known.)
-//   k_rx_keep     the reference's walk over the occurrences of a chunk (shift = match + match.size(),
-//                 search_wrappers.h:72-75): an occurrence is reported iff it starts at or behind the end of the
-//                 last reported one.  One lane per chunk, sequential -- occurrences are sparse where this route
-//                 is taken.
+//   k_rx_heads /  the reference's walk over the occurrences of a chunk (shift = match + match.size(),
+//   k_rx_chains   search_wrappers.h:72-75): an occurrence is reported iff it starts at or behind the end of the
+//                 last reported one -- resolved in parallel from a running maximum of the ends (below).
 //   k_rx_compact  the reported occurrences, packed: from here on the list is what k_rx_scan's emit pass would
 //                 have produced, and the shared list pipeline takes over.
 // Works for expressions that can match a newline as well (the chunk is the unit of the walk, which k_rx_keep is).
@@ -428,19 +427,116 @@ __global__ __launch_bounds__(kBlock) void k_rx_verify(const RxPreArgs A) {
   A.c_len[i] = end ? (uint32_t)(end - p0 > 0xffffffffull ? 0xffffffffull : end - p0) : 0u;
 }
 
-__global__ void k_rx_keep(const RxPreArgs A) {
-  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (c >= A.nchunks) return;
-  uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
-  r0 = r0 < A.n ? r0 : A.n;
-  r1 = r1 < A.n ? r1 : A.n;
-  uint64_t last_end = 0;
-  for (uint64_t i = r0; i < r1; ++i) {
-    const uint32_t len = A.c_len[i];
-    const uint64_t p = A.c_pos[i];
-    const bool k = len != 0 && p >= last_end;
-    A.c_keep[i] = k ? 1u : 0u;
-    if (k) last_end = p + len;
+// ---- the walk over the occurrences, in parallel ------------------------------------------------------------------
+// An occurrence is reported iff it starts at or behind the end of the last reported one.  Sequential as written, but
+// an occurrence that starts at or behind the end of EVERY earlier occurrence (reported or not) is reported whatever
+// happened before it, and the walk behind it does not depend on anything before it: a HEAD.  So: the running maximum
+// of the ends (one max-scan over all candidates; keys carry the chunk number in their upper bits, so a chunk's
+// occurrences never cover those of the next), heads from it, and the thread of each head walks its chain -- the
+// occurrences up to the next head, usually none or one.
+constexpr int kRxScanItems = 8;
+constexpr uint64_t kRxScanBlock = (uint64_t)kBlock * kRxScanItems;
+__device__ __forceinline__ uint64_t rx_key(uint32_t chunk, uint64_t off) { return ((uint64_t)chunk << 40) | off; }  // off < 2^40
+__device__ __forceinline__ uint64_t rx_end_key(const RxPreArgs& A, uint64_t i) {
+  const uint32_t len = A.c_len[i];
+  return len ? rx_key(A.c_chunk[i], A.c_pos[i] + len) : 0ull;
+}
+__device__ __forceinline__ uint64_t rx_block_max(uint64_t v, uint64_t* sh) {  // max over the block, valid in every thread
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const uint64_t o = (uint64_t)__shfl_xor((long long)v, s);
+    v = o > v ? o : v;
+  }
+  if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint64_t m = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) m = sh[w] > m ? sh[w] : m;
+  __syncthreads();
+  return m;
+}
+__global__ __launch_bounds__(kBlock) void k_rx_block_max(const RxPreArgs A, uint64_t* block_max) {
+  __shared__ uint64_t sh[kWaves];
+  const uint64_t b0 = (uint64_t)blockIdx.x * kRxScanBlock + (uint64_t)threadIdx.x * kRxScanItems;
+  uint64_t v = 0;
+#pragma unroll
+  for (int k = 0; k < kRxScanItems; ++k)
+    if (b0 + k < A.n) {
+      const uint64_t e = rx_end_key(A, b0 + k);
+      v = e > v ? e : v;
+    }
+  const uint64_t m = rx_block_max(v, sh);
+  if (threadIdx.x == 0) block_max[blockIdx.x] = m;
+}
+// exclusive running maximum of one value per thread over the block (in thread order); *total = the block's maximum
+__device__ __forceinline__ uint64_t rx_block_excl_max(uint64_t v, uint64_t* sh, uint64_t* total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint64_t incl = v;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const uint64_t o = (uint64_t)__shfl_up((long long)incl, s);
+    if (lane >= (uint32_t)s) incl = o > incl ? o : incl;
+  }
+  uint64_t excl = (uint64_t)__shfl_up((long long)incl, 1);
+  if (lane == 0) excl = 0;
+  if (lane == 63u) sh[wave] = incl;
+  __syncthreads();
+  uint64_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    if ((uint32_t)w < wave) before = sh[w] > before ? sh[w] : before;
+    all = sh[w] > all ? sh[w] : all;
+  }
+  __syncthreads();
+  *total = all;
+  return excl > before ? excl : before;
+}
+__global__ __launch_bounds__(kBlock) void k_rx_block_max_scan(uint64_t* block_max, uint64_t nb) {  // in place, one workgroup
+  __shared__ uint64_t sh[kWaves];
+  uint64_t carry = 0;
+  for (uint64_t i0 = 0; i0 < nb; i0 += kBlock) {
+    const uint64_t i = i0 + threadIdx.x;
+    const uint64_t v = i < nb ? block_max[i] : 0ull;
+    uint64_t tot;
+    const uint64_t ex = rx_block_excl_max(v, sh, &tot);
+    if (i < nb) block_max[i] = ex > carry ? ex : carry;
+    carry = tot > carry ? tot : carry;
+  }
+}
+// heads: flagged in `head` (1 / 0); c_keep is cleared for the chain walk
+__global__ __launch_bounds__(kBlock) void k_rx_heads(const RxPreArgs A, const uint64_t* block_max, uint32_t* head) {
+  __shared__ uint64_t sh[kWaves];
+  const uint64_t b0 = (uint64_t)blockIdx.x * kRxScanBlock + (uint64_t)threadIdx.x * kRxScanItems;
+  uint64_t e[kRxScanItems], tmax = 0;
+#pragma unroll
+  for (int k = 0; k < kRxScanItems; ++k) {
+    e[k] = b0 + k < A.n ? rx_end_key(A, b0 + k) : 0ull;
+    tmax = e[k] > tmax ? e[k] : tmax;
+  }
+  uint64_t tot;
+  uint64_t run = rx_block_excl_max(tmax, sh, &tot);
+  const uint64_t bm = block_max[blockIdx.x];
+  run = bm > run ? bm : run;
+#pragma unroll
+  for (int k = 0; k < kRxScanItems; ++k) {
+    if (b0 + k < A.n) {
+      head[b0 + k] = (e[k] != 0 && rx_key(A.c_chunk[b0 + k], A.c_pos[b0 + k]) >= run) ? 1u : 0u;
+      A.c_keep[b0 + k] = 0u;
+    }
+    run = e[k] > run ? e[k] : run;
+  }
+}
+__global__ void k_rx_chains(const RxPreArgs A, const uint32_t* head) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.n || !head[i]) return;
+  uint64_t last_end = rx_end_key(A, i);
+  A.c_keep[i] = 1u;
+  for (uint64_t j = i + 1; j < A.n && !head[j]; ++j) {  // up to the next head: its own thread's business
+    const uint64_t e = rx_end_key(A, j);
+    if (e != 0 && rx_key(A.c_chunk[j], A.c_pos[j]) >= last_end) {
+      A.c_keep[j] = 1u;
+      last_end = e;
+    }
   }
 }
 
@@ -456,7 +552,12 @@ hipError_t launch_rx_verify_keep(const RxPreArgs& a, hipStream_t s) {
   if (a.n) {
     const size_t dyn = ((size_t)a.pat.rx_anc_n * 2u + 15u) & ~(size_t)15u;
     hipLaunchKernelGGL(k_rx_verify, dim3((unsigned)((a.n + kBlock - 1) / kBlock)), dim3(kBlock), dyn, s, a);
-    hipLaunchKernelGGL(k_rx_keep, dim3((unsigned)((a.nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
+    const uint64_t nb = (a.n + kRxScanBlock - 1) / kRxScanBlock;
+    hipLaunchKernelGGL(k_rx_block_max, dim3((unsigned)nb), dim3(kBlock), 0, s, a, a.scan_tmp);
+    uint32_t* head = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(a.c_pre));  // free until the scan of c_keep writes it
+    hipLaunchKernelGGL(k_rx_block_max_scan, dim3(1), dim3(kBlock), 0, s, a.scan_tmp, nb);
+    hipLaunchKernelGGL(k_rx_heads, dim3((unsigned)nb), dim3(kBlock), 0, s, a, (const uint64_t*)a.scan_tmp, head);
+    hipLaunchKernelGGL(k_rx_chains, dim3((unsigned)((a.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, (const uint32_t*)head);
   }
   return hipGetLastError();
 }
