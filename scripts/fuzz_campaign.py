@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long differential fuzz run of the HIP path against the oracle (the same generators as
-tests/test_gpu_fuzz.py and, every third seed, tests/test_gpu_regex.py; many more seeds).  Runs for --minutes, prints a progress line
+tests/test_gpu_fuzz.py and, every third seed each, the class-sequence and the variable-length rounds of
+tests/test_gpu_regex.py; many more seeds).  Runs for --minutes, prints a progress line
 every few seeds, stops at the first difference (the assertion message reproduces it).
 Result summary -> gpurun_out/fuzz_campaign.json."""
 import argparse
@@ -15,7 +16,7 @@ for d in ("", "x-search_amd", "oracle", "tests"):
 import xs_oracle  # noqa: E402
 from gpu_util import GpuSearch  # noqa: E402
 from test_gpu_fuzz import fuzz_rounds  # noqa: E402
-from test_gpu_regex import regex_rounds  # noqa: E402
+from test_gpu_regex import regex_rounds, rx_rounds  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=8.0)
@@ -35,6 +36,11 @@ while time.time() - t0 < a.minutes * 60:
         fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000 if seed % 4 else 600000)
         if seed % 3 == 0:
             regex_rounds(seed, oracle, gs, rounds=10)
+        if seed % 3 == 1:  # variable-length expressions: the automaton route, prefilter on (default) / off per seed
+            import os
+            os.environ["XSG_RX_PRE"] = "0" if seed % 2 else "1"
+            rx_rounds(seed, oracle, gs, rounds=6)
+            os.environ.pop("XSG_RX_PRE")
     except AssertionError as e:
         status["failed"] = {"seed": seed, "message": str(e)[:2000]}
         print("FAIL", seed, str(e)[:2000], flush=True)

@@ -56,60 +56,67 @@ __device__ __forceinline__ uint32_t rx_class(const RxCtx& X, uint64_t q) {
 
 // One line, from its start `cur` (chunk-relative): the reference's walk restricted to the line.  Returns the number
 // of matches (LINES: 1 if there is any).  EMITTING: their start offsets go to m_pos[rank...], rank advances.
+// Positions inside the tile are 32-bit and tile-relative (`rel`); a line that leaves the tile continues through
+// global memory with 64-bit offsets, byte by byte (rare: one line per tile at most).
 template <bool EMITTING, bool LINES>
 __device__ __forceinline__ uint32_t rx_walk_line(const RxCtx& X, uint64_t cur, const ScanArgs& A, uint32_t chunk,
                                                  uint64_t& rank) {
   uint32_t n = 0;
   for (;;) {
     uint32_t st = X.fwd_start;
-    uint64_t q = cur, last_end = 0;  // a match ends behind at least one byte: 0 = none yet
-    bool stop = false;               // the state died, or (LINES) a match was seen
-    while (!stop && q < X.L) {
-      const uint64_t rel64 = q - X.toff;
-      if (rel64 >= kRxTile) {  // the line has left the tile: byte by byte through global memory
-        st = X.fwd[st + (X.cls[X.cbase[q]] & X.cmask)];
-        if (st == 0) break;
-        ++q;
-        if (st >= X.fwd_acc) {
-          last_end = q;
-          if (LINES) break;
-        }
-        continue;
-      }
-      uint32_t rel = (uint32_t)rel64;
-      // In its start state the automaton only waits for a byte that can begin a match: every other byte leaves it
-      // where it is.  Those bytes (and '\n') are the tile's TRIGGERS, flagged for all 16 KiB at once in the staging
-      // phase; the walk jumps from one to the next on the bit masks instead of stepping through the text.
-      if (X.skip && st == X.fwd_start) {
-        uint32_t w = rel >> 6;
-        unsigned long long m = X.trig[w] & (~0ull << (rel & 63u));
-        while (!m && ++w < (uint32_t)kBlock) m = X.trig[w];
-        if (!m) {  // none left in the tile (the line runs on behind it)
-          q = X.toff + kRxTile;
-          continue;
-        }
-        rel = w * kRxSeg + (uint32_t)__builtin_ctzll(m);
-        q = X.toff + rel;
-      }
-      // the class codes of four bytes with one read; bytes at or beyond L are '\n' here, which kills every state
-      const uint32_t cw = X.tilew[rx_addr(rel & ~3u) >> 2];
-      uint32_t sh = 8u * (rel & 3u);
-      do {
-        st = X.fwd[st + ((cw >> sh) & X.cmask)];
-        if (st == 0) {
-          stop = true;  // dead: the line ended, or nothing can outrank the match already seen
-          break;
-        }
-        ++q;
-        sh += 8u;
-        if (st >= X.fwd_acc) {
-          last_end = q;
-          if (LINES) {
-            stop = true;  // any match makes the line a matching line
+    uint64_t last_end = 0;  // a match ends behind at least one byte: 0 = none yet
+    bool stop = false;      // the state died, or (LINES) a match was seen
+    uint64_t q = cur;
+    if (cur - X.toff < kRxTile) {
+      uint32_t rel = (uint32_t)(cur - X.toff);
+      uint32_t last_rel = 0;
+      while (rel < kRxTile) {
+        // In its start state the automaton only waits for a byte that can begin a match: every other byte leaves it
+        // where it is.  Those bytes (and '\n') are the tile's TRIGGERS, flagged for all 16 KiB at once in the staging
+        // phase; the walk jumps from one to the next on the bit masks instead of stepping through the text.
+        if (X.skip && st == X.fwd_start) {
+          uint32_t w = rel >> 6;
+          unsigned long long m = X.trig[w] & (~0ull << (rel & 63u));
+          while (!m && ++w < (uint32_t)kBlock) m = X.trig[w];
+          if (!m) {  // none left in the tile (the line runs on behind it)
+            rel = kRxTile;
             break;
           }
+          rel = w * kRxSeg + (uint32_t)__builtin_ctzll(m);
         }
-      } while (sh < 32u && !(X.skip && st == X.fwd_start));
+        // the class codes of four bytes with one read; bytes at or beyond L are '\n' here, which kills every state
+        // The four steps are straight-line and predicated instead of leaving the loop one lane at a time (the exec-mask
+        // bookkeeping of a divergent exit per byte cost more than the step): a lane that is dead stays dead -- row 0
+        // of the table is all zeros --, a lane whose dword started in the middle sits out the last steps.  Stepping on
+        // in the start state to the end of the dword is harmless (skipping is an optimisation, not a condition).
+        uint32_t cw = X.tilew[(rel >> 2) + (rel >> 6)] >> (8u * (rel & 3u));  // = rx_addr(rel & ~3) / 4
+        const uint32_t nsteps = 4u - (rel & 3u);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+          const uint32_t nst = X.fwd[st + (cw & X.cmask)];
+          cw >>= 8u;
+          const bool on = k < nsteps && st != 0u;
+          st = on ? nst : st;
+          const bool moved = on && nst != 0u;
+          rel += moved ? 1u : 0u;
+          last_rel = (moved && nst >= X.fwd_acc) ? rel : last_rel;
+        }
+        if (st == 0u || (LINES && last_rel != 0u)) {  // dead (the line ended, or nothing can outrank the match seen); a matching line
+          stop = true;
+          break;
+        }
+      }
+      q = X.toff + rel;
+      if (last_rel) last_end = X.toff + last_rel;
+    }
+    while (!stop && q < X.L) {  // behind the tile
+      st = X.fwd[st + (X.cls[X.cbase[q]] & X.cmask)];
+      if (st == 0) break;
+      ++q;
+      if (st >= X.fwd_acc) {
+        last_end = q;
+        if (LINES) break;
+      }
     }
     if (!last_end) break;  // no (further) match in this line
     ++n;
