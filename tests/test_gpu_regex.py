@@ -327,3 +327,17 @@ def test_both_routes_of_the_automaton_family_agree(gs, oracle, monkeypatch):
                 res.append(check(gs, oracle, blocks, expr, icase, f"pre={pre}"))
             assert res[0] == res[1] and res[0] is not None
     monkeypatch.delenv("XSG_RX_PRE")
+
+
+def test_prefilter_gives_way_when_candidates_run_far(gs, oracle):
+    """`aaa+` on a long run of `a`: every position of the run is a candidate and would scan to its end -- the
+    verification pass has a budget per candidate, and when one outruns it the search is redone by walking the text
+    once (k_rx_scan).  Same answers either way."""
+    run = np.full(300_000, ord("a"), dtype=np.uint8)
+    blocks = [np.concatenate([run, np.frombuffer(b"\nxaaay aaaa b\n", dtype=np.uint8), run[:5000], np.frombuffer(b"\n", dtype=np.uint8)]),
+              corpus.text_block(3, 0, 100_000)]
+    gs.bind(blocks)
+    for expr in (b"aaa+", b"aaa+b?", b"xaa+y"):
+        assert xsg.regex_prefix(expr)[0] >= 3
+        want = check(gs, oracle, blocks, expr, False, "budget")
+        assert want is not None and want["count_matches"] >= 1

@@ -1142,7 +1142,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   XSG_TRY(choose_hot_filter(s, st));
   XSG_TRY(prepare_tiles(s, false, st));
   ScanArgs a = scan_args(s);
-  const bool pre = c->pat.kind == kDfa && c->rx_pre;  // candidates by the class-sequence matcher, then the automaton
+  const bool pre = c->pat.kind == kDfa && c->rx_pre && !s->pre_off;  // candidates by the class-sequence matcher, then the automaton
   if (pre) {
     a.pat = c->pre_pat;
     a.pat.hot = 0;
@@ -1212,9 +1212,20 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     r.c_keep = s->d_c_keep.as<uint32_t>();
     r.c_pre = s->d_c_pre.as<uint64_t>();
     r.scan_tmp = s->d_scan_tmp.as<uint64_t>();
+    r.flags = a.flags;
     HIP_TRY(launch_rx_verify_keep(r, st));
     HIP_TRY(launch_exclusive_scan_u32(r.c_keep, s->d_c_pre.as<uint64_t>(), Mc, s->d_scan_tmp.as<uint64_t>(), st));
+    uint32_t vflags = 0;
+    HIP_TRY(hipMemcpyAsync(&vflags, a.flags, 4, hipMemcpyDeviceToHost, st));
     XSG_TRY(d2h_u64(c, s->d_c_pre.as<uint64_t>() + Mc, &M));
+    if (vflags & 2u) {  // a candidate outran the verification budget: walk the text once instead (the other route)
+      HIP_TRY(hipMemsetAsync(a.flags, 0, 4, st));
+      s->cnt_clean = false;
+      s->pre_off = true;
+      const int rr = run_list(s, mode, outputs);
+      s->pre_off = false;
+      return rr;
+    }
     XSG_TRY(s->d_m_pos.ensure(8 * std::max<uint64_t>(M, 1)));
     XSG_TRY(s->d_m_chunk.ensure(4 * std::max<uint64_t>(M, 1)));
     r.m_pos = s->d_m_pos.as<uint64_t>();

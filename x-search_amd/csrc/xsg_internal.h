@@ -152,6 +152,7 @@ struct RxPreArgs {
   uint32_t* c_len;           // length of the match that starts at the candidate, 0: none
   uint32_t* c_keep;          // reported by the reference's walk
   uint64_t* scan_tmp;        // n / 2048 + 1 words
+  uint32_t* flags;           // ScanArgs::flags; bit 1: a candidate outran k_rx_verify's budget (the host takes the other route)
   const uint64_t* c_pre;     // exclusive prefix of c_keep
   uint64_t* m_pos;           // the reported ones, packed
   uint32_t* m_chunk;

@@ -137,6 +137,7 @@ struct xsg_shard {
   bool begin_sync_result = false;  // xsg_count_begin had to run synchronously: _end hands out begin_counters
   uint64_t begin_counters[XSG_NUM_COUNTERS] = {0, 0, 0, 0};
 
+  bool pre_off = false;        // run_list: this call must not take the prefilter route (its verification budget ran out)
   bool want_nl_total = false;  // run_list: also leave the shard's newline total in last_newlines (xsg_count on the prefilter route)
   int last_mode = -1;
   uint64_t last_raw_matches = 0;  // raw occurrences of the last list pass (capacity hint for xsg_count_async, bordered patterns)

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(kBlock) void k_rx_newlines(const ScanArgs A) {
 //                 have produced, and the shared list pipeline takes over.
 // Works for expressions that can match a newline as well (the chunk is the unit of the walk, which k_rx_keep is).
 // ---------------------------------------------------------------------------
+constexpr uint64_t kRxVerifyBudget = 4096;
 __global__ __launch_bounds__(kBlock) void k_rx_verify(const RxPreArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // the anchored table
   __shared__ uint8_t s_cls[256];
@@ -425,13 +426,19 @@ __global__ __launch_bounds__(kBlock) void k_rx_verify(const RxPreArgs A) {
   const uint64_t p0 = A.c_pos[i];
   uint64_t q = p0, end = 0;
   uint32_t st = P.rx_anc_start;
-  while (q < ch.length) {
+  // A budget per candidate: an expression that runs far from every candidate (`aaa+` on a megabyte of `a`: every
+  // position is a candidate and scans to the end of the run) would make this pass quadratic where walking the text
+  // once (k_rx_scan, k_rx_chunk) is linear.  A candidate still alive after kRxVerifyBudget bytes raises flag bit 1
+  // and the host redoes the search on the other route.
+  const uint64_t stop_at = ch.length - p0 > kRxVerifyBudget ? p0 + kRxVerifyBudget : ch.length;
+  while (q < stop_at) {
     st = anc[st + s_cls[d[q]]];
     if (st == 0) break;
     ++q;
     if (st >= P.rx_anc_acc) end = q;
   }
-  A.c_len[i] = end ? (uint32_t)(end - p0 > 0xffffffffull ? 0xffffffffull : end - p0) : 0u;
+  if (st != 0 && q < ch.length) atomicOr(A.flags, 2u);
+  A.c_len[i] = end ? (uint32_t)(end - p0) : 0u;
 }
 
 // ---- the walk over the occurrences, in parallel ------------------------------------------------------------------
