@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--e2e-gib", type=float, default=4.0,
                     help="size of the tmpfs file of the end-to-end (file -> result) leg; 0 = skip")
     ap.add_argument("--no-tune", action="store_true", help="keep the per-variant default stagger")
+    ap.add_argument("--no-regex", action="store_true", help="skip the regex leg (N=1: a few expressions on the resident shard)")
     return ap.parse_args()
 
 
@@ -312,6 +313,32 @@ def _allreduce_max_host(dist, x: float) -> float:
     return max(objs)
 
 
+def regex_leg(xsg, torch, ctx, shard, stream, shard_bytes):
+    """The regex row on the resident shard, N=1 only, reported next to the headline (never `value`):
+    whole synchronous xsg_count calls per expression -- class sequences inside k_scan, variable-length expressions on
+    the automaton route (prefilter where the expression starts selectively, k_rx_scan otherwise).  Every count is
+    cross-checked between the two device routes that can serve it: the synchronous call and xsg_count_async."""
+    out = []
+    c = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device=f"cuda:{torch.cuda.current_device()}")
+    for expr in ("She[r ]lock", "[Ss]herlock", "Sherlock|Holmes", "Sher.*mes", "colou?r", "\\w+ing"):
+        ctx.set_pattern(expr.encode(), xsg.FLAG_REGEX)
+        got = int(shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])  # warm-up (also settles the hot filter)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            got = int(shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        shard.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
+        torch.cuda.synchronize()
+        other = int(c[xsg.CTR_MATCHES])
+        if other != got:
+            raise SystemExit(f"regex PARITY FAILURE: {expr!r}: xsg_count {got} != xsg_count_async {other}")
+        out.append({"expr": expr, "matches": got, "ms_per_call": round(ms, 3), "gbs": round(shard_bytes / ms / 1e6, 1),
+                    "frac_of_hbm_peak": round(shard_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                    "kernel": shard.scan_kernel_name(xsg.COUNT_MATCHES)})
+    return {"what": "whole synchronous xsg_count(COUNT_MATCHES) calls with XSG_FLAG_REGEX on the same resident shard; "
+                    "each count equals the one xsg_count_async computes on its own route", "cases": out}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -555,6 +582,11 @@ def main():
                              f"(separate runs; not measured in this run)"
             break
 
+    regex = None
+    if world == 1 and not args.no_regex:
+        regex = regex_leg(xsg, torch, ctx, shard, stream, shard_bytes)
+        ctx.set_pattern(pattern)
+
     e2e = None
     if args.e2e_gib > 0:
         e2e = e2e_leg(args, blocks, pattern, tcount, rank, world, dist, dev_index)
@@ -608,6 +640,8 @@ def main():
                 "algorithmic_bytes_per_launch": shard_bytes,
             },
         }
+        if regex is not None:
+            line["regex"] = regex
         if e2e is not None:
             line["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline:

@@ -25,12 +25,12 @@ ap.add_argument("--hot", type=int, default=-1, help="pin the hot filter of the w
 a = ap.parse_args()
 oracle = xs_oracle.Oracle()
 searchers = {0: GpuSearch(hot=0), 1: GpuSearch(hot=1), 2: GpuSearch(probe=True)}
-t0 = time.time()
+t0 = time.monotonic()
 seed = a.first_seed
 out = ROOT / "gpurun_out" / "fuzz_campaign.json"
 out.parent.mkdir(exist_ok=True)
 status = {"first_seed": a.first_seed, "seeds_done": 0, "failed": None, "hot": a.hot}
-while time.time() - t0 < a.minutes * 60:
+while time.monotonic() - t0 < a.minutes * 60:
     gs = searchers[a.hot if a.hot >= 0 else seed % 3]
     try:
         fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000 if seed % 4 else 600000)
@@ -47,7 +47,7 @@ while time.time() - t0 < a.minutes * 60:
         break
     seed += 1
     status["seeds_done"] = seed - a.first_seed
-    status["elapsed_s"] = round(time.time() - t0, 1)
+    status["elapsed_s"] = round(time.monotonic() - t0, 1)
     if (seed - a.first_seed) % 5 == 0:
         print(json.dumps(status), flush=True)
         out.write_text(json.dumps(status) + "\n")

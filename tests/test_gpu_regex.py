@@ -258,6 +258,38 @@ def test_variable_length_ascii_only_refusal_and_job_api(gs, oracle, tmp_path):
     assert j.result().tolist() == want2["match_byte_offsets"]
 
 
+def oracle_is_quick(oracle, blocks, expr, icase, seconds=3):
+    """CPython's `re` -- the oracle's stand-in for RE2 -- backtracks; a random expression with ambiguous alternatives
+    under a loop (`([ab]|a)+c`) can take exponential time where the product's automata are linear.  Such an
+    expression is no use as a test case: found out here, under an alarm, before the GPU is asked."""
+    import signal
+    from xs_oracle import RegexProgram, UnsupportedRegex, compile_class_sequence
+
+    class TooSlow(Exception):
+        pass
+
+    def on_alarm(*_):
+        raise TooSlow()
+
+    try:
+        compile_class_sequence(expr, icase)
+        return True  # a class sequence: the C oracle, no backtracking
+    except UnsupportedRegex:
+        pass
+    prog = RegexProgram(expr, icase)
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(seconds)
+    try:
+        for b in blocks:
+            oracle.rx_byte_offsets(b, prog, False)
+        return True
+    except TooSlow:
+        return False
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+
+
 def rx_rounds(seed, oracle, gs, rounds=12):
     rng = np.random.default_rng(9000 + seed)
     sizes = [0, 1, 63, 64, 65, 1023, 1024, 1025, 16383, 16384, 16385, 32769]
@@ -280,6 +312,8 @@ def rx_rounds(seed, oracle, gs, rounds=12):
             try:
                 xsg.regex_check(expr, xsg.FLAG_IGNORE_CASE if icase else 0)
             except xsg.XsgError:
+                continue
+            if not oracle_is_quick(oracle, blocks, expr, icase):
                 continue
             check(gs, oracle, blocks, expr, icase, f"seed={seed} it={it} sizes={[b.size for b in blocks]}")
             done += 1
@@ -329,7 +363,7 @@ def test_both_routes_of_the_automaton_family_agree(gs, oracle, monkeypatch):
     monkeypatch.delenv("XSG_RX_PRE")
 
 
-def test_prefilter_gives_way_when_candidates_run_far(gs, oracle):
+def test_prefilter_gives_way_when_candidates_run_far(gs, oracle, monkeypatch):
     """`aaa+` on a long run of `a`: every position of the run is a candidate and would scan to its end -- the
     verification pass has a budget per candidate, and when one outruns it the search is redone by walking the text
     once (k_rx_scan).  Same answers either way."""
@@ -337,6 +371,7 @@ def test_prefilter_gives_way_when_candidates_run_far(gs, oracle):
     blocks = [np.concatenate([run, np.frombuffer(b"\nxaaay aaaa b\n", dtype=np.uint8), run[:5000], np.frombuffer(b"\n", dtype=np.uint8)]),
               corpus.text_block(3, 0, 100_000)]
     gs.bind(blocks)
+    monkeypatch.setenv("XSG_RX_PRE", "1")  # by default shards this small are walked by k_rx_scan in the first place
     for expr in (b"aaa+", b"aaa+b?", b"xaa+y"):
         assert xsg.regex_prefix(expr)[0] >= 3
         want = check(gs, oracle, blocks, expr, False, "budget")

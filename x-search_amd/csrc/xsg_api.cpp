@@ -332,6 +332,7 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   // (rx_pre_matches); xsg_count_async, which may not wait for the host, keeps k_rx_scan.  XSG_RX_PRE=0 switches it off.
   const char* pre_env = getenv("XSG_RX_PRE");
   c->rx_pre = dfa.prefix.npos != 0 && !(pre_env && *pre_env == '0');
+  c->rx_pre_forced = pre_env && *pre_env == '1';  // on shards of any size (tests; by default only where it pays, use_prefilter)
   if (c->rx_pre) {
     std::vector<uint8_t> pblob;
     class_fields(dfa.prefix, false, &c->pre_pat, &pblob);  // the sets are closed under case already: no folding
@@ -554,6 +555,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   // whatever was derived from the old binding's bytes is void
   s->nl_cached = s->nl_off_cached = false;
   s->hot_serial = 0;
+  s->pre_dense_serial = 0;
   bool grew = false;
   XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
   XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
@@ -928,6 +930,13 @@ extern "C" int xsg_count_async(xsg_shard* s, uint32_t mode, void* stream, uint64
 }
 
 static int run_list(xsg_shard* s, uint32_t mode, bool outputs);
+// The prefilter route is half a dozen kernels and three trips to the host where k_rx_scan is one pass: it pays on
+// shards where a pass takes longer than that (the file pipeline's 16 MiB chunks are walked by k_rx_scan in tens of
+// microseconds).
+static bool use_prefilter(const xsg_shard* s) {
+  const xsg_ctx* c = s->ctx;
+  return c->pat.kind == kDfa && c->rx_pre && !s->pre_off && (c->rx_pre_forced || s->total_bytes >= (512ull << 20));
+}
 constexpr int kDenseCandidates = 1;  // run_list(outputs = false) on the prefilter route: too many candidates, count by k_rx_scan
 
 extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_COUNTERS]) {
@@ -937,7 +946,7 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   if (m != XSG_COUNT_MATCHES && m != XSG_COUNT_LINES) return fail(XSG_EINVAL, "mode %u is not a count mode", m);
-  if (c->pat.kind == kDfa && c->rx_pre) {
+  if (use_prefilter(s) && s->pre_dense_serial != c->pattern_serial) {  // (not again where the candidates were found dense)
     // the prefilter route of the automaton family: candidates, verification and the walk produce the list; its
     // length is the count (the newline total, if asked for, comes from the cached per-tile counts)
     if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
@@ -995,7 +1004,7 @@ extern "C" int xsg_count_begin(xsg_shard* s, uint32_t mode) {
   if (m != XSG_COUNT_MATCHES && m != XSG_COUNT_LINES) return fail(XSG_EINVAL, "mode %u is not a count mode", m);
   if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
   s->begin_sync_result = false;
-  if ((m == XSG_COUNT_MATCHES && c->bordered) || (c->pat.kind == kDfa && c->rx_pre)) {  // needs the ordered list: done synchronously, handed out by _end
+  if ((m == XSG_COUNT_MATCHES && c->bordered) || (use_prefilter(s) && s->pre_dense_serial != c->pattern_serial)) {  // needs the ordered list: done synchronously, handed out by _end
     XSG_TRY(xsg_count(s, mode, s->begin_counters));
     s->begin_sync_result = true;
     return XSG_OK;
@@ -1061,7 +1070,7 @@ extern "C" int xsg_scan_kernel_name(xsg_shard* s, uint32_t mode, char* out, size
   // what the FIRST pass of this mode launches on this shard right now (newline counts already cached -> plain kernel)
   const bool want_nl = ((mode & XSG_WITH_NEWLINES) != 0 || m == XSG_LINE_INDICES) && !s->nl_cached;
   ScanArgs a = scan_args(s);
-  if (a.pat.kind == kDfa && s->ctx->rx_pre) {  // what xsg_count / xsg_search launch: the candidate scan, then the automaton at candidates
+  if (use_prefilter(s)) {  // what xsg_count / xsg_search launch: the candidate scan, then the automaton at candidates
     a.pat = s->ctx->pre_pat;
     a.pat.hot = 0;
     char inner[160];
@@ -1142,7 +1151,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   XSG_TRY(choose_hot_filter(s, st));
   XSG_TRY(prepare_tiles(s, false, st));
   ScanArgs a = scan_args(s);
-  const bool pre = c->pat.kind == kDfa && c->rx_pre && !s->pre_off;  // candidates by the class-sequence matcher, then the automaton
+  const bool pre = use_prefilter(s);  // candidates by the class-sequence matcher, then the automaton
   if (pre) {
     a.pat = c->pre_pat;
     a.pat.hot = 0;
@@ -1181,8 +1190,9 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     // lines once (k_rx_scan + finish, no list at all) than by listing, verifying and packing tens of millions of
     // entries -- measured on the bench corpus, where `Sher` is a lexicon word: count_lines of `lock(ed|s)?` 18 ms
     // by candidates against 10 ms by k_rx_scan (8 GiB).  The caller takes the other route.
-    if (!outputs && !c->pat.rx_multiline && M * 512 > s->total_bytes) {
+    if (!outputs && !c->pat.rx_multiline && M * 128 > s->total_bytes) {
       s->cnt_clean = false;
+      s->pre_dense_serial = c->pattern_serial;  // later counts of this pattern on this binding go straight to k_rx_scan
       return kDenseCandidates;
     }
     // M candidates so far: emit them, run the anchored automaton at each, walk every chunk's occurrences as the

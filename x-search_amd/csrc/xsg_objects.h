@@ -77,6 +77,7 @@ struct xsg_ctx {
   DevBuf d_pat;
   // kDfa with a selective start (xsg_regex.h: RegexDfa::prefix): the class-sequence pattern that finds the candidates
   bool rx_pre = false;
+  bool rx_pre_forced = false;  // XSG_RX_PRE=1: on shards of any size
   xsg::PatternDev pre_pat{};
   DevBuf d_pre;
   uint32_t tile_bytes = xsg::kDefaultTileBytes;  // geometry new shards get (XSG_TILE_KIB)
@@ -137,6 +138,7 @@ struct xsg_shard {
   bool begin_sync_result = false;  // xsg_count_begin had to run synchronously: _end hands out begin_counters
   uint64_t begin_counters[XSG_NUM_COUNTERS] = {0, 0, 0, 0};
 
+  uint64_t pre_dense_serial = 0;  // the ctx->pattern_serial whose prefilter candidates were found dense on this binding (0: none)
   bool pre_off = false;        // run_list: this call must not take the prefilter route (its verification budget ran out)
   bool want_nl_total = false;  // run_list: also leave the shard's newline total in last_newlines (xsg_count on the prefilter route)
   int last_mode = -1;
