@@ -910,17 +910,13 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A) {
   }
 }
 
-// The kernel proper.  Two entry points over the same body: the class-sequence kinds keep sixteen lane masks and the
-// window dwords in scalar registers and took all 106 SGPRs the compiler may use -- 7 waves per SIMD instead of 8
-// (800 SGPRs per SIMD) on a kernel that hides its loads by occupancy.  Told to fit 8 waves (78 SGPRs, a dozen more
-// spilled to VGPR lanes) they gained 7-15 % on the 50 GiB shard (`She[r ]lock` 5.4 -> 6.1 TB/s, `[Ss]herlock` 7.0 ->
-// 7.3); the same request cost the byte-parallel kinds 3-4 %, so it is made for the class kinds only.
+// The kernel proper.  (Round 2 also measured an occupancy request for the class-sequence kinds -- they keep sixteen
+// lane masks and the window dwords in scalar registers and take all 106 SGPRs the compiler may use, 7 waves per SIMD
+// instead of 8; `amdgpu_waves_per_eu(8, 8)` brings them to 78 SGPRs and a dozen more spills.  Three builds, two
+// interleaved rounds on one box, 50 GiB: no gain for `She[r ]lock` (5.29 against 5.36 TB/s), a loss for `[Ss]herlock`
+// and `[0-9]{4}-[0-9]{2}` (6.50 against 6.88, 6.52 against 6.94): not adopted.  scripts/ab_waves.sh.)
 template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, int LOADS, bool ICASE, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
-  scan_tile<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE, ALIGNED>(A);
-}
-template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, int LOADS, bool ICASE, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_scan_cls(const ScanArgs A) {
   scan_tile<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE, ALIGNED>(A);
 }
 
@@ -928,13 +924,7 @@ template <int KIND, bool ICASE, bool ALIGNED>
 static hipError_t launch_scan_kind(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, dim3 grid,
                                    hipStream_t s) {
   constexpr int LOADS = 4;  // 16 KiB tiles (32 KiB measured 8 % slower)
-#define KSCAN_LAUNCH(NL, LINES, EM)                                                                                   \
-  do {                                                                                                                \
-    if constexpr (is_cls(KIND))                                                                                       \
-      hipLaunchKernelGGL((k_scan_cls<KIND, NL, LINES, EM, LOADS, ICASE, ALIGNED>), grid, dim3(kBlock), 0, s, a);      \
-    else                                                                                                              \
-      hipLaunchKernelGGL((k_scan<KIND, NL, LINES, EM, LOADS, ICASE, ALIGNED>), grid, dim3(kBlock), 0, s, a);          \
-  } while (0)
+#define KSCAN_LAUNCH(NL, LINES, EM) hipLaunchKernelGGL((k_scan<KIND, NL, LINES, EM, LOADS, ICASE, ALIGNED>), grid, dim3(kBlock), 0, s, a)
   if (emit) {
     KSCAN_LAUNCH(false, false, true);
   } else if (want_lines) {
@@ -995,7 +985,7 @@ void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, 
   }
   const bool window = a.pat.kind == kTwo || a.pat.kind == kLong || a.pat.kind == kClass;
   const int kind = (a.pat.kind == kClass && a.pat.cls_fast && !a.pat.hot) ? (int)kClassFast : (int)a.pat.kind;
-  snprintf(out, cap, "xsg::k_scan%s<%d, %s, %s, %s, 4, %s, %s> stagger=%u", is_cls(kind) ? "_cls" : "", kind, b[emit ? 0 : want_nl],
+  snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s, %s> stagger=%u", kind, b[emit ? 0 : want_nl],
            b[emit ? 0 : want_lines], b[emit], b[a.pat.icase ? 1 : 0], b[window && a.pat.hot ? 1 : 0],
            pick_stagger(a, want_nl, want_lines, emit));
 }
