@@ -344,7 +344,7 @@ def test_expressions_that_can_match_a_newline(gs, oracle):
         assert ei.value.code == xsg.ENOTSUP
 
 
-def test_both_routes_of_the_automaton_family_agree(gs, oracle, monkeypatch):
+def test_both_routes_of_the_automaton_family_agree(gs, oracle, monkeypatch, tmp_path):
     """an expression with a selective start is searched two ways: candidates by the scan kernel's class-sequence
     matcher + the anchored automaton at candidates (xsg_count / xsg_search / the jobs), or every line walked by
     k_rx_scan (xsg_count_async; XSG_RX_PRE=0 forces it everywhere).  Same oracle, same answers."""
@@ -360,6 +360,20 @@ def test_both_routes_of_the_automaton_family_agree(gs, oracle, monkeypatch):
                 monkeypatch.setenv("XSG_RX_PRE", pre)
                 res.append(check(gs, oracle, blocks, expr, icase, f"pre={pre}"))
             assert res[0] == res[1] and res[0] is not None
+    # the file pipeline on the prefilter route (xsg_count_begin / _end run it synchronously; list tags through xsg_search)
+    data = np.concatenate(blocks[:3])
+    path = tmp_path / "routes.txt"
+    data.tofile(path)
+    want, _ = oracle_regex_all_modes(oracle, [data], b"Sher.*mes")
+    for pre in ("1", "0"):
+        monkeypatch.setenv("XSG_RX_PRE", pre)
+        for mode, key in ((xsg.COUNT_MATCHES, "count_matches"), (xsg.COUNT_LINES, "count_lines"),
+                          (xsg.LINE_BYTE_OFFSETS, "line_byte_offsets")):
+            j = xsg.Job(b"Sher.*mes", str(path), mode=mode, flags=xsg.FLAG_REGEX, chunk_bytes=1 << 20, num_threads=2,
+                        num_max_readers=2)
+            r = j.result()
+            assert (r if isinstance(r, int) else r.tolist()) == want[key], (pre, key)
+            j.close()
     monkeypatch.delenv("XSG_RX_PRE")
 
 

@@ -650,7 +650,10 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.ntiles = s->ntiles;
   a.nchunks = s->chunks.size();
   a.tile_bytes = s->tile_bytes;
-  a.tune = s->ctx->tune != kTuneAuto ? s->ctx->tune : s->tune;  // XSG_TUNE, else xsg_shard_tune's choice, else per variant
+  // XSG_TUNE, else xsg_shard_tune's choice -- for the pattern it was measured with: a stagger tuned for a literal would
+  // cost an instruction-bound class-sequence scan 10 % -- else per variant
+  a.tune = s->ctx->tune != kTuneAuto ? s->ctx->tune
+                                     : (s->tune_serial == s->ctx->pattern_serial || s->tune_serial == 0) ? s->tune : kTuneAuto;
   a.epoch = s->epoch;
   a.pat = s->ctx->pat;
   a.pat.hot = s->ctx->hot_env >= 0 ? (uint32_t)s->ctx->hot_env : (s->hot_serial == s->ctx->pattern_serial ? s->hot : 0u);
@@ -1090,6 +1093,7 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   s->tune = kTuneAuto;
+  s->tune_serial = 0;  // (0: the candidate values set inside the loop below apply whatever the serial)
   if (chosen) *chosen = kTuneAuto;
   if (c->tune != kTuneAuto || s->total_bytes < (1ull << 30)) return XSG_OK;  // XSG_TUNE wins; too small to measure
   if (c->pat.kind == kDfa) return XSG_OK;  // k_rx_scan has no stagger
@@ -1118,6 +1122,7 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
     }
   }
   s->tune = best;
+  s->tune_serial = c->pattern_serial;
   s->hot = best_hot;
   if (chosen) *chosen = best;
   return XSG_OK;
