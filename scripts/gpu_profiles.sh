@@ -17,6 +17,6 @@ timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${
 cd $REPO
 F=$(find $OUT/prof_${TAG}_fetch -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/prof_${TAG}_write -name '*counter_collection.csv' | head -1)
-python3 scripts/pmc_traffic.py $F $W $OUT/BENCH_${TAG}_plain.json $TAG | cut -c1-600
+python3 scripts/pmc_traffic.py $F $W $OUT/BENCH_${TAG}_plain.json $TAG | tee $OUT/${TAG}_pmc_traffic.json | cut -c1-600
 for f in $(find $OUT/prof_${TAG}_stats -name '*kernel_stats.csv' | head -1); do cp $f $OUT/${TAG}_bench50g_kernel_stats.csv; head -8 $f | cut -c1-200; done
 exit 0
