@@ -114,3 +114,53 @@ def test_config3_shape_50gib_count(oracle):
     assert int(sh.count(xsg.COUNT_MATCHES)[xsg.CTR_BYTES]) == int(chunks["length"].sum())
     sh.close()
     ctx.close()
+
+
+def test_regex_routes_10gib(shard10, oracle):
+    """The regex row at full size, exactly: expected results of the whole shard from the oracle's results on the
+    templates (chunks are independent units).  `Sher.*mes` takes the prefilter route here (shard >= 512 MiB) and
+    k_rx_scan through xsg_count_async; `[A-Z][a-z]+ [A-Z][a-z]+` has no selective start (k_rx_scan everywhere);
+    `She[r ]lock` is decided inside k_scan."""
+    import torch
+    from xs_oracle import RegexProgram, compile_class_sequence
+    s = shard10
+    plan, goffs = s["plan"], s["goffs"]
+    nl_t = np.array([oracle.count_newlines(b) for b in s["blocks"]], dtype=np.uint64)
+    nl_before = np.concatenate([[0], np.cumsum(nl_t[plan])[:-1]]).astype(np.uint64)
+    dc = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+
+    # variable length, selective start: offsets, line indices and both counts, element by element
+    expr = b"Sher.*mes"
+    prog = RegexProgram(expr)
+    s["ctx"].set_pattern(expr, xsg.FLAG_REGEX)
+    assert "prefilter" in s["shard"].scan_kernel_name(xsg.COUNT_MATCHES)
+    tl = [oracle.rx_byte_offsets(b, prog, False) for b in s["blocks"]]
+    want = np.concatenate([tl[int(c)] + goffs[i] for i, c in enumerate(plan)])
+    got = s["shard"].search_u64(xsg.MATCH_BYTE_OFFSETS)
+    assert got.size == want.size > 100_000 and np.array_equal(got, want)
+    li_t = [oracle.rx_line_indices(b, prog, 0) for b in s["blocks"]]
+    want_idx = np.concatenate([li_t[int(c)] + nl_before[i] for i, c in enumerate(plan)])
+    assert np.array_equal(s["shard"].search_u64(xsg.LINE_INDICES), want_idx)
+    assert int(s["shard"].count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == want.size
+    assert int(s["shard"].count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == want_idx.size
+    s["shard"].count_async(xsg.COUNT_MATCHES, 0, dc.data_ptr())  # the other device route: every line walked by k_rx_scan
+    torch.cuda.synchronize()
+    assert int(dc[xsg.CTR_MATCHES]) == want.size
+
+    # variable length, no selective start: counts by linearity over the chunks
+    expr = b"[A-Z][a-z]+ [A-Z][a-z]+"
+    prog = RegexProgram(expr)
+    s["ctx"].set_pattern(expr, xsg.FLAG_REGEX)
+    assert "k_rx_scan" in s["shard"].scan_kernel_name(xsg.COUNT_MATCHES)
+    tm = np.array([oracle.rx_count(b, prog, False) for b in s["blocks"]], dtype=np.int64)
+    tlc = np.array([oracle.rx_count(b, prog, True) for b in s["blocks"]], dtype=np.int64)
+    assert int(s["shard"].count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == int(tm[plan].sum()) > 0
+    assert int(s["shard"].count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == int(tlc[plan].sum())
+
+    # the reference's own integration expression, class sequence inside k_scan
+    cs = compile_class_sequence(b"She[r ]lock")
+    s["ctx"].set_pattern(b"She[r ]lock", xsg.FLAG_REGEX)
+    tm = np.array([oracle.regex_count(b, cs, False) for b in s["blocks"]], dtype=np.int64)
+    tlc = np.array([oracle.regex_count(b, cs, True) for b in s["blocks"]], dtype=np.int64)
+    assert int(s["shard"].count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == int(tm[plan].sum()) > 0
+    assert int(s["shard"].count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == int(tlc[plan].sum())
