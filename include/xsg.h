@@ -183,6 +183,11 @@ typedef struct xsg_regex_dfa {
    * prefix_alternatives class sequences; the synchronous entry points (xsg_count, xsg_search, the jobs) then find
    * candidate positions with the scan kernel's class-sequence matcher and run the automaton at candidates only. */
   uint32_t prefix_positions, prefix_alternatives;
+  /* FACTOR (expressions without a selective start that cannot match across lines): if factor_positions != 0, every match
+   * CONTAINS that many consecutive bytes accepted by one class sequence (`\w+ing`: `\wing`); the synchronous entry
+   * points mark the tiles in which a line with an occurrence starts, once per binding and pattern, and the line-walking
+   * kernel skips every other tile. */
+  uint32_t factor_positions;
   uint32_t fwd_states, fwd_start, fwd_first_acc;
   uint32_t rev_states, rev_start, rev_first_acc;
   uint8_t class_of[256];
@@ -193,6 +198,8 @@ int xsg_regex_dfa_info(const void* expr, size_t n, uint32_t flags, xsg_regex_dfa
  * every match starts with *positions bytes that one of the *alternatives class sequences accepts.  *positions == 0:
  * the expression has no selective start, every entry point walks all lines (k_rx_scan). */
 int xsg_regex_prefix(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* alternatives, uint32_t* sets);
+/* ... and its factor (xsg_regex_dfa.factor_positions): one class sequence, room for 32 x 8 uint32. */
+int xsg_regex_factor(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets);
 
 /* ---- shards ---------------------------------------------------------------- */
 /* d_base/capacity: device memory owned by the caller (hipMalloc, a torch

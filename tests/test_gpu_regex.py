@@ -390,3 +390,35 @@ def test_prefilter_gives_way_when_candidates_run_far(gs, oracle, monkeypatch):
         assert xsg.regex_prefix(expr)[0] >= 3
         want = check(gs, oracle, blocks, expr, False, "budget")
         assert want is not None and want["count_matches"] >= 1
+
+
+def test_factor_prefilter_of_expressions_without_a_selective_start(gs, oracle, monkeypatch):
+    """`\\w+ere`: no definite start, but every match contains `\\were` -- the synchronous entry points mark the tiles in
+    which a line with an occurrence starts (once per binding and pattern) and k_rx_scan leaves every other tile at
+    once.  XSG_RX_FAC=1 forces the mask on these small shards, =0 walks every tile; same answers, also from the
+    stream-ordered count that follows and reuses the mask."""
+    import torch
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"aabbccxyz01 _\n", dtype=np.uint8)
+    long_line = alphabet[rng.integers(0, len(alphabet) - 1, size=50_000)].copy()  # no newline in 50 KB: crosses three tiles
+    sets = {
+        "text": ([corpus.text_block(606, i, 700_000 + 999 * i, needle_rate=2e-4) for i in range(3)],
+                 (b"\\w+ere", b"[a-z]*ould", b"\\w+ock(ed|s)?", b"[a-z]+ +Holmes", b"\\w*zzzq\\w*")),
+        "awkward": ([alphabet[rng.integers(0, len(alphabet), size=n)].copy() for n in (0, 1, 16383, 16384, 16385, 40_000)] +
+                    [long_line, np.concatenate([long_line[:20_000], np.array([10], dtype=np.uint8), long_line[:30_000]])],
+                    (b"[a-c]+xyz", b"\\w+_01", b"[ab]*cc[xy]+", b"\\S*01_\\S*")),
+    }
+    c = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    for name, (blocks, exprs) in sets.items():
+        gs.bind(blocks)
+        for expr in exprs:
+            assert xsg.regex_prefix(expr)[0] == 0 and xsg.regex_factor(expr)[0] >= 3, expr
+            res = []
+            for fac in ("1", "0"):
+                monkeypatch.setenv("XSG_RX_FAC", fac)
+                res.append(check(gs, oracle, blocks, expr, False, f"{name} fac={fac}"))
+                gs.shard.count_async(xsg.COUNT_MATCHES, 0, c.data_ptr())  # stream-ordered, behind the mask of the calls above
+                torch.cuda.synchronize()
+                assert int(c[xsg.CTR_MATCHES]) == res[-1]["count_matches"], (name, expr, fac)
+            assert res[0] == res[1] and res[0] is not None
+    monkeypatch.delenv("XSG_RX_FAC")

@@ -269,3 +269,39 @@ def test_walk_over_occurrences_by_heads_and_chains():
                     got[j], last = True, ends[j]
                 j += 1
         assert got == want
+
+
+def test_every_match_contains_the_factor():
+    """expressions without a selective start: the class sequence the product says every match CONTAINS
+    (xsg_regex.h: RegexDfa::factor; the line prefilter rests on it)"""
+    n, sets = xsg.regex_factor(b"\\w+ing")
+    assert n == 4 and prefix_accepts([sets], b"King") and not prefix_accepts([sets], b" ing")
+    assert xsg.regex_factor(b"[a-z]*tion(s|al)?")[0] == 4
+    assert xsg.regex_factor(b"[A-Z][a-z]+ [A-Z][a-z]+")[0] == 0  # nothing narrow enough
+    assert xsg.regex_factor(b"Sher.*mes")[0] == 0                 # has a selective start: the prefix route serves it
+    rng = np.random.default_rng(2718)
+    alphabet = np.frombuffer(b"aabbccxyz01 _\n\n", dtype=np.uint8)
+    with_factor = 0
+    heads = [b"\\w+", b"[a-c]*", b".+?", b"(?:x|yz)+", b"[ab]{1,3}", b"\\S*", b"[a-c]+_?"]
+    tails = [b"", b"\\d*", b"(?:a|bc)?", b"[xyz]+", b".*"]
+    for it in range(2800):
+        if it < 2500:
+            expr = rand_var_expr(rng)
+        else:  # a variable head, a literal run every match must contain, a variable tail
+            lit = bytes(b"abcxyz01_"[int(i)] for i in rng.integers(0, 9, size=int(rng.integers(3, 6))))
+            expr = heads[int(rng.integers(0, len(heads)))] + lit + tails[int(rng.integers(0, len(tails)))]
+        icase = bool(rng.integers(0, 4) == 0)
+        flags = xsg.FLAG_IGNORE_CASE if icase else 0
+        try:
+            prog = RegexProgram(expr, icase)
+            n, sets = xsg.regex_factor(expr, flags)
+        except (UnsupportedRegex, xsg.XsgError):
+            continue
+        if n == 0:
+            continue
+        assert xsg.regex_prefix(expr, flags)[0] == 0 and not prog.multiline
+        data = alphabet[rng.integers(0, len(alphabet), size=600)].tobytes()
+        for a, b in oracle_matches(prog, data):
+            assert any(prefix_accepts([sets], data[k:k + n]) for k in range(a, b - n + 1)), (expr, icase, data[a:b])
+        with_factor += 1
+    assert with_factor > 150

@@ -116,6 +116,7 @@ extern "C" void xsg_ctx_destroy(xsg_ctx* c) {
   }
   c->d_pat.release();
   c->d_pre.release();
+  c->d_fac.release();
   delete c;
 }
 
@@ -342,6 +343,20 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
     c->pre_pat.d_pat = c->d_pre.as<uint8_t>();
     c->pre_pat.ascii_only = P.ascii_only;  // the candidate scan reads every byte: it raises the refusal flag
   }
+  // No selective start, but a factor every match contains (`\\w+ing`: `\\wing`): lines without it have no match, and the
+  // synchronous entry points first mark the tiles in which a line with an occurrence starts (ensure_factor_mask).
+  const char* fac_env = getenv("XSG_RX_FAC");
+  c->rx_fac = !c->rx_pre && dfa.factor.npos != 0 && !(fac_env && *fac_env == '0');
+  c->rx_fac_forced = fac_env && *fac_env == '1';
+  if (c->rx_fac) {
+    std::vector<uint8_t> fblob;
+    class_fields(dfa.factor, false, &c->fac_pat, &fblob);
+    XSG_TRY(c->d_fac.ensure(fblob.size()));
+    HIP_TRY(hipMemcpyAsync(c->d_fac.p, fblob.data(), fblob.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->fac_pat.d_pat = c->d_fac.as<uint8_t>();
+    c->fac_pat.ascii_only = P.ascii_only;
+  }
   return XSG_OK;
 }
 
@@ -379,6 +394,7 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   P.d_pat = c->d_pat.as<uint8_t>();
   c->pat = P;
   c->rx_pre = false;
+  c->rx_fac = false;
   return XSG_OK;
 }
 
@@ -404,6 +420,7 @@ extern "C" int xsg_regex_dfa_info(const void* expr, size_t n, uint32_t flags, xs
   info->multiline = dfa.multiline ? 1u : 0u;
   info->prefix_positions = dfa.prefix.npos;
   info->prefix_alternatives = (uint32_t)dfa.prefix.alts.size();
+  info->factor_positions = dfa.factor.npos;
   info->fwd_states = dfa.fwd_states, info->fwd_start = dfa.fwd_start, info->fwd_first_acc = dfa.fwd_first_acc;
   info->rev_states = dfa.rev_states, info->rev_start = dfa.rev_start, info->rev_first_acc = dfa.rev_first_acc;
   memcpy(info->class_of, dfa.class_of, 256);
@@ -425,6 +442,18 @@ extern "C" int xsg_regex_prefix(const void* expr, size_t n, uint32_t flags, uint
   if (sets)
     for (size_t a = 0; a < dfa.prefix.alts.size(); ++a)
       memcpy(sets + a * dfa.prefix.npos * 8, dfa.prefix.alts[a].data(), dfa.prefix.npos * sizeof(xsg::ByteSet));
+  return XSG_OK;
+}
+
+extern "C" int xsg_regex_factor(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets) {
+  if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
+  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  xsg::RegexDfa dfa;
+  std::string err;
+  if (!xsg::compile_regex_dfa(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &dfa, &err))
+    return fail(XSG_ENOTSUP, "regex not supported by the automaton route: %s", err.c_str());
+  if (positions) *positions = dfa.factor.npos;
+  if (sets && dfa.factor.npos) memcpy(sets, dfa.factor.alts[0].data(), dfa.factor.npos * sizeof(xsg::ByteSet));
   return XSG_OK;
 }
 
@@ -503,6 +532,7 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   window_fields(p, plen, pick_filter_window(p, plen), &P);  // koff 0 unless plen > 8
   c->koff_cands = window_candidates(p, plen);
   c->rx_pre = false;
+  c->rx_fac = false;
   P.kind = plen < 4 ? kMask1 : plen == 4 ? kOne : plen < 8 ? kMask2 : plen == 8 ? kTwo : kLong;
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;
@@ -556,6 +586,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   s->nl_cached = s->nl_off_cached = false;
   s->hot_serial = 0;
   s->pre_dense_serial = 0;
+  s->mask_serial = s->mask_dense_serial = 0;
   bool grew = false;
   XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
   XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
@@ -664,6 +695,8 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.tile_sum = s->d_tile_sum.as<uint32_t>();
   a.tile_last = s->d_tile_last.as<uint32_t>();
   a.flags = reinterpret_cast<uint32_t*>(s->d_finish.as<uint64_t>() + 3 * (size_t)kFinishBlocks) + 1;  // behind the ticket
+  a.tile_mask = (a.pat.kind == kDfa && s->mask_serial != 0 && s->mask_serial == s->ctx->pattern_serial)
+                    ? s->d_tile_mask.as<uint32_t>() : nullptr;
   return a;
 }
 
@@ -936,9 +969,75 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs);
 // The prefilter route is half a dozen kernels and three trips to the host where k_rx_scan is one pass: it pays on
 // shards where a pass takes longer than that (the file pipeline's 16 MiB chunks are walked by k_rx_scan in tens of
 // microseconds).
+// The factor prefilter of the automaton route: for an expression without a selective start but with a class sequence
+// every match contains, the occurrences of that factor are found by the scan kernel's class-sequence matcher (count +
+// emit), the first occurrence of every line gives the line's start (k_line_starts_keep, as for any line tag), and the
+// tiles in which such lines start are marked.  k_rx_scan then leaves every other tile at once.  Built once per
+// (binding, pattern) by the first synchronous call and used by every later pass, the stream-ordered ones included;
+// not built where the factor turns out dense (most tiles would be marked) or the shard is small.
+static int d2h_u64(xsg_ctx* c, const uint64_t* d, uint64_t* h);
+static int ensure_factor_mask(xsg_shard* s) {
+  xsg_ctx* c = s->ctx;
+  if (c->pat.kind != kDfa || !c->rx_fac || s->ntiles == 0) return XSG_OK;
+  if (s->mask_serial == c->pattern_serial || s->mask_dense_serial == c->pattern_serial) return XSG_OK;
+  if (!c->rx_fac_forced && s->total_bytes < (512ull << 20)) return XSG_OK;
+  hipStream_t st = c->stream;
+  const uint64_t nchunks = s->chunks.size(), ntiles = s->ntiles;
+  XSG_TRY(prepare_tiles(s, false, st));
+  ScanArgs a = scan_args(s);
+  a.pat = c->fac_pat;
+  a.pat.hot = 0;
+  a.tile_mask = nullptr;
+  s->cnt_clean = false;
+  HIP_TRY(launch_scan_count(a, false, false, st));
+  XSG_TRY(s->d_tile_off.ensure(8 * (ntiles + 1)));
+  XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(std::max<uint64_t>(ntiles, nchunks) + 1)));
+  HIP_TRY(launch_exclusive_scan_u32(a.tile_cnt, s->d_tile_off.as<uint64_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(), st));
+  uint64_t M = 0;
+  uint32_t flags = 0;
+  HIP_TRY(hipMemcpyAsync(&flags, a.flags, 4, hipMemcpyDeviceToHost, st));
+  XSG_TRY(d2h_u64(c, s->d_tile_off.as<uint64_t>() + ntiles, &M));
+  if (flags & 1u) {  // non-ASCII data under an ascii_only expression: the search itself will refuse
+    HIP_TRY(hipMemsetAsync(a.flags, 0, 4, st));
+    return fail(XSG_ENOTSUP, "%s", kNonAsciiMsg);
+  }
+  if (!c->rx_fac_forced && M * 256 > s->total_bytes) {  // most tiles would be marked
+    s->mask_dense_serial = c->pattern_serial;
+    return XSG_OK;
+  }
+  XSG_TRY(s->d_c_pos.ensure(8 * std::max<uint64_t>(M, 1)));
+  XSG_TRY(s->d_c_chunk.ensure(4 * std::max<uint64_t>(M, 1)));
+  XSG_TRY(s->d_c_keep.ensure(4 * std::max<uint64_t>(M, 1)));
+  XSG_TRY(s->d_m_ls.ensure(8 * std::max<uint64_t>(M, 1)));
+  XSG_TRY(s->d_tile_mask.ensure(4 * ntiles));
+  a.tile_off = s->d_tile_off.as<uint64_t>();
+  a.m_pos = s->d_c_pos.as<uint64_t>();
+  a.m_chunk = s->d_c_chunk.as<uint32_t>();
+  if (M) HIP_TRY(launch_scan_emit(a, st));
+  ListArgs l{};
+  l.base = s->base;
+  l.chunks = a.chunks;
+  l.chunk_tile0 = a.chunk_tile0;
+  l.nchunks = nchunks;
+  l.pat = a.pat;
+  l.M = M;
+  l.m_pos = a.m_pos;
+  l.m_chunk = a.m_chunk;
+  l.tile_off = a.tile_off;
+  l.m_ls = s->d_m_ls.as<uint64_t>();
+  l.keep = s->d_c_keep.as<uint32_t>();
+  l.line_mode = 1;
+  HIP_TRY(launch_line_starts_keep(l, st));
+  HIP_TRY(hipMemsetAsync(s->d_tile_mask.p, 0, 4 * ntiles, st));
+  HIP_TRY(launch_rx_mark_tiles(l, s->d_tile_mask.as<uint32_t>(), st));
+  s->mask_serial = c->pattern_serial;
+  return XSG_OK;
+}
+
 static bool use_prefilter(const xsg_shard* s) {
   const xsg_ctx* c = s->ctx;
-  return c->pat.kind == kDfa && c->rx_pre && !s->pre_off && (c->rx_pre_forced || s->total_bytes >= (512ull << 20));
+  return c->pat.kind == kDfa && c->rx_pre && !s->pre_off && (c->rx_pre_forced || s->total_bytes >= (512ull << 20)) &&
+         s->chunks.size() < (1u << 24);  // k_rx_heads' keys: chunk number above 40 bits of offset
 }
 constexpr int kDenseCandidates = 1;  // run_list(outputs = false) on the prefilter route: too many candidates, count by k_rx_scan
 
@@ -949,6 +1048,7 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   if (m != XSG_COUNT_MATCHES && m != XSG_COUNT_LINES) return fail(XSG_EINVAL, "mode %u is not a count mode", m);
+  XSG_TRY(ensure_factor_mask(s));
   if (use_prefilter(s) && s->pre_dense_serial != c->pattern_serial) {  // (not again where the candidates were found dense)
     // the prefilter route of the automaton family: candidates, verification and the walk produce the list; its
     // length is the count (the newline total, if asked for, comes from the cached per-tile counts)
@@ -1007,6 +1107,7 @@ extern "C" int xsg_count_begin(xsg_shard* s, uint32_t mode) {
   if (m != XSG_COUNT_MATCHES && m != XSG_COUNT_LINES) return fail(XSG_EINVAL, "mode %u is not a count mode", m);
   if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
   s->begin_sync_result = false;
+  XSG_TRY(ensure_factor_mask(s));
   if ((m == XSG_COUNT_MATCHES && c->bordered) || (use_prefilter(s) && s->pre_dense_serial != c->pattern_serial)) {  // needs the ordered list: done synchronously, handed out by _end
     XSG_TRY(xsg_count(s, mode, s->begin_counters));
     s->begin_sync_result = true;
@@ -1150,6 +1251,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   s->last_mode = -1;
   s->total = 0;
   s->line_bytes = 0;
+  XSG_TRY(ensure_factor_mask(s));
 
   // 1. bulk count per tile
   if (want_nl) XSG_TRY(ensure_tile_nl(s));

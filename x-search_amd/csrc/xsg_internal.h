@@ -96,6 +96,8 @@ struct ScanArgs {
   uint32_t* tile_sum;                  // line summary PER WAVE (4 per tile), stored XOR kSumNl (WANT_LINES)
   uint32_t* tile_last;                 // (epoch << 16) | max (match offset + plen) in the tile, relative to the tile start
   uint32_t* flags;                     // one word per shard, zero at rest: bit 0 = "non-ASCII byte under an ascii_only expression"
+  const uint32_t* tile_mask;           // k_rx_scan: if set, only tiles with a non-zero word can hold the start of a line with a
+                                       // match (the factor prefilter, xsg_api.cpp: ensure_factor_mask); null: every tile
   // inputs/outputs of the emit pass
   uint64_t m_cap;            // entries m_pos / m_chunk can hold (ranks beyond are dropped; 0 = as many as there are)
   const uint64_t* tile_off;  // exclusive prefix of tile_cnt
@@ -196,6 +198,8 @@ struct ListArgs {
   uint64_t total;
 };
 
+// mask[tile of the line start] = 1 for every kept entry of a candidate list (ListArgs after launch_line_starts_keep)
+hipError_t launch_rx_mark_tiles(const ListArgs& a, uint32_t* mask, hipStream_t s);
 hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s);
 hipError_t launch_line_starts_keep(const ListArgs& a, hipStream_t s);
 hipError_t launch_keep_all(const ListArgs& a, hipStream_t s);

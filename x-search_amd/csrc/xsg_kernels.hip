@@ -979,8 +979,9 @@ void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, 
   if (!out || !cap) return;
   const char* b[2] = {"false", "true"};
   if (a.pat.kind == kDfa) {
-    snprintf(out, cap, "xsg::k_rx_scan<%s, %s> states=%u classes=%u", b[emit], b[emit ? 0 : want_lines],
-             a.pat.rx_ncls ? a.pat.rx_fwd_n / a.pat.rx_ncls : 0u, a.pat.rx_ncls);
+    snprintf(out, cap, "xsg::k_rx_scan<%s, %s> states=%u classes=%u%s", b[emit], b[emit ? 0 : want_lines],
+             a.pat.rx_ncls ? a.pat.rx_fwd_n / a.pat.rx_ncls : 0u, a.pat.rx_ncls,
+             a.tile_mask ? " (tiles marked by the factor prefilter only)" : "");
     return;
   }
   const bool window = a.pat.kind == kTwo || a.pat.kind == kLong || a.pat.kind == kClass;

@@ -78,6 +78,11 @@ struct xsg_ctx {
   // kDfa with a selective start (xsg_regex.h: RegexDfa::prefix): the class-sequence pattern that finds the candidates
   bool rx_pre = false;
   bool rx_pre_forced = false;  // XSG_RX_PRE=1: on shards of any size
+  // kDfa without a selective start but with a factor every match contains (RegexDfa::factor): the class-sequence pattern
+  // that finds the lines worth walking
+  bool rx_fac = false, rx_fac_forced = false;
+  xsg::PatternDev fac_pat{};
+  DevBuf d_fac;
   xsg::PatternDev pre_pat{};
   DevBuf d_pre;
   uint32_t tile_bytes = xsg::kDefaultTileBytes;  // geometry new shards get (XSG_TILE_KIB)
@@ -118,6 +123,9 @@ struct xsg_shard {
   DevBuf d_chunk_shift0, d_tail_cnt, d_tail_pos, d_tail_pre;
   DevBuf d_f_pos, d_f_match, d_f_chunk, d_out_u64, d_line_len, d_line_off, d_line_bytes;
   DevBuf d_c_pos, d_c_chunk, d_c_len, d_c_keep, d_c_pre;  // prefilter route of kDfa: the candidates
+  DevBuf d_tile_mask;             // factor prefilter of kDfa: tiles in which a line with a factor occurrence starts
+  uint64_t mask_serial = 0;       // ... valid for this ctx->pattern_serial on this binding (0: not built)
+  uint64_t mask_dense_serial = 0; // ... found useless for this pattern here (factor occurrences too dense)
 
   // State of the per-tile arrays between passes (host-side bookkeeping; see ScanArgs).  A count pass leaves
   // tile_cnt / tile_sum clean (k_count_finish zeroes what it read); a list pass or a timing loop leaves them
@@ -154,7 +162,7 @@ struct xsg_shard {
                      &d_counters, &d_finish, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls,
                      &d_keep, &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
                      &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes, &d_c_pos, &d_c_chunk, &d_c_len, &d_c_keep,
-                     &d_c_pre};
+                     &d_c_pre, &d_tile_mask};
     for (DevBuf* b : all) b->release();
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_counters) (void)hipHostFree(h_counters);

@@ -468,6 +468,92 @@ void find_prefix(const Dfa& ad, const std::vector<uint8_t>& rep, const uint8_t (
   }
 }
 
+// ---- a factor every match contains ------------------------------------------------------------------------------
+// The class sequence a node matches if it matches exactly one (a set, a concatenation of such, x{n} of such)
+bool fixed_sequence(const std::vector<Node>& pool, int node, std::vector<ByteSet>* out) {
+  const Node& nd = pool[node];
+  switch (nd.kind) {
+    case Node::kSet:
+      out->push_back(nd.set);
+      return out->size() <= 64;
+    case Node::kCat:
+      for (int kid : nd.kids)
+        if (!fixed_sequence(pool, kid, out)) return false;
+      return true;
+    case Node::kRep: {
+      if (nd.lo != nd.hi || nd.lo > 16) return false;
+      for (uint32_t k = 0; k < nd.lo; ++k)
+        if (!fixed_sequence(pool, nd.kids[0], out)) return false;
+      return true;
+    }
+    default:
+      return false;
+  }
+}
+
+// Runs of positions that are adjacent in every match: `cur` grows along a concatenation and is closed (`done`) wherever
+// the text between two pieces can vary.  x{lo,hi} of a fixed x with hi > lo: the first lo copies are adjacent to what
+// precedes, the last lo copies to what follows.
+void collect_runs(const std::vector<Node>& pool, int node, std::vector<ByteSet>* cur, std::vector<std::vector<ByteSet>>* done) {
+  auto flush = [&] {
+    if (!cur->empty()) done->push_back(*cur);
+    cur->clear();
+  };
+  const Node& nd = pool[node];
+  std::vector<ByteSet> fx;
+  if (fixed_sequence(pool, node, &fx)) {
+    cur->insert(cur->end(), fx.begin(), fx.end());
+    return;
+  }
+  switch (nd.kind) {
+    case Node::kCat:
+      for (int kid : nd.kids) collect_runs(pool, kid, cur, done);
+      return;
+    case Node::kRep: {
+      std::vector<ByteSet> one;
+      const bool fixed = fixed_sequence(pool, nd.kids[0], &one) && one.size() <= 8;
+      if (fixed && nd.lo >= 1) {
+        const uint32_t copies = std::min<uint32_t>(nd.lo, 4);
+        for (uint32_t k = 0; k < copies; ++k) cur->insert(cur->end(), one.begin(), one.end());
+        flush();
+        for (uint32_t k = 0; k < copies; ++k) cur->insert(cur->end(), one.begin(), one.end());
+      } else if (nd.lo >= 1) {  // at least one copy of something variable: what it must contain, on its own
+        flush();
+        collect_runs(pool, nd.kids[0], cur, done);
+        flush();
+      } else {
+        flush();
+      }
+      return;
+    }
+    default:  // an alternation: nothing is common to all alternatives for sure
+      flush();
+      return;
+  }
+}
+
+void find_factor(const std::vector<Node>& pool, int root, ClassExpr* out) {
+  *out = ClassExpr{};
+  std::vector<ByteSet> cur;
+  std::vector<std::vector<ByteSet>> runs;
+  collect_runs(pool, root, &cur, &runs);
+  if (!cur.empty()) runs.push_back(cur);
+  size_t best_narrow = 0;
+  const std::vector<ByteSet>* best = nullptr;
+  for (const auto& r : runs) {
+    size_t narrow = 0;
+    for (const ByteSet& st : r) narrow += set_size(st) <= 2;
+    if (narrow > best_narrow) best_narrow = narrow, best = &r;
+  }
+  if (!best || best_narrow < 3) return;
+  std::vector<ByteSet> seq(best->begin(), best->begin() + (ptrdiff_t)std::min<size_t>(best->size(), kMaxClassSeq));
+  size_t narrow = 0;
+  for (const ByteSet& st : seq) narrow += set_size(st) <= 2;
+  if (narrow < 3) return;
+  std::vector<std::vector<ByteSet>> alts{seq};
+  if (!class_expr_from_alternatives(std::move(alts), out)) *out = ClassExpr{};
+}
+
 }  // namespace
 
 bool compile_regex_dfa(const uint8_t* re, size_t n, bool ignore_case, RegexDfa* out, std::string* err) {
@@ -533,6 +619,7 @@ bool compile_regex_dfa(const uint8_t* re, size_t n, bool ignore_case, RegexDfa* 
   if (!flatten(rd, out->ncls, &out->rev, &out->rev_states, &out->rev_start, &out->rev_first_acc, err)) return false;
   if (!flatten(ad, out->ncls, &out->anc, &out->anc_states, &out->anc_start, &out->anc_first_acc, err)) return false;
   find_prefix(ad, rep, out->class_of, (uint32_t)std::min<uint64_t>(p.pool[root].minlen, 8), &out->prefix);
+  if (out->prefix.npos == 0 && !out->multiline) find_factor(p.pool, root, &out->factor);
   out->minlen = (uint32_t)std::min<uint64_t>(p.pool[root].minlen, 0xffffffffu);
   out->ascii_only = p.ascii_only;
   return true;

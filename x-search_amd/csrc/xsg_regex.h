@@ -61,6 +61,11 @@ struct RegexDfa {
   // candidate positions with the scan kernel's class-sequence matcher at streaming speed and run the anchored
   // automaton at candidates only (csrc/xsg_rx_kernels.hip: k_rx_verify).
   ClassExpr prefix;
+  // FACTOR: a class sequence that every match CONTAINS somewhere (`\\w+ing` -> `\\wing`), for expressions without a
+  // selective start (prefix.npos == 0) that cannot match across lines.  A line without the factor has no match, so
+  // k_rx_scan only needs the tiles in which a line with a factor occurrence starts (csrc/xsg_api.cpp:
+  // ensure_factor_mask).  npos == 0: none found.
+  ClassExpr factor;
   bool ascii_only = false;   // as ClassExpr::ascii_only: a search refuses data with a byte >= 0x80
   bool multiline = false;    // some set accepts '\n': matches may span lines ('\n' is then an ordinary byte for the automata)
 };

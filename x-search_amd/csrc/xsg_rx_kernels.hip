@@ -159,6 +159,9 @@ __global__ __launch_bounds__(kBlock) void k_rx_scan(const ScanArgs A, const uint
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (tile >= A.ntiles) return;
   if (EMIT && A.tile_cnt[tile] == 0) return;
+  // the factor prefilter: no line that starts in this tile holds the factor every match contains -> nothing to find
+  // (a pass that also counts newlines needs every tile)
+  if (A.tile_mask && !want_nl && A.tile_mask[tile] == 0u) return;
   const PatternDev P = A.pat;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t c = A.tile_chunk ? A.tile_chunk[tile] : 0u;
@@ -575,6 +578,16 @@ hipError_t launch_rx_verify_keep(const RxPreArgs& a, hipStream_t s) {
   }
   return hipGetLastError();
 }
+__global__ void k_rx_mark_tiles(const ListArgs A, uint32_t* mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.M || !A.keep[i]) return;  // kept = the first factor occurrence of its line; m_ls = where that line starts
+  mask[A.chunk_tile0[A.m_chunk[i]] + A.m_ls[i] / kRxTile] = 1u;
+}
+hipError_t launch_rx_mark_tiles(const ListArgs& a, uint32_t* mask, hipStream_t s) {
+  if (a.M) hipLaunchKernelGGL(k_rx_mark_tiles, dim3((unsigned)((a.M + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, mask);
+  return hipGetLastError();
+}
+
 hipError_t launch_rx_compact(const RxPreArgs& a, hipStream_t s) {
   if (a.n) hipLaunchKernelGGL(k_rx_compact, dim3((unsigned)((a.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
   return hipGetLastError();

@@ -53,7 +53,7 @@ class JobStats(C.Structure):
 
 class RegexDfaInfo(C.Structure):
     _fields_ = [("ncls", C.c_uint32), ("minlen", C.c_uint32), ("ascii_only", C.c_uint32), ("multiline", C.c_uint32),
-                ("prefix_positions", C.c_uint32), ("prefix_alternatives", C.c_uint32),
+                ("prefix_positions", C.c_uint32), ("prefix_alternatives", C.c_uint32), ("factor_positions", C.c_uint32),
                 ("fwd_states", C.c_uint32), ("fwd_start", C.c_uint32), ("fwd_first_acc", C.c_uint32),
                 ("rev_states", C.c_uint32), ("rev_start", C.c_uint32), ("rev_first_acc", C.c_uint32),
                 ("class_of", C.c_uint8 * 256)]
@@ -109,6 +109,7 @@ def load():
         "xsg_set_pattern": (ci, [vp, C.c_char_p, sz, u32]),
         "xsg_regex_check": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32)]),
         "xsg_regex_info": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+        "xsg_regex_factor": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32)]),
         "xsg_regex_prefix": (ci, [C.c_char_p, sz, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "xsg_regex_dfa_info": (ci, [C.c_char_p, sz, u32, C.POINTER(RegexDfaInfo), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), sz]),
         "xsg_shard_create": (ci, [vp, vp, u64, vp, u64, C.POINTER(vp)]),
@@ -178,7 +179,7 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_host_offsets", "xsg_host_lines", "xsg_scan_kernel_name", "xsg_shard_tune", "xsg_count_begin",
            "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
            "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
-           "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info", "xsg_regex_dfa_info", "xsg_regex_prefix",
+           "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info", "xsg_regex_dfa_info", "xsg_regex_prefix", "xsg_regex_factor",
            "xsg_result_u64_view"]
 
 
@@ -227,6 +228,15 @@ def regex_prefix(expr: bytes, flags: int = 0):
     sets = np.zeros((64, 8), dtype=np.uint32)
     _check(lib.xsg_regex_prefix(expr, len(expr), flags, C.byref(n), C.byref(na), sets.ctypes.data_as(C.POINTER(C.c_uint32))))
     return int(n.value), sets[:n.value * na.value].reshape(na.value, n.value, 8).copy()
+
+
+def regex_factor(expr: bytes, flags: int = 0):
+    """-> (positions, sets[positions, 8] uint32): a class sequence every match contains; positions == 0: none"""
+    lib = load()
+    n = C.c_uint32(0)
+    sets = np.zeros((32, 8), dtype=np.uint32)
+    _check(lib.xsg_regex_factor(expr, len(expr), flags, C.byref(n), sets.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return int(n.value), sets[:n.value].copy()
 
 
 def device_count() -> int:
