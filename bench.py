@@ -322,18 +322,27 @@ def regex_leg(xsg, torch, ctx, shard, stream, shard_bytes):
     c = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device=f"cuda:{torch.cuda.current_device()}")
     for expr in ("She[r ]lock", "[Ss]herlock", "Sherlock|Holmes", "Sher.*mes", "colou?r", "\\w+ing"):
         ctx.set_pattern(expr.encode(), xsg.FLAG_REGEX)
-        got = int(shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])  # warm-up (also settles the hot filter)
+        # the first call on a (binding, pattern) also pays what the library measures or builds once: the hot-filter probe
+        # of the window kinds, the factor prefilter's tile marks.  Reported on its own; for an expression whose later
+        # calls reuse such marks (they do not read the whole shard again) the rate is the FIRST call's.
+        t0 = time.perf_counter()
+        got = int(shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
+        first_ms = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
         for _ in range(3):
             got = int(shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
         ms = (time.perf_counter() - t0) / 3 * 1e3
+        marked = "factor prefilter" in shard.scan_kernel_name(xsg.COUNT_MATCHES)
+        rate_ms = first_ms if marked else ms
         shard.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
         torch.cuda.synchronize()
         other = int(c[xsg.CTR_MATCHES])
         if other != got:
             raise SystemExit(f"regex PARITY FAILURE: {expr!r}: xsg_count {got} != xsg_count_async {other}")
-        out.append({"expr": expr, "matches": got, "ms_per_call": round(ms, 3), "gbs": round(shard_bytes / ms / 1e6, 1),
-                    "frac_of_hbm_peak": round(shard_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+        out.append({"expr": expr, "matches": got, "first_call_ms": round(first_ms, 3), "ms_per_call": round(ms, 3),
+                    "gbs": round(shard_bytes / rate_ms / 1e6, 1),
+                    "frac_of_hbm_peak": round(shard_bytes / rate_ms / 1e6 / HBM_PEAK_GBS, 4),
+                    "rate_is_of": "the first call (later calls reuse the tile marks)" if marked else "repeated calls",
                     "kernel": shard.scan_kernel_name(xsg.COUNT_MATCHES)})
     return {"what": "whole synchronous xsg_count(COUNT_MATCHES) calls with XSG_FLAG_REGEX on the same resident shard; "
                     "each count equals the one xsg_count_async computes on its own route", "cases": out}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/rx_sweep_{pre,nopre}.jsonl (scripts/rx_sweep.py, default and XSG_RX_PRE=0) + gpurun_out/rx_pmc/
+"""gpurun_out/rx_sweep_{pre,nopre}.jsonl (scripts/rx_sweep.py, default and XSG_RX_PRE=0 XSG_RX_FAC=0) + gpurun_out/rx_pmc/
 (scripts/gpu_rx_pmc.sh) -> the tables committed as profiles/r02_rx_sweep.txt and profiles/r02_rx_pmc.txt."""
 import json
 import sys
@@ -20,12 +20,19 @@ lines = ["# The regex row on one MI355X, 8 GiB of the bench corpus resident in H
          "#   k_rx_scan for the automaton route); call: a whole synchronous xsg_count() incl. finish kernel and host sync.",
          "# default = the library's own routing (prefilter route where the expression starts selectively and the shard is",
          "#   >= 512 MiB; a count whose candidates turn out dense falls back to k_rx_scan and remembers it);",
-         "# XSG_RX_PRE=0 = k_rx_scan everywhere.  frac = of 8 TB/s.",
-         "pattern | mode | matches | kernel GB/s | default call ms | GB/s | frac | XSG_RX_PRE=0 call ms | GB/s | frac | default route"]
+         "# XSG_RX_PRE=0 XSG_RX_FAC=0 = k_rx_scan on every tile, for every expression of the automaton route.  frac = of 8 TB/s.",
+         "# first call: the first xsg_count() on a fresh binding (hot-filter probe, factor prefilter's tile marks included);",
+         "#   later calls of an expression with a factor prefilter reuse the marks and do not read the whole shard again:",
+         "#   their time is given, a rate is not.",
+         "pattern | mode | matches | kernel GB/s | first call ms | GB/s | later calls ms | GB/s | frac | no prefilters: later calls ms | GB/s | default route"]
 for a, b in zip(pre, nopre):
-    route = "prefilter (k_scan<kClass> + k_rx_verify ...)" if "prefilter" in a["kernel"] else a["kernel"].split(" stagger")[0].split(" states")[0]
-    lines.append(f"{a['pattern']} | {a['mode']} | {a['result']} | {b['gbs']:.0f} | {a['count_call_ms']:.2f} | {a['count_call_gbs']:.0f} | "
-                 f"{a['count_call_gbs'] / 8000:.3f} | {b['count_call_ms']:.2f} | {b['count_call_gbs']:.0f} | {b['count_call_gbs'] / 8000:.3f} | {route}")
+    ka = a.get("kernel_after", a["kernel"])
+    marked = "factor prefilter" in ka
+    route = ("prefilter (k_scan<kClass> + k_rx_verify ...)" if "prefilter route" in ka else
+             "k_rx_scan on the tiles the factor prefilter marked" if marked else ka.split(" stagger")[0].split(" states")[0])
+    later = f"{a['count_call_ms']:.2f} | - | -" if marked else f"{a['count_call_ms']:.2f} | {a['count_call_gbs']:.0f} | {a['count_call_gbs'] / 8000:.3f}"
+    lines.append(f"{a['pattern']} | {a['mode']} | {a['result']} | {b['gbs']:.0f} | {a.get('first_call_ms', 0):.2f} | {a.get('first_call_gbs', 0):.0f} | "
+                 f"{later} | {b['count_call_ms']:.2f} | {b['count_call_gbs']:.0f} | {route}")
 (ROOT / "profiles" / "r02_rx_sweep.txt").write_text("\n".join(lines) + "\n")
 pm = out / "rx_pmc" / "summary.txt"
 if pm.exists():
@@ -36,4 +43,4 @@ if pm.exists():
             "# cases: rx_none `zzz+` (no trigger byte in the text: the staging phase alone), rx_alt `Sherlock|Holmes`,",
             "# rx_dotstar `Sher.*mes`, rx_word `\\w+ing` (a trigger at every word: no skipping)"]
     (ROOT / "profiles" / "r02_rx_pmc.txt").write_text("\n".join(head + body) + "\n")
-print("\n".join(lines[6:]))
+print("\n".join(lines[9:]))

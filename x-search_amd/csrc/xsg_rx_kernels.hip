@@ -18,6 +18,8 @@
 // tile, nothing stored when there are none; tile_nl on request; emission at tile_off ranks), so the finish kernel
 // and the whole list pipeline behind it are shared.  The automata are tables of pre-multiplied uint16 row offsets
 // in LDS: next = fwd[state + class_of[byte]]; all of it is byte/integer work, LDS-latency-bound, no MFMA.
+// With a factor prefilter (xsg_api.cpp: ensure_factor_mask) the kernel returns at once from tiles in which no line with
+// an occurrence of the factor starts.
 // The staged tile is translated to class codes in place (one table read per byte, off every dependency chain), the
 // walks read four codes at a time, and a walk in the start state skips from trigger byte to trigger byte.
 #include "xsg_internal.h"
