@@ -38,9 +38,10 @@ while time.monotonic() - t0 < a.minutes * 60:
             regex_rounds(seed, oracle, gs, rounds=10)
         if seed % 3 == 1:  # variable-length expressions: the automaton route, prefilter on (default) / off per seed
             import os
-            os.environ["XSG_RX_PRE"] = "0" if seed % 2 else "1"
+            os.environ["XSG_RX_PRE"] = os.environ["XSG_RX_FAC"] = "0" if seed % 2 else "1"  # both prefilters forced on / off
             rx_rounds(seed, oracle, gs, rounds=6)
             os.environ.pop("XSG_RX_PRE")
+            os.environ.pop("XSG_RX_FAC")
     except AssertionError as e:
         status["failed"] = {"seed": seed, "message": str(e)[:2000]}
         print("FAIL", seed, str(e)[:2000], flush=True)
