@@ -16,7 +16,8 @@
 //            "(a[n|m]t)", the integration tests `She[r ]lock`)
 //   a|b      alternation at any depth, as long as every alternative of the whole expression ends up with the
 //            same length (then leftmost-first has nothing to choose: see xsg_classseq.h)
-// Refused: * + ? {n,m} {n,} ^ $ (?flags) (?P<..>) \b \B \A \z \p \P \Q \C, backslash + letter/digit otherwise,
+// Refused HERE (the caller then tries the automaton route, xsg_regex.cpp, which serves the variable-length operators):
+//   * + ? {n,m} {n,} ^ $ (?flags) (?P<..>) \b \B \A \z \p \P \Q \C, backslash + letter/digit otherwise,
 //   class members >= 0x80, alternatives of different lengths, more than kMaxClassSeq positions, more than
 //   kMaxAlt alternatives (after merging those that differ in one position), an empty expression or alternative.
 #include "xsg_classseq.h"

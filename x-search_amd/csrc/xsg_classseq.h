@@ -7,9 +7,10 @@
 // classes -- `She[r ]lock` (test/src/xsearchTest.cpp:9), `(a[n|m]t)`
 // (test/src/string_search/search_wrappersTest.cpp:78).  For exactly that family
 // a match is a position where every class accepts its byte: the same
-// position-wise decision as a literal, so it runs in k_scan.  Everything else
-// (repetition, alternation, anchors, `.`, negated classes -- the last two match
-// multi-byte UTF-8 code points in RE2) is refused, never approximated.
+// position-wise decision as a literal, so it runs in k_scan.  Expressions of
+// variable length (repetition operators, alternatives of different lengths) are
+// not this family: xsg_regex.h compiles them to automata for a second kernel.
+// Anchors and flags are refused by both, never approximated.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
