@@ -160,7 +160,9 @@ int xsg_set_pattern(xsg_ctx* ctx, const void* pattern, size_t plen, uint32_t fla
  * reference routes on use_str_as_regex, utils/utils.h:17-25).  Optional outputs:
  * the number of byte positions, and their 256-bit sets (room for 32 x 8 uint32;
  * bit b of sets[8*k + b/32] set <=> position k accepts byte b; folded if
- * XSG_FLAG_IGNORE_CASE is in flags). */
+ * XSG_FLAG_IGNORE_CASE is in flags).  *positions == 0: an expression of variable
+ * length, served by the automaton route below (no position-wise sets; whether it
+ * can match a '\n' is xsg_regex_dfa.multiline). */
 int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets);
 /* The same with the whole structure: number of alternatives, whether the expression is exact on ASCII data only
  * ('.', negated classes), and every alternative's sets (room for 64 x 8 uint32, alternative-major).  xsg_regex_check
@@ -170,8 +172,8 @@ int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32_t* positio
 /* Expressions of VARIABLE length (x* x+ x? x{n,m}, lazy forms, alternatives of different lengths) are served by a
  * second route: the library compiles them into a forward (leftmost-first) and a reverse (longest) byte-class DFA
  * and k_rx_scan walks every line with them (csrc/xsg_regex.h; restrictions there: no empty matches, no anchors; an
- * expression with a set that accepts '\n' is walked chunk by chunk instead and serves the match tags only).  xsg_regex_check / xsg_regex_info return XSG_OK with *positions == 0 for such an
- * expression.  This call hands out the automata (for inspection and for the host-side tests, which drive the tables
+ * expression with a set that accepts '\n' is walked chunk by chunk instead and serves the match tags only).
+ * xsg_regex_check / xsg_regex_info return XSG_OK with *positions == 0 for such an expression.  This call hands out the automata (for inspection and for the host-side tests, which drive the tables
  * against another regex engine without a GPU): `info` always; `fwd` / `rev` (row-major, states x ncls entries, each
  * the NEXT STATE'S ROW OFFSET = state * ncls; state 0 is dead, states >= *_first_acc hold a match) if they have room
  * for the tables (cap_entries each).  XSG_ENOTSUP: the expression is not served by this route (it may still be a
