@@ -17,7 +17,7 @@
 // Per-tile outputs are those of k_scan (tile_cnt: matches -- or matching lines -- of the lines that start in the
 // tile, nothing stored when there are none; tile_nl on request; emission at tile_off ranks), so the finish kernel
 // and the whole list pipeline behind it are shared.  The automata are tables of pre-multiplied uint16 row offsets
-// in LDS: next = fwd[state + class_of[byte]]; all of it is byte/integer work, LDS-latency-bound, no MFMA.
+// in LDS: next = fwd[state + class_of[byte]]; all of it is byte/integer work, bound by instruction issue and LDS latency, no MFMA.
 // With a factor prefilter (xsg_api.cpp: ensure_factor_mask) the kernel returns at once from tiles in which no line with
 // an occurrence of the factor starts.
 // The staged tile is translated to class codes in place (one table read per byte, off every dependency chain), the
