@@ -22,277 +22,13 @@
 // summaries) lives in a wave-uniform slow path.
 #include <algorithm>
 
-#include "xsg_internal.h"
+#include "xsg_devutil.h"
 #include "xsg_linesum.h"
 #include "xsg_tail.h"
 
 namespace xsg {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__host__ __device__ constexpr bool is_cls(int kind) { return kind == kClass || kind == kClassFast; }
-
-// ---------------------------------------------------------------------------
-// cross-lane helpers (wave64)
-// ---------------------------------------------------------------------------
-// value of lane+1 (lane 63 receives `edge`)
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t x, uint32_t edge, uint32_t lane) {
-#if defined(XSG_USE_DPP_SHIFT)
-  // v_mov_b32_dpp wave_shl:1 -- lane i reads lane i+1 (gfx9 DPP wavefront shift).
-  // Lane 63 has no source lane: with bound_ctrl off it keeps the destination's old
-  // value, which is preset to `edge` -- two instructions per dword in all.
-  (void)lane;
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130, 0xf, 0xf, false);
-#else
-  const uint32_t y = (uint32_t)__shfl_down((int)x, 1);
-  return lane == 63u ? edge : y;
-#endif
-}
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v += (uint32_t)__shfl_xor((int)v, s);
-  return v;
-}
-// inclusive prefix sum over lanes
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
-    uint32_t o = (uint32_t)__shfl_up((int)v, s);
-    if (lane >= (uint32_t)s) v += o;
-  }
-  return v;
-}
-
-// ordered reduction over the 64 lanes; result valid in lane 0
-__device__ __forceinline__ uint32_t wave_sum_combine(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_down((int)v, s);
-    if ((lane & (uint32_t)(2 * s - 1)) == 0u) v = sum_combine(v, o);
-  }
-  return v;
-}
-
-// Combined summary of the 64 consecutive units of one wave-load: ballots of the
-// lanes' unit summaries, then xsg_linesum.h's O(1) mask algebra (result wave-uniform).
-__device__ __forceinline__ uint32_t wave_units_combine(uint32_t us) {
-  const unsigned long long N = __ballot(us & kSumNl);
-  const unsigned long long Fm = __ballot(us & kSumF);
-  const unsigned long long Lm = __ballot(us & kSumL);
-  const uint32_t c = us >> kSumCShift;  // <= 7 closed segments inside one 16-byte unit
-  const uint32_t csum = (uint32_t)__popcll(__ballot(c & 1u)) + 2u * (uint32_t)__popcll(__ballot(c & 2u)) +
-                        4u * (uint32_t)__popcll(__ballot(c & 4u));
-  return sum_combine_lanes(N, Fm, Lm, csum);
-}
-
-// ---------------------------------------------------------------------------
-// per-unit byte tests
-// ---------------------------------------------------------------------------
-// exact 0x80-per-byte flags of bytes equal to '\n'
-__device__ __forceinline__ uint32_t nl_flags(uint32_t d) {
-  const uint32_t x = d ^ 0x0a0a0a0au;
-  const uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
-  return ~t;  // 0x80 in every byte that was '\n'
-}
-// number of '\n' among the 16 bytes of the unit.  t = nl_flags' intermediate has
-// the low 7 bits of every byte set and bit 7 set iff the byte is NOT a newline, so
-// popcount(t) = 28 + (non-newline bytes) and the four popcounts chain through
-// v_bcnt_u32_b32's accumulator operand: 4 ops per dword + 1.
-__device__ __forceinline__ uint32_t nl_count16(const uint32_t (&d)[8]) {
-  uint32_t acc = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t x = d[q] ^ 0x0a0a0a0au;
-    const uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
-    acc += (uint32_t)__popc(t);
-  }
-  return 128u - acc;
-}
-// bit b set <=> byte b of the unit is '\n'
-__device__ __forceinline__ uint32_t nl_mask16(const uint32_t (&d)[8]) {
-  uint32_t m = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t f = nl_flags(d[q]) >> 7;  // bit 0, 8, 16, 24
-    const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
-    m |= nib << (4 * q);
-  }
-  return m;
-}
-__device__ __forceinline__ bool nl_any16(const uint32_t (&d)[8]) {
-  uint32_t acc = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t x = d[q] ^ 0x0a0a0a0au;
-    acc |= (x - 0x01010101u) & ~x;
-  }
-  return (acc & 0x80808080u) != 0;
-}
-
-// ---- newline searches over arbitrary distances (list kernels, walk_entry) -----------------------------
-// One thread, aligned 16-byte loads only (chunk buffers are padded to 16), 64 bytes per step while nothing is
-// found: a line of a few dozen bytes costs one or two loads, and a scan that has to cross megabytes of a
-// newline-less line moves 8-16x faster than a byte loop would.
-__device__ __forceinline__ uint32_t nl_mask_of_unit(const uint8_t* p) {
-  const uint4 v = *reinterpret_cast<const uint4*>(p);
-  const uint32_t d[8] = {v.x, v.y, v.z, v.w, 0u, 0u, 0u, 0u};
-  return nl_mask16(d);
-}
-__device__ __forceinline__ uint32_t unit_has_nl(const uint8_t* p) {  // 0 / 1; combined with | so that the loads stay independent
-  const uint4 v = *reinterpret_cast<const uint4*>(p);
-  const uint32_t d[8] = {v.x, v.y, v.z, v.w, 0u, 0u, 0u, 0u};
-  return nl_any16(d) ? 1u : 0u;
-}
-// does any of the 256 bytes at p (16-byte aligned) hold a newline?  Sixteen independent loads, one combined test.
-__device__ __forceinline__ bool block_has_nl(const uint8_t* p) {
-  uint32_t acc = 0;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p + u * kUnit);
-    const uint32_t x0 = v.x ^ 0x0a0a0a0au, x1 = v.y ^ 0x0a0a0a0au, x2 = v.z ^ 0x0a0a0a0au, x3 = v.w ^ 0x0a0a0a0au;
-    acc |= ((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) | ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3);
-  }
-  return (acc & 0x80808080u) != 0;  // exact as an existence test
-}
-// offset of the first '\n' in d[lo, hi), or -1
-__device__ __forceinline__ int64_t first_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi) {
-  if (lo >= hi) return -1;
-  uint64_t p = lo & ~(uint64_t)15;
-  uint32_t range = 0xffffu << (uint32_t)(lo - p);  // first unit: positions >= lo
-  for (;;) {
-    if (range == 0xffffu) {  // past the first unit: skip 256, then 64 bytes at a time while they hold no newline
-      while (p + 16 * kUnit <= hi && !block_has_nl(d + p)) p += 16 * kUnit;
-      while (p + 4 * kUnit <= hi && !(unit_has_nl(d + p) | unit_has_nl(d + p + kUnit) | unit_has_nl(d + p + 2 * kUnit) |
-                                      unit_has_nl(d + p + 3 * kUnit)))
-        p += 4 * kUnit;
-    }
-    if (p >= hi) return -1;
-    uint32_t m = nl_mask_of_unit(d + p) & range & 0xffffu;
-    if (hi - p < kUnit) m &= (1u << (uint32_t)(hi - p)) - 1u;
-    if (m) return (int64_t)(p + (uint32_t)__ffs((int)m) - 1u);
-    p += kUnit;
-    range = 0xffffu;
-  }
-}
-// offset of the last '\n' in d[lo, hi), or -1
-__device__ __forceinline__ int64_t last_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi) {
-  if (lo >= hi) return -1;
-  uint64_t p = (hi - 1u) & ~(uint64_t)15;  // unit of the last byte of the range
-  uint32_t range = hi - p >= kUnit ? 0xffffu : (1u << (uint32_t)(hi - p)) - 1u;
-  const uint64_t lo_unit = lo & ~(uint64_t)15;
-  for (;;) {
-    if (range == 0xffffu) {
-      while (p >= lo_unit + 16 * kUnit && !block_has_nl(d + p - 15 * kUnit)) p -= 16 * kUnit;
-      while (p >= lo_unit + 4 * kUnit && !(unit_has_nl(d + p) | unit_has_nl(d + p - kUnit) | unit_has_nl(d + p - 2 * kUnit) |
-                                           unit_has_nl(d + p - 3 * kUnit)))
-        p -= 4 * kUnit;
-    }
-    uint32_t m = nl_mask_of_unit(d + p) & range;
-    if (p < lo) m &= 0xffffu << (uint32_t)(lo - p);  // only in the unit that holds lo
-    m &= 0xffffu;
-    if (m) return (int64_t)(p + 31u - (uint32_t)__clz(m));
-    if (p <= lo_unit) return -1;
-    p -= kUnit;
-    range = 0xffffu;
-  }
-}
-
-// ---- the same searches by a whole wave ---------------------------------------------------------------
-// One lane moves ~0.25 GB/s through a newline-less stretch however the loads are arranged; a line of hundreds of
-// megabytes (a minified file, a binary blob) would keep a list kernel busy for seconds per scan.  All 64 lanes
-// together read 4 KiB per step.  Every lane must call these with the SAME arguments (and all 64 must be active).
-__device__ __forceinline__ int64_t wave_first_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi, uint32_t lane) {
-  if (lo >= hi) return -1;
-  constexpr int U = 4;
-  for (uint64_t p = lo & ~(uint64_t)15; p < hi; p += (uint64_t)U * 64u * kUnit) {
-    uint32_t m[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t a = p + ((uint64_t)u * 64u + lane) * kUnit;
-      uint32_t x = 0;
-      if (a < hi) {
-        x = nl_mask_of_unit(d + a) & 0xffffu;
-        if (a < lo) x &= 0xffffu << (uint32_t)(lo - a);  // the unit that holds lo
-        if (hi - a < kUnit) x &= (1u << (uint32_t)(hi - a)) - 1u;
-      }
-      m[u] = x;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned long long b = __ballot(m[u] != 0);
-      if (b) {
-        const int L = __builtin_ctzll(b);  // lowest address of the group
-        const uint32_t mm = (uint32_t)__shfl((int)m[u], L);
-        return (int64_t)(p + ((uint64_t)u * 64u + (uint64_t)L) * kUnit + (uint32_t)__ffs((int)mm) - 1u);
-      }
-    }
-  }
-  return -1;
-}
-__device__ __forceinline__ int64_t wave_last_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi, uint32_t lane) {
-  if (lo >= hi) return -1;
-  constexpr int U = 4;
-  const uint64_t top = (hi - 1u) & ~(uint64_t)15;               // unit of the last byte
-  const uint64_t K = (top - (lo & ~(uint64_t)15)) / kUnit;      // units are numbered downwards from the top: 0..K
-  for (uint64_t kb = 0; kb <= K; kb += (uint64_t)U * 64u) {
-    uint32_t m[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t k = kb + (uint64_t)u * 64u + lane;
-      uint32_t x = 0;
-      if (k <= K) {
-        const uint64_t a = top - k * kUnit;
-        x = nl_mask_of_unit(d + a) & 0xffffu;
-        if (a < lo) x &= 0xffffu << (uint32_t)(lo - a);
-        if (hi - a < kUnit) x &= (1u << (uint32_t)(hi - a)) - 1u;
-      }
-      m[u] = x;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned long long b = __ballot(m[u] != 0);
-      if (b) {
-        const int L = __builtin_ctzll(b);  // smallest k = highest address of the group
-        const uint32_t mm = (uint32_t)__shfl((int)m[u], L);
-        const uint64_t a = top - (kb + (uint64_t)u * 64u + (uint64_t)L) * kUnit;
-        return (int64_t)(a + 31u - (uint32_t)__clz(mm));
-      }
-    }
-  }
-  return -1;
-}
-
-// A newline query per lane (live lanes only), FORWARD: first in [lo, hi), else last in [lo, hi).  Each lane looks
-// kSoloScan bytes far on its own -- that settles every ordinary line -- and the whole wave then finishes the
-// queries that are still open, one after the other.  All 64 lanes of the wave must call this together.
-constexpr uint64_t kSoloScan = 4096;
-template <bool FORWARD>
-__device__ __forceinline__ int64_t newline_query(bool live, const uint8_t* d, uint64_t lo, uint64_t hi, uint32_t lane) {
-  int64_t res = -1;
-  bool pending = false;
-  if (live && lo < hi) {
-    if (FORWARD) {
-      const uint64_t cut = hi - lo > kSoloScan ? lo + kSoloScan : hi;
-      res = first_newline_in(d, lo, cut);
-      if (res < 0 && cut < hi) pending = true, lo = cut;
-    } else {
-      const uint64_t cut = hi - lo > kSoloScan ? hi - kSoloScan : lo;
-      res = last_newline_in(d, cut, hi);
-      if (res < 0 && cut > lo) pending = true, hi = cut;
-    }
-  }
-  unsigned long long pend = __ballot(pending);
-  while (pend) {  // wave-uniform
-    const int L = __builtin_ctzll(pend);
-    const uint8_t* dd = reinterpret_cast<const uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)d, L));
-    const uint64_t l2 = (uint64_t)__shfl((long long)lo, L), h2 = (uint64_t)__shfl((long long)hi, L);
-    const int64_t r = FORWARD ? wave_first_newline_in(dd, l2, h2, lane) : wave_last_newline_in(dd, l2, h2, lane);
-    if ((int)lane == L) res = r;
-    pend &= pend - 1ull;
-  }
-  return res;
-}
+// (cross-lane helpers, byte tests and newline searches: xsg_devutil.h)
 
 // w[b] = the 4 bytes starting at byte b of the lane's 32-byte view (own unit + neighbour's)
 // simd::toLower on 4 bytes at once (src/utils/string_utils.cpp:11-33): bytes in
@@ -1026,19 +762,6 @@ hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s) {
 // partial sums and writes the four counters (device and, if given, a pinned
 // host mirror), so the counters need no zeroing either.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* sh) {
-  // sh: kWaves entries
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v += (uint64_t)__shfl_xor((long long)v, s);
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (lane == 0) sh[wave] = v;
-  __syncthreads();
-  uint64_t t = 0;
-  if (threadIdx.x == 0)
-    for (int w = 0; w < kWaves; ++w) t += sh[w];
-  __syncthreads();
-  return t;  // valid in thread 0
-}
 
 // where the reference walk stands when it reaches the tail zone of a chunk: after the last bulk match (match
 // modes), at the start of the line after the last bulk matching line (line modes; UINT64_MAX if that line has
@@ -1266,527 +989,6 @@ hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s) {
   if (blocks < 1) blocks = 1;
   if (blocks > kFinishBlocks) blocks = kFinishBlocks;
   hipLaunchKernelGGL(k_count_finish, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// exclusive scan (uint32 or uint64 in -> uint64 out), three small kernels
-// ---------------------------------------------------------------------------
-constexpr int kScanItems = 8;
-constexpr uint64_t kScanBlockElems = (uint64_t)kBlock * kScanItems;
-
-uint64_t scan_tmp_elems(uint64_t n) { return (n + kScanBlockElems - 1) / kScanBlockElems + 1; }
-
-__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, uint32_t lane) {
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
-    uint64_t o = (uint64_t)__shfl_up((long long)v, s);
-    if (lane >= (uint32_t)s) v += o;
-  }
-  return v;
-}
-
-// block-wide exclusive scan of one value per thread; returns exclusive prefix, *total = block sum
-__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* sh, uint64_t* total) {
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint64_t incl = wave_incl_scan_u64(v, lane);
-  if (lane == 63) sh[wave] = incl;
-  __syncthreads();
-  uint64_t base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < kWaves; ++w) {
-    if ((uint32_t)w < wave) base += sh[w];
-    tot += sh[w];
-  }
-  __syncthreads();
-  *total = tot;
-  return base + incl - v;
-}
-
-// UINT64_MAX in a uint64 input is the "dropped line" marker of k_line_lengths: it scans as 0
-__device__ __forceinline__ uint64_t scan_val(uint32_t v) { return v; }
-__device__ __forceinline__ uint64_t scan_val(uint64_t v) { return v == UINT64_MAX ? 0 : v; }
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_scan_block_sums(const T* in, uint64_t n, uint64_t* block_sums) {
-  __shared__ uint64_t sh[kWaves];
-  const uint64_t b0 = (uint64_t)blockIdx.x * kScanBlockElems + (uint64_t)threadIdx.x * kScanItems;
-  uint64_t v = 0;
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k)
-    if (b0 + k < n) v += scan_val(in[b0 + k]);
-  uint64_t tot;
-  block_excl_scan_u64(v, sh, &tot);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-// single block: exclusive scan of block_sums in place (nb entries), total appended at [nb]
-__global__ __launch_bounds__(kBlock) void k_scan_top(uint64_t* block_sums, uint64_t nb) {
-  __shared__ uint64_t sh[kWaves];
-  uint64_t carry = 0;
-  for (uint64_t i0 = 0; i0 < nb; i0 += kBlock) {
-    const uint64_t i = i0 + threadIdx.x;
-    const uint64_t v = i < nb ? block_sums[i] : 0;
-    uint64_t tot;
-    const uint64_t ex = block_excl_scan_u64(v, sh, &tot);
-    if (i < nb) block_sums[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) block_sums[nb] = carry;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_scan_write(const T* in, uint64_t n, const uint64_t* block_sums,
-                                                       uint64_t* out) {
-  __shared__ uint64_t sh[kWaves];
-  const uint64_t b0 = (uint64_t)blockIdx.x * kScanBlockElems + (uint64_t)threadIdx.x * kScanItems;
-  uint64_t x[kScanItems];
-  uint64_t v = 0;
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    x[k] = b0 + k < n ? scan_val(in[b0 + k]) : 0;
-    v += x[k];
-  }
-  uint64_t tot;
-  uint64_t run = block_sums[blockIdx.x] + block_excl_scan_u64(v, sh, &tot);
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    if (b0 + k < n) out[b0 + k] = run;
-    run += x[k];
-  }
-  // the grand total goes to out[n]
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = block_sums[gridDim.x];
-}
-
-__global__ void k_set_u64(uint64_t* p, uint64_t v) { *p = v; }
-
-template <typename T>
-static hipError_t exclusive_scan_impl(const T* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s) {
-  if (n == 0) {
-    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, out, (uint64_t)0);
-    return hipGetLastError();
-  }
-  const uint64_t nb = (n + kScanBlockElems - 1) / kScanBlockElems;
-  hipLaunchKernelGGL((k_scan_block_sums<T>), dim3((unsigned)nb), dim3(kBlock), 0, s, in, n, tmp);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, tmp, nb);
-  hipLaunchKernelGGL((k_scan_write<T>), dim3((unsigned)nb), dim3(kBlock), 0, s, in, n, tmp, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s) {
-  return exclusive_scan_impl<uint32_t>(in, out, n, tmp, s);
-}
-hipError_t launch_exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s) {
-  return exclusive_scan_impl<uint64_t>(in, out, n, tmp, s);
-}
-
-// ---------------------------------------------------------------------------
-// list post-processing: one thread per raw match / per chunk.  Matches are
-// sparse at text densities (~5e-7 per byte), so these are latency-, not
-// bandwidth-bound and deliberately simple.
-// ---------------------------------------------------------------------------
-static inline dim3 grid_for(uint64_t n) {
-  uint64_t b = (n + kBlock - 1) / kBlock;
-  if (b < 1) b = 1;
-  return dim3((unsigned)b);
-}
-
-// number of raw entries the list kernels work on: the host's value, or the device's bounded by the arrays' capacity
-__device__ __forceinline__ uint64_t list_count(const ListArgs& A) {
-  if (!A.M_dev) return A.M;
-  const uint64_t m = *A.M_dev;
-  return m < A.M ? m : A.M;
-}
-
-__global__ void k_keep_all(const ListArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < list_count(A)) A.keep[i] = 1u;
-}
-
-// Greedy non-overlap (shift = match + plen, simd_search.cpp:333 /
-// search_wrappers.h:42): only patterns with a border can overlap themselves.
-// An occurrence >= plen after its predecessor is always kept and starts a
-// chain; the thread owning a chain head walks its chain.
-__global__ void k_greedy_keep(const ListArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint64_t M = list_count(A);
-  if (i >= M) return;
-  const uint32_t plen = A.pat.plen;
-  const uint32_t c = A.m_chunk[i];
-  const bool head = i == 0 || A.m_chunk[i - 1] != c || A.m_pos[i] - A.m_pos[i - 1] >= plen;
-  if (!head) return;
-  A.keep[i] = 1u;
-  uint64_t last = A.m_pos[i], prev = last;
-  // The walk is a chain of dependent decisions, but not of dependent LOADS: eight entries are fetched at a time
-  // (independent loads, one latency) and decided from registers -- a long chain (a run of one byte searched for
-  // `aa` is one chain per chunk) moves at ~6 ns per occurrence instead of ~50.
-  for (uint64_t j = i + 1; j < M;) {
-    uint64_t p[8];
-    uint32_t ch[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const uint64_t idx = j + (uint64_t)u < M ? j + (uint64_t)u : M - 1;
-      p[u] = A.m_pos[idx];
-      ch[u] = A.m_chunk[idx];
-    }
-    bool done = false;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (done || j + (uint64_t)u >= M) continue;
-      if (ch[u] != c || p[u] - prev >= plen) {  // the chain ends: the next occurrence is a head of its own
-        done = true;
-        continue;
-      }
-      const bool k = p[u] >= last + plen;
-      A.keep[j + (uint64_t)u] = k ? 1u : 0u;
-      if (k) last = p[u];
-      prev = p[u];
-    }
-    if (done) break;
-    j += 8;
-  }
-}
-
-// Which raw matches survive the skip_to_nl walk, and their line starts
-// (search_wrappers.h:111-123,149-154).  A match is the first of its line iff a
-// '\n' lies between the previous match and it, so every thread scans back only as
-// far as the previous match (the first match of a chunk: to the chunk start).  The
-// scans of one chunk are disjoint: O(chunk) bytes in total however long the lines
-// are (a walk back to the line start per match would be quadratic on one huge line).
-__global__ __launch_bounds__(kBlock) void k_line_starts_keep(const ListArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool live = i < A.M;  // no early return: the wave finishes long scans together (newline_query)
-  const uint32_t c = live ? A.m_chunk[i] : 0u;
-  const uint8_t* d = A.base + A.chunks[c].offset;
-  const bool first_in_chunk = live && (i == 0 || A.m_chunk[i - 1] != c);
-  const uint64_t lo = (!live || first_in_chunk) ? 0 : A.m_pos[i - 1];
-  const uint64_t hi = live ? A.m_pos[i] : 0;
-  // the newline that opens the match's line, if it lies in [lo, match)
-  const int64_t nl = newline_query<false>(live, d, lo, hi, threadIdx.x & 63u);
-  if (!live) return;
-  const bool found_nl = nl >= 0;
-  A.keep[i] = (found_nl || first_in_chunk) ? 1u : 0u;
-  A.m_ls[i] = found_nl ? (uint64_t)nl + 1u : lo;  // meaningful for kept matches only (0 for a first match on the chunk's first line)
-}
-
-// per chunk: where the walk enters the tail zone, from the last kept bulk match
-__global__ __launch_bounds__(kBlock) void k_chunk_shift0(const ListArgs A) {
-  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool live = c < A.nchunks;
-  uint64_t last_end = 0;
-  ChunkDev ch{};
-  if (live) {
-    const uint64_t M = list_count(A);
-    uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
-    r0 = r0 < M ? r0 : M;  // bounded emission: entries beyond the capacity do not exist (the total is refused later)
-    r1 = r1 < M ? r1 : M;
-    // last kept raw match of the chunk (kept ones are never far from the end of a chain)
-    for (uint64_t i = r1; i > r0; --i) {
-      if (A.keep[i - 1]) {
-        last_end = A.m_pos[i - 1] + A.pat.plen;
-        break;
-      }
-    }
-    ch = A.chunks[c];
-  }
-  // line modes: the walk continues at the start of the line after the last kept match (UINT64_MAX: no such line)
-  const bool need_nl = live && last_end != 0 && A.line_mode != 0;
-  const int64_t nl = newline_query<true>(need_nl, A.base + ch.offset, last_end, ch.length, threadIdx.x & 63u);
-  if (!live) return;
-  A.chunk_shift0[c] = last_end == 0 ? 0 : !A.line_mode ? last_end : nl < 0 ? UINT64_MAX : (uint64_t)nl + 1u;
-}
-
-__global__ void k_tail_list(const ListArgs A) {
-  const uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (c >= A.nchunks) return;
-  uint32_t n = 0;
-  if (!A.pat.exact_tail && A.pat.plen > 1) {
-    const ChunkDev ch = A.chunks[c];
-    n = tail_walk(A.base + ch.offset, ch.length, A.pat.d_pat, A.pat.plen, A.chunk_shift0[c], A.line_mode != 0,
-                  A.tail_pos + c * A.tail_cap, A.tail_cap, A.pat.icase != 0);
-  }
-  A.tail_cnt[c] = n;
-}
-
-// final list = per chunk: kept bulk matches, then the tail walk's matches
-__global__ void k_assemble(const ListArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < A.M && A.keep[i]) {
-    const uint32_t c = A.m_chunk[i];
-    const uint64_t dst = A.keep_pre[i] + A.tail_pre[c];
-    A.f_pos[dst] = A.line_mode ? A.m_ls[i] : A.m_pos[i];
-    A.f_match[dst] = A.m_pos[i];
-    A.f_chunk[dst] = c;
-  }
-  // the tail walk's matches, one thread per chunk; their line starts may lie a whole huge line back, so the
-  // loop runs wave-uniformly (up to the largest count in the wave) and the wave shares long scans
-  const bool has_chunk = i < A.nchunks;
-  const uint64_t c = has_chunk ? i : 0;
-  const uint32_t n = has_chunk ? A.tail_cnt[c] : 0u;
-  uint32_t nmax = n;
-#pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)nmax, sft);
-    nmax = o > nmax ? o : nmax;
-  }
-  if (nmax) {
-    const uint64_t r1 = has_chunk ? A.tile_off[A.chunk_tile0[c + 1]] : 0;
-    const uint64_t dst0 = has_chunk ? A.keep_pre[r1] + A.tail_pre[c] : 0;
-    const uint8_t* d = A.base + A.chunks[c].offset;
-    for (uint32_t k = 0; k < nmax; ++k) {
-      const bool live = k < n;
-      const uint64_t m = live ? A.tail_pos[c * A.tail_cap + k] : 0;
-      const int64_t nl = newline_query<false>(live && A.line_mode != 0, d, 0, m, threadIdx.x & 63u);
-      if (live) {
-        A.f_pos[dst0 + k] = !A.line_mode ? m : nl < 0 ? 0u : (uint64_t)nl + 1u;
-        A.f_match[dst0 + k] = m;
-        A.f_chunk[dst0 + k] = (uint32_t)c;
-      }
-    }
-  }
-}
-
-// xsg_count_async for patterns that can overlap themselves: the greedy walk's count without a trip to the host
-__global__ __launch_bounds__(kBlock) void k_bordered_total(const ListArgs A, uint64_t* counters) {
-  __shared__ uint64_t sh[kWaves];
-  const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint64_t gsz = (uint64_t)gridDim.x * kBlock;
-  const uint64_t M = list_count(A);
-  uint64_t n = 0;
-  for (uint64_t i = gid; i < M; i += gsz) n += A.keep[i];
-  for (uint64_t c = gid; c < A.nchunks; c += gsz) n += A.tail_cnt[c];
-  const uint64_t t = block_sum_u64(n, sh);
-  if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&counters[XSG_CTR_MATCHES], (unsigned long long)t);
-}
-__global__ void k_bordered_seal(const ListArgs A, uint64_t* counters, uint64_t total_bytes, uint32_t* flags) {
-  const bool overflow = A.M_dev && *A.M_dev > A.M;
-  const bool refuse = (A.pat.kind == kClass || A.pat.kind == kDfa) && A.pat.ascii_only && (*flags & 1u);
-  *flags = 0u;
-  if (overflow || refuse) {
-    for (int k = 0; k < XSG_NUM_COUNTERS; ++k) counters[k] = UINT64_MAX;
-  } else {
-    counters[XSG_CTR_BYTES] = total_bytes;
-  }
-}
-
-hipError_t launch_bordered_total(const ListArgs& a, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, hipStream_t s) {
-  uint64_t blocks = (std::max<uint64_t>(a.M, a.nchunks) + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
-  if (blocks < 1) blocks = 1;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_bordered_total, dim3((unsigned)blocks), dim3(kBlock), 0, s, a, counters);
-  hipLaunchKernelGGL(k_bordered_seal, dim3(1), dim3(1), 0, s, a, counters, total_bytes, flags);
-  return hipGetLastError();
-}
-
-hipError_t launch_keep_all(const ListArgs& a, hipStream_t s) {
-  if (!a.M) return hipSuccess;
-  hipLaunchKernelGGL(k_keep_all, grid_for(a.M), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s) {
-  if (!a.M) return hipSuccess;
-  hipLaunchKernelGGL(k_greedy_keep, grid_for(a.M), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_line_starts_keep(const ListArgs& a, hipStream_t s) {
-  if (!a.M) return hipSuccess;
-  hipLaunchKernelGGL(k_line_starts_keep, grid_for(a.M), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s) {
-  if (!a.nchunks) return hipSuccess;
-  hipLaunchKernelGGL(k_chunk_shift0, grid_for(a.nchunks), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_tail_list(const ListArgs& a, hipStream_t s) {
-  if (!a.nchunks) return hipSuccess;
-  hipLaunchKernelGGL(k_tail_list, grid_for(a.nchunks), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_assemble(const ListArgs& a, hipStream_t s) {
-  const uint64_t n = a.M > a.nchunks ? a.M : a.nchunks;
-  if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_assemble, grid_for(n), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// outputs of the list modes
-// ---------------------------------------------------------------------------
-__global__ void k_globalize(const LineOutArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < A.total) A.out_u64[i] = A.chunks[A.f_chunk[i]].global_offset + A.f_pos[i];
-}
-
-// xs::line_indices: number of '\n' before the line start
-// = newlines in all tiles before the line's tile (exclusive scan of tile_nl) + newlines between the tile start
-// and the line start.  Counting from the tile start for every line would cost O(lines x tile) when most lines
-// match (66 M lines in 10 GiB: 90 ms); instead every list entry counts only the gap back to the previous entry
-// (the previous entry of the same tile, else both ends from their tile starts), and one prefix sum over the
-// entries turns the differences into counts: O(shard) whatever the density.
-__device__ __forceinline__ uint32_t unit_newlines(const uint8_t* p) {
-  const uint4 v = *reinterpret_cast<const uint4*>(p);
-  return (uint32_t)__popc(nl_flags(v.x)) + (uint32_t)__popc(nl_flags(v.y)) + (uint32_t)__popc(nl_flags(v.z)) +
-         (uint32_t)__popc(nl_flags(v.w));
-}
-// newlines among bytes [lo, hi) of the aligned 16-byte unit at p
-__device__ __forceinline__ uint32_t unit_newlines_masked(const uint8_t* p, uint32_t lo, uint32_t hi) {
-  const uint4 v = *reinterpret_cast<const uint4*>(p);
-  const uint32_t f[4] = {nl_flags(v.x), nl_flags(v.y), nl_flags(v.z), nl_flags(v.w)};
-  uint32_t n = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t b0 = 4u * q;
-    uint32_t keep = 0xffffffffu;
-    if (lo > b0) keep &= lo >= b0 + 4 ? 0u : 0xffffffffu << (8u * (lo - b0));
-    if (hi < b0 + 4) keep &= hi <= b0 ? 0u : 0xffffffffu >> (8u * (b0 + 4 - hi));
-    n += (uint32_t)__popc(f[q] & keep);
-  }
-  return n;
-}
-// Newlines in d[from, to) with aligned 16-byte loads only (a gap is ~30 bytes when most lines match: byte loads
-// would be 10x the memory operations); the units at both ends are masked.  Chunk buffers are padded to 16.
-// The interior runs four independent loads per step: a walk over a whole tile is latency-bound otherwise.
-__device__ __forceinline__ uint64_t count_newlines(const uint8_t* d, uint64_t from, uint64_t to) {
-  if (from >= to) return 0;
-  uint64_t n = 0;
-  uint64_t p = from & ~(uint64_t)15;
-  if (p < from) {  // leading partial unit
-    const uint64_t end = p + kUnit < to ? p + kUnit : to;
-    n += unit_newlines_masked(d + p, (uint32_t)(from - p), (uint32_t)(end - p));
-    p += kUnit;
-  }
-  for (; p + 4 * kUnit <= to; p += 4 * kUnit)
-    n += unit_newlines(d + p) + unit_newlines(d + p + kUnit) + unit_newlines(d + p + 2 * kUnit) +
-         unit_newlines(d + p + 3 * kUnit);
-  for (; p + kUnit <= to; p += kUnit) n += unit_newlines(d + p);
-  if (p < to) n += unit_newlines_masked(d + p, 0u, (uint32_t)(to - p));  // trailing partial unit
-  return n;
-}
-
-// shard-wide newline count before entry i's line start, from its tile's prefix (up to one tile of counting)
-__device__ __forceinline__ uint64_t newlines_before_entry(const LineOutArgs& A, uint64_t i) {
-  const uint32_t c = A.f_chunk[i];
-  const uint8_t* d = A.base + A.chunks[c].offset;
-  const uint64_t b = A.f_pos[i];
-  const uint32_t sh = 31u - (uint32_t)__clz(A.tile_bytes);  // tiles are a power of two
-  const uint64_t tl = b >> sh;
-  return A.tile_nl_off[A.chunk_tile0[c] + tl] + count_newlines(d, tl << sh, b);
-}
-
-// An entry is "near" if the previous entry is in the same chunk and at most a quarter tile back: its gap is
-// counted directly -- when most lines match the gaps are tens of bytes and no thread walks a tile while its wave
-// waits.  Farther apart, the entry counts from its tile start (at most 4x the bytes of its gap).
-__device__ __forceinline__ bool entry_is_near(const LineOutArgs& A, uint64_t i) {
-  return i > 0 && A.f_chunk[i - 1] == A.f_chunk[i] && A.f_pos[i] - A.f_pos[i - 1] <= A.tile_bytes / 4u;
-}
-
-// pass 1: the far entries get their absolute count (into out_u64, overwritten by k_line_indices later)
-__global__ void k_line_nl_abs(const LineOutArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= A.total) return;
-  if (!entry_is_near(A, i)) A.out_u64[i] = newlines_before_entry(A, i);
-}
-
-// pass 2: line_len[i] = (newlines before entry i) - (newlines before entry i-1); entry 0: its own count.
-__global__ void k_line_nl_delta(const LineOutArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= A.total) return;
-  uint64_t delta;
-  if (entry_is_near(A, i)) {
-    const uint8_t* d = A.base + A.chunks[A.f_chunk[i]].offset;
-    delta = count_newlines(d, A.f_pos[i - 1], A.f_pos[i]);  // line starts ascend inside a chunk
-  } else {
-    const uint64_t prev = i == 0 ? 0u : entry_is_near(A, i - 1) ? newlines_before_entry(A, i - 1) : A.out_u64[i - 1];
-    delta = A.out_u64[i] - prev;
-  }
-  A.line_len[i] = delta;
-}
-
-// line_out_off = exclusive prefix sums of the deltas (total + 1 entries): entry i's count is line_out_off[i + 1]
-__global__ void k_line_indices(const LineOutArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= A.total) return;
-  const uint32_t c = A.f_chunk[i];
-  const ChunkDev ch = A.chunks[c];
-  const uint64_t n = A.line_out_off[i + 1];
-  if (ch.line_base == XSG_LINE_BASE_AUTO)
-    A.out_u64[i] = A.shard_line_base + n;
-  else
-    A.out_u64[i] = ch.line_base + (n - A.tile_nl_off[A.chunk_tile0[c]]);
-}
-
-// xs::lines: [line start, next '\n' after the match); a line without '\n' is
-// dropped (search_wrappers.h:199-202)
-__global__ __launch_bounds__(kBlock) void k_line_lengths(const LineOutArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool live = i < A.total;  // no early return: see newline_query
-  const ChunkDev ch = A.chunks[live ? A.f_chunk[i] : 0u];
-  const uint8_t* d = A.base + ch.offset;
-  const int64_t e = newline_query<true>(live, d, live ? A.f_match[i] + A.pat.plen : 0, ch.length, threadIdx.x & 63u);
-  if (!live) return;
-  A.line_len[i] = e < 0 ? UINT64_MAX : (uint64_t)e - A.f_pos[i];
-  A.out_u64[i] = ch.global_offset + A.f_pos[i];
-}
-
-// xs::lines: the bytes of every reported line, packed.  One THREAD per line: a line of text is a few dozen bytes,
-// which a lane moves with one or two 16-byte loads and stores (unaligned global accesses are native on gfx950) --
-// a wave per line, the first version, kept 64 lanes busy with 30 bytes (19 ms for the 66 M lines that contain
-// `She` in 10 GiB).  Lines over 256 bytes wait until the wave has finished its short ones and are then copied by
-// all 64 lanes together, 1 KiB a step.
-typedef unsigned int uint4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
-__global__ __launch_bounds__(kBlock) void k_line_gather(const LineOutArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint64_t len = i < A.total ? A.line_len[i] : UINT64_MAX;
-  const bool live = len != UINT64_MAX;  // UINT64_MAX: no terminating newline -> not reported
-  const uint8_t* src = live ? A.base + A.chunks[A.f_chunk[i]].offset + A.f_pos[i] : nullptr;
-  uint8_t* dst = live ? A.line_bytes + A.line_out_off[i] : nullptr;
-  if (!live) len = 0;
-  const bool big = len > 256;
-  if (!big) {
-    uint64_t k = 0;
-    for (; k + 16 <= len; k += 16) *reinterpret_cast<uint4_unaligned*>(dst + k) = *reinterpret_cast<const uint4_unaligned*>(src + k);
-    for (; k < len; ++k) dst[k] = src[k];
-  }
-  unsigned long long pend = __ballot(big);
-  while (pend) {  // wave-uniform
-    const int L = __builtin_ctzll(pend);
-    pend &= pend - 1ull;
-    const uint8_t* s2 = reinterpret_cast<const uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)src, L));
-    uint8_t* d2 = reinterpret_cast<uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)dst, L));
-    const uint64_t n2 = (uint64_t)__shfl((long long)len, L);
-    const uint64_t whole = n2 & ~(uint64_t)15;
-    for (uint64_t k = (uint64_t)lane * 16u; k < whole; k += 64u * 16u)
-      *reinterpret_cast<uint4_unaligned*>(d2 + k) = *reinterpret_cast<const uint4_unaligned*>(s2 + k);
-    if (whole + lane < n2) d2[whole + lane] = s2[whole + lane];
-  }
-}
-
-hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s) {
-  if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_globalize, grid_for(a.total), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_line_nl_delta(const LineOutArgs& a, hipStream_t s) {
-  if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_line_nl_abs, grid_for(a.total), dim3(kBlock), 0, s, a);
-  hipLaunchKernelGGL(k_line_nl_delta, grid_for(a.total), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_line_indices(const LineOutArgs& a, hipStream_t s) {
-  if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_line_indices, grid_for(a.total), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_line_lengths(const LineOutArgs& a, hipStream_t s) {
-  if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_line_lengths, grid_for(a.total), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s) {
-  if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_line_gather, grid_for(a.total), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 
