@@ -587,6 +587,8 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   s->hot_serial = 0;
   s->pre_dense_serial = 0;
   s->mask_serial = s->mask_dense_serial = 0;
+  s->fast_dense_serial = 0;
+  s->fast_result = false;
   bool grew = false;
   XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
   XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
@@ -1238,6 +1240,287 @@ static int d2h_u64(xsg_ctx* c, const uint64_t* d, uint64_t* h) {
   return XSG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The one-sync list route.  A list search on the exact route below fetches three to four sizes from the device (raw
+// occurrences, kept + tail matches, line bytes), each a stream sync, and launches 17-25 small kernels -- ~0.45 ms on
+// top of a 1.5 ms scan of 10 GiB for a few thousand matches (profiles/r03_list_before_kernel_trace.txt).  Here the
+// sizes stay on the device: arrays get capacities (a sparse result fits them by a wide margin), every kernel reads
+// the counts it needs from a block of device words (FastTot) and bounds itself, the tile ranks and the keep prefix
+// take two launches each (ticketed last workgroup), the emit pass visits only the tiles that hold a match, the
+// end-of-chunk walk is one wave per chunk on bit masks, and totals and results are ALSO stored into pinned host
+// memory by the kernels that produce them.  The host syncs once and reads them there.  A result that does not fit
+// (kTotOverflow) is redone on the exact route, which reuses the tile counts of this pass; the binding remembers it.
+// ---------------------------------------------------------------------------
+constexpr int kFastOverflow = 2;  // run_list_fast: capacity exceeded, tile counts in place -> the exact route from step 2
+
+static uint64_t fast_capacity(const xsg_shard* s) {
+  if (const char* e = getenv("XSG_LIST_CAP")) {  // tests: tiny capacities force the fallback
+    const long long v = atoll(e);
+    if (v > 0) return (uint64_t)v;
+  }
+  // one entry per 256 bytes of text, 16 Ki .. 1 Mi entries (a 16 MiB chunk of the file pipeline: 64 Ki)
+  return std::min<uint64_t>(std::max<uint64_t>(s->total_bytes / 256, 1u << 14), 1u << 20);
+}
+
+static bool fast_route_serves(const xsg_shard* s, uint32_t mode, bool outputs) {
+  const xsg_ctx* c = s->ctx;
+  const char* e = getenv("XSG_LIST_FAST");  // 0: every list search takes the exact route (tests, A/B)
+  if ((e && *e == '0') || !outputs || s->ntiles == 0 || s->want_nl_total) return false;
+  if (c->pat.kind == kDfa) return false;                                // k_rx_scan / the prefilter route: exact route
+  if (mode == XSG_MATCH_BYTE_OFFSETS && c->bordered) return false;      // greedy keep: exact route
+  if (s->chunks.size() > (1u << 20)) return false;                      // the tail prefix is one workgroup's work
+  if (s->ntiles >= (1ull << 32)) return false;                          // hit list: uint32 tile numbers
+  return s->fast_dense_serial != c->pattern_serial;
+}
+
+template <typename T>
+static int ensure_pinned(T** p, size_t* cap_elems, size_t want_elems) {
+  if (*p && *cap_elems >= want_elems) return XSG_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap_elems = 0;
+  hipError_t e = hipHostMalloc((void**)p, std::max<size_t>(want_elems, 1) * sizeof(T), hipHostMallocDefault);
+  if (e != hipSuccess) return fail(XSG_ENOMEM, "hipHostMalloc(%zu) failed: %s", want_elems * sizeof(T), hipGetErrorString(e));
+  *cap_elems = want_elems;
+  return XSG_OK;
+}
+
+static int run_list_fast(xsg_shard* s, uint32_t mode) {
+  xsg_ctx* c = s->ctx;
+  hipStream_t st = c->stream;
+  const bool line_mode = mode != XSG_MATCH_BYTE_OFFSETS;
+  const bool want_f = mode == XSG_LINE_INDICES || mode == XSG_LINES;
+  const uint64_t nchunks = s->chunks.size(), ntiles = s->ntiles;
+  const uint64_t cap = fast_capacity(s);
+  const uint32_t tail_cap = std::max<uint32_t>(tail_max_matches(c->pat.plen), 1u);
+  const uint64_t fcap = cap + nchunks * tail_cap;  // a list whose raw part fits always fits
+  const uint64_t bytes_cap = std::min<uint64_t>(fcap * 128, 32ull << 20);
+
+  // ---- buffers (grow-only; the file pipeline re-binds the same shard for every chunk)
+  bool grew = false;
+  XSG_TRY(s->d_tot.ensure(8 * kTotWords + 64, &grew));
+  if (grew) HIP_TRY(hipMemsetAsync(s->d_tot.p, 0, 8 * kTotWords + 64, st));  // tickets = 0
+  if (!s->h_tot) HIP_TRY(hipHostMalloc((void**)&s->h_tot, 8 * (kTotWords + 1), hipHostMallocDefault));
+  XSG_TRY(s->d_tile_off.ensure(8 * (ntiles + 1)));
+  XSG_TRY(s->d_scan2.ensure(8 * scan2_tmp_elems(std::max<uint64_t>(ntiles, fcap) + 1)));
+  XSG_TRY(s->d_hit.ensure(4 * cap));
+  XSG_TRY(s->d_m_pos.ensure(8 * cap));
+  XSG_TRY(s->d_m_chunk.ensure(4 * cap));
+  if (line_mode) {
+    XSG_TRY(s->d_m_ls.ensure(8 * cap));
+    XSG_TRY(s->d_keep.ensure(4 * cap));
+    XSG_TRY(s->d_keep_pre.ensure(8 * (cap + 1)));
+  }
+  XSG_TRY(s->d_chunk_shift0.ensure(8 * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_tail_cnt.ensure(4 * std::max<uint64_t>(nchunks, 1)));
+  XSG_TRY(s->d_tail_pos.ensure(8 * std::max<uint64_t>(nchunks, 1) * tail_cap));
+  XSG_TRY(s->d_tail_pre.ensure(8 * (nchunks + 1)));
+  XSG_TRY(s->d_out_u64.ensure(8 * fcap));
+  if (want_f) {
+    XSG_TRY(s->d_f_pos.ensure(8 * fcap));
+    XSG_TRY(s->d_f_match.ensure(8 * fcap));
+    XSG_TRY(s->d_f_chunk.ensure(4 * fcap));
+  }
+  {
+    size_t have = s->h_result_cap / 8;
+    uint64_t* hp = static_cast<uint64_t*>(s->h_result);
+    XSG_TRY(ensure_pinned(&hp, &have, (size_t)fcap));
+    s->h_result = hp;
+    s->h_result_cap = have * 8;
+  }
+  if (mode == XSG_LINES) {
+    XSG_TRY(s->d_line_len.ensure(8 * fcap));
+    XSG_TRY(s->d_line_off.ensure(8 * (fcap + 1)));
+    XSG_TRY(s->d_line_bytes.ensure(bytes_cap));
+    XSG_TRY(ensure_pinned(&s->hp_line_len, &s->hp_line_len_cap, (size_t)fcap));
+    XSG_TRY(ensure_pinned(&s->hp_line_bytes, &s->hp_line_bytes_cap, (size_t)bytes_cap));
+  }
+  const bool want_nl = mode == XSG_LINE_INDICES;
+  if (want_nl) {
+    XSG_TRY(ensure_tile_nl(s));
+    bool g2 = false;
+    XSG_TRY(s->d_tile_nl_off.ensure(8 * (ntiles + 1), &g2));
+    if (g2) s->nl_off_cached = false;
+  }
+  uint64_t* tot = s->d_tot.as<uint64_t>();
+  uint32_t* tickets = reinterpret_cast<uint32_t*>(tot + kTotWords);
+  memset(s->h_tot, 0, 8 * (kTotWords + 1));  // nothing of this shard is in flight: every search ends in a sync
+
+  // ---- 1. bulk count per tile (+ newlines per tile, once per binding)
+  XSG_TRY(choose_hot_filter(s, st));
+  XSG_TRY(prepare_tiles(s, false, st));
+  ScanArgs a = scan_args(s);
+  s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them
+  const bool scan_nl = want_nl && !s->nl_cached;
+  HIP_TRY(launch_scan_count(a, scan_nl, false, st));
+  if (scan_nl) s->nl_cached = true;
+
+  // ---- 2. ranks of the tiles + the ordered list of the tiles that hold a match (two launches)
+  Scan2Args r{};
+  r.in = a.tile_cnt;
+  r.out = s->d_tile_off.as<uint64_t>();
+  r.n_cap = ntiles;
+  r.blk = s->d_scan2.as<uint64_t>();
+  r.ticket = tickets;
+  r.tot_dev = tot + kTotRaw;
+  r.tot_host = s->h_tot + kTotRaw;
+  r.hit_idx = s->d_hit.as<uint32_t>();
+  r.hit_cap = cap;
+  r.hits_dev = tot + kTotHits;
+  r.hits_host = s->h_tot + kTotHits;
+  r.ovf_dev = tot + kTotOverflow;
+  r.ovf_host = s->h_tot + kTotOverflow;
+  r.total_cap = cap;
+  r.ovf_bit = 1;
+  r.ovf_init = 1;
+  HIP_TRY(launch_scan2_u32(r, true, st));
+  if (want_nl && !s->nl_off_cached) {
+    Scan2Args n{};
+    n.in = a.tile_nl;
+    n.out = s->d_tile_nl_off.as<uint64_t>();
+    n.n_cap = ntiles;
+    n.blk = r.blk;
+    n.ticket = tickets;
+    n.tot_dev = tot + kTotNewlines;
+    n.tot_host = s->h_tot + kTotNewlines;
+    HIP_TRY(launch_scan2_u32(n, false, st));
+  }
+
+  // ---- 3. ordered emission, only from the tiles on the list
+  a.tile_off = r.out;
+  a.m_pos = s->d_m_pos.as<uint64_t>();
+  a.m_chunk = s->d_m_chunk.as<uint32_t>();
+  a.m_cap = cap;
+  a.hit_tiles = r.hit_idx;
+  a.n_hits_dev = tot + kTotHits;
+  a.hit_cap = cap;
+  HIP_TRY(launch_scan_emit(a, st));
+
+  // ---- 4. which occurrences the walk reports; 5. the end of every chunk; 6. the list
+  ListArgs l{};
+  l.base = s->base;
+  l.chunks = a.chunks;
+  l.chunk_tile0 = a.chunk_tile0;
+  l.nchunks = nchunks;
+  l.pat = a.pat;
+  l.M = cap;
+  l.M_dev = tot + kTotRaw;
+  l.m_pos = a.m_pos;
+  l.m_chunk = a.m_chunk;
+  l.tile_off = a.tile_off;
+  l.m_ls = s->d_m_ls.as<uint64_t>();
+  l.keep = s->d_keep.as<uint32_t>();
+  l.keep_pre = s->d_keep_pre.as<uint64_t>();
+  l.chunk_shift0 = s->d_chunk_shift0.as<uint64_t>();
+  l.tail_cnt = s->d_tail_cnt.as<uint32_t>();
+  l.tail_pos = s->d_tail_pos.as<uint64_t>();
+  l.tail_cap = tail_cap;
+  l.tail_pre = s->d_tail_pre.as<uint64_t>();
+  l.line_mode = line_mode ? 1u : 0u;
+  l.keep_all = line_mode ? 0u : 1u;
+  l.tot_dev = tot;
+  l.tot_host = s->h_tot;
+  l.ticket = tickets;
+  l.f_cap = fcap;
+  l.f_pos = s->d_f_pos.as<uint64_t>();
+  l.f_match = s->d_f_match.as<uint64_t>();
+  l.f_chunk = s->d_f_chunk.as<uint32_t>();
+  l.want_f = want_f ? 1u : 0u;
+  l.out_u64 = want_f ? nullptr : s->d_out_u64.as<uint64_t>();
+  l.out_host = want_f ? nullptr : static_cast<uint64_t*>(s->h_result);
+  if (line_mode) {
+    HIP_TRY(launch_line_starts_keep(l, st));
+    Scan2Args k{};
+    k.in = l.keep;
+    k.out = s->d_keep_pre.as<uint64_t>();
+    k.n_cap = cap;
+    k.n_dev = tot + kTotRaw;
+    k.blk = r.blk;
+    k.ticket = tickets;
+    HIP_TRY(launch_scan2_u32(k, false, st));
+  }
+  HIP_TRY(launch_chunk_tail(l, st));
+  HIP_TRY(launch_list_out(l, st));
+
+  if (want_f) {
+    LineOutArgs o{};
+    o.base = s->base;
+    o.chunks = a.chunks;
+    o.chunk_tile0 = a.chunk_tile0;
+    o.nchunks = nchunks;
+    o.pat = c->pat;
+    o.total = fcap;
+    o.tot_dev = tot;
+    o.f_pos = l.f_pos;
+    o.f_match = l.f_match;
+    o.f_chunk = l.f_chunk;
+    o.out_u64 = s->d_out_u64.as<uint64_t>();
+    o.out_host = static_cast<uint64_t*>(s->h_result);
+    o.shard_line_base = s->shard_line_base;
+    o.tile_bytes = s->tile_bytes;
+    if (mode == XSG_LINE_INDICES) {
+      o.tile_nl_off = s->d_tile_nl_off.as<uint64_t>();
+      HIP_TRY(launch_line_index_waves(o, st));
+    } else {
+      o.line_len = s->d_line_len.as<uint64_t>();
+      o.line_len_host = s->hp_line_len;
+      o.line_out_off = s->d_line_off.as<uint64_t>();
+      o.line_bytes = s->d_line_bytes.as<uint8_t>();
+      o.line_bytes_host = s->hp_line_bytes;
+      o.line_bytes_cap = bytes_cap;
+      HIP_TRY(launch_line_lengths(o, st));
+      Scan2Args b{};
+      b.in = o.line_len;
+      b.out = s->d_line_off.as<uint64_t>();
+      b.n_cap = fcap;
+      b.n_dev = tot + kTotFinal;
+      b.blk = r.blk;
+      b.ticket = tickets;
+      b.tot_dev = tot + kTotLineBytes;
+      b.tot_host = s->h_tot + kTotLineBytes;
+      b.ovf_dev = tot + kTotOverflow;
+      b.ovf_host = s->h_tot + kTotOverflow;
+      b.total_cap = bytes_cap;
+      b.ovf_bit = 4;
+      HIP_TRY(launch_scan2_u64(b, st));
+      HIP_TRY(launch_line_gather(o, st));
+    }
+  }
+  const bool ascii_only = c->pat.kind == kClass && c->pat.ascii_only;
+  if (ascii_only) HIP_TRY(hipMemcpyAsync(s->h_tot + kTotWords, a.flags, 4, hipMemcpyDeviceToHost, st));
+
+  // ---- the one sync
+  HIP_TRY(hipStreamSynchronize(st));
+  s->table_pending = false;
+  if (ascii_only && (s->h_tot[kTotWords] & 1u)) {  // non-ASCII data under an ascii_only expression
+    HIP_TRY(hipMemsetAsync(a.flags, 0, 4, st));
+    return fail(XSG_ENOTSUP, "%s", kNonAsciiMsg);
+  }
+  s->last_raw_matches = s->h_tot[kTotRaw];
+  if (want_nl && !s->nl_off_cached) {
+    s->nl_total = s->h_tot[kTotNewlines];
+    s->nl_off_cached = true;
+  }
+  if (s->h_tot[kTotOverflow]) {
+    s->fast_dense_serial = c->pattern_serial;  // later searches of this pattern on this binding: the exact route at once
+    return kFastOverflow;
+  }
+  const uint64_t total = s->h_tot[kTotFinal];
+  s->total = total;
+  s->fast_result = true;
+  if (want_nl) s->last_newlines = s->nl_total;
+  if (mode == XSG_LINES) {
+    // lines without a terminating '\n' are not reported (search_wrappers.h:199-202)
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < total; ++i) n += s->hp_line_len[i] != UINT64_MAX;
+    s->fast_raw_lines = total;
+    s->total = n;
+    s->line_bytes = s->h_tot[kTotLineBytes];
+  }
+  s->last_mode = (int)mode;
+  return XSG_OK;
+}
+
 static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   xsg_ctx* c = s->ctx;
   hipStream_t st = c->stream;
@@ -1251,12 +1534,25 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   s->last_mode = -1;
   s->total = 0;
   s->line_bytes = 0;
+  s->fast_result = false;
   XSG_TRY(ensure_factor_mask(s));
+
+  // 0. a result that fits the one-sync route's capacities is done there (one stream sync, a third of the launches)
+  bool counts_ready = false;
+  if (fast_route_serves(s, mode, outputs)) {
+    const int fr = run_list_fast(s, mode);
+    if (fr != kFastOverflow) return fr;
+    counts_ready = true;  // the per-tile counts (and newline counts) of that pass stand: continue at the ranks
+    s->last_mode = -1;
+    s->total = 0;
+  }
 
   // 1. bulk count per tile
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
-  XSG_TRY(choose_hot_filter(s, st));
-  XSG_TRY(prepare_tiles(s, false, st));
+  if (!counts_ready) {
+    XSG_TRY(choose_hot_filter(s, st));
+    XSG_TRY(prepare_tiles(s, false, st));
+  }
   ScanArgs a = scan_args(s);
   const bool pre = use_prefilter(s);  // candidates by the class-sequence matcher, then the automaton
   if (pre) {
@@ -1265,7 +1561,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   }
   s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them
   const bool scan_nl = want_nl && !s->nl_cached;  // newline counts per tile: once per binding, whatever the pattern
-  HIP_TRY(launch_scan_count(a, scan_nl, false, st));
+  if (!counts_ready) HIP_TRY(launch_scan_count(a, scan_nl, false, st));
   if (scan_nl) s->nl_cached = true;
 
   // 2. ranks
@@ -1412,6 +1708,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
       s->nl_off_cached = true;
     }
     XSG_TRY(d2h_u64(c, s->d_tile_nl_off.as<uint64_t>() + ntiles, &s->last_newlines));
+    s->nl_total = s->last_newlines;
   }
   if (!outputs) return XSG_OK;
 
@@ -1484,6 +1781,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     HIP_TRY(hipMemcpyAsync(s->h_line_off.data(), o.line_out_off, 8 * (total + 1), hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
+  if (mode == XSG_LINE_INDICES) s->nl_total = s->last_newlines;
   if (mode == XSG_LINES) {
     // lines without a terminating '\n' are not reported (search_wrappers.h:199-202)
     uint64_t n = 0;
@@ -1514,6 +1812,10 @@ extern "C" int xsg_result_u64(xsg_shard* s, uint64_t* out, uint64_t cap) {
                                   (unsigned long long)s->total);
   if (s->total == 0) return XSG_OK;
   if (!out) return fail(XSG_EINVAL, "out is null");
+  if (s->fast_result) {  // the one-sync route: the kernels stored the result into the shard's pinned buffer as well
+    memcpy(out, s->h_result, 8 * s->total);
+    return XSG_OK;
+  }
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(out, s->d_out_u64.p, 8 * s->total, hipMemcpyDeviceToHost, c->stream));
@@ -1532,6 +1834,10 @@ extern "C" int xsg_result_u64_view(xsg_shard* s, const uint64_t** out, uint64_t*
   *out = nullptr;
   *n = s->total;
   if (s->total == 0) return XSG_OK;
+  if (s->fast_result) {  // already there
+    *out = static_cast<const uint64_t*>(s->h_result);
+    return XSG_OK;
+  }
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   const size_t need = 8 * (size_t)s->total;
@@ -1569,6 +1875,21 @@ extern "C" int xsg_result_lines(xsg_shard* s, uint64_t* lengths, char* bytes, ui
   if (!s) return fail(XSG_EINVAL, "shard is null");
   if (s->last_mode != XSG_LINES) return fail(XSG_ESTATE, "no XSG_LINES result is pending on this shard");
   if (bytes_cap < s->line_bytes) return fail(XSG_EINVAL, "bytes_cap too small");
+  if (s->fast_result) {  // the one-sync route: lengths, offsets and bytes are in the pinned mirrors
+    if (s->line_bytes) {
+      if (!bytes) return fail(XSG_EINVAL, "bytes is null");
+      memcpy(bytes, s->hp_line_bytes, s->line_bytes);
+    }
+    const uint64_t* goff = static_cast<const uint64_t*>(s->h_result);
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < s->fast_raw_lines; ++i) {
+      if (s->hp_line_len[i] == UINT64_MAX) continue;
+      if (lengths) lengths[k] = s->hp_line_len[i];
+      if (offsets) offsets[k] = goff[i];
+      ++k;
+    }
+    return XSG_OK;
+  }
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
   const uint64_t raw = s->h_line_len.size();

@@ -4,6 +4,7 @@
 #pragma once
 #include "xsg_internal.h"
 #include "xsg_linesum.h"
+#include "xsg_tail.h"
 
 namespace xsg {
 
@@ -134,32 +135,54 @@ __device__ __forceinline__ bool block_has_nl(const uint8_t* p) {
   }
   return (acc & 0x80808080u) != 0;  // exact as an existence test
 }
+// 64 consecutive bytes at p (16-byte aligned) as one newline mask; units at or beyond `end` are not read.  The four
+// loads are independent: a line of text (~30 bytes) is settled by ONE memory latency instead of two or three
+// dependent ones -- the list kernels are chains of such latencies, little else.
+__device__ __forceinline__ uint64_t nl_mask_of_64(const uint8_t* d, uint64_t p, uint64_t end) {
+  uint64_t m = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (p + (uint64_t)u * kUnit < end) m |= (uint64_t)(nl_mask_of_unit(d + p + (uint64_t)u * kUnit) & 0xffffu) << (16 * u);
+  return m;
+}
 // offset of the first '\n' in d[lo, hi), or -1
 __device__ __forceinline__ int64_t first_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi) {
   if (lo >= hi) return -1;
   uint64_t p = lo & ~(uint64_t)15;
-  uint32_t range = 0xffffu << (uint32_t)(lo - p);  // first unit: positions >= lo
+  {  // first step: the unit that holds lo and the three behind it
+    uint64_t m = nl_mask_of_64(d, p, hi) & (~0ull << (uint32_t)(lo - p));
+    if (hi - p < 64u) m &= (1ull << (uint32_t)(hi - p)) - 1ull;
+    if (m) return (int64_t)(p + (uint32_t)__builtin_ctzll(m));
+    p += 4 * kUnit;
+  }
   for (;;) {
-    if (range == 0xffffu) {  // past the first unit: skip 256, then 64 bytes at a time while they hold no newline
-      while (p + 16 * kUnit <= hi && !block_has_nl(d + p)) p += 16 * kUnit;
-      while (p + 4 * kUnit <= hi && !(unit_has_nl(d + p) | unit_has_nl(d + p + kUnit) | unit_has_nl(d + p + 2 * kUnit) |
-                                      unit_has_nl(d + p + 3 * kUnit)))
-        p += 4 * kUnit;
-    }
+    // past the first step: skip 256, then 64 bytes at a time while they hold no newline
+    while (p + 16 * kUnit <= hi && !block_has_nl(d + p)) p += 16 * kUnit;
+    while (p + 4 * kUnit <= hi && !(unit_has_nl(d + p) | unit_has_nl(d + p + kUnit) | unit_has_nl(d + p + 2 * kUnit) |
+                                    unit_has_nl(d + p + 3 * kUnit)))
+      p += 4 * kUnit;
     if (p >= hi) return -1;
-    uint32_t m = nl_mask_of_unit(d + p) & range & 0xffffu;
+    uint32_t m = nl_mask_of_unit(d + p) & 0xffffu;
     if (hi - p < kUnit) m &= (1u << (uint32_t)(hi - p)) - 1u;
     if (m) return (int64_t)(p + (uint32_t)__ffs((int)m) - 1u);
     p += kUnit;
-    range = 0xffffu;
   }
 }
 // offset of the last '\n' in d[lo, hi), or -1
 __device__ __forceinline__ int64_t last_newline_in(const uint8_t* d, uint64_t lo, uint64_t hi) {
   if (lo >= hi) return -1;
   uint64_t p = (hi - 1u) & ~(uint64_t)15;  // unit of the last byte of the range
-  uint32_t range = hi - p >= kUnit ? 0xffffu : (1u << (uint32_t)(hi - p)) - 1u;
   const uint64_t lo_unit = lo & ~(uint64_t)15;
+  {  // first step: the (up to) four units that end with the one holding hi - 1
+    const uint64_t q = p >= lo_unit + 3 * kUnit ? p - 3 * kUnit : lo_unit;  // first unit of the group
+    uint64_t m = nl_mask_of_64(d, q, p + kUnit);
+    if (hi - q < 64u) m &= (1ull << (uint32_t)(hi - q)) - 1ull;
+    if (q < lo) m &= ~0ull << (uint32_t)(lo - q);
+    if (m) return (int64_t)(q + 63u - (uint32_t)__builtin_clzll(m));
+    if (q <= lo_unit) return -1;
+    p = q - kUnit;
+  }
+  uint32_t range = 0xffffu;
   for (;;) {
     if (range == 0xffffu) {
       while (p >= lo_unit + 16 * kUnit && !block_has_nl(d + p - 15 * kUnit)) p -= 16 * kUnit;
@@ -286,6 +309,61 @@ __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* sh) {
     for (int w = 0; w < kWaves; ++w) t += sh[w];
   __syncthreads();
   return t;  // valid in thread 0
+}
+
+// where the reference walk stands when it reaches the tail zone of a chunk: after the last bulk match (match
+// modes), at the start of the line after the last bulk matching line (line modes; UINT64_MAX if that line has
+// no '\n': the walk ended).  Wave-uniform arguments, all lanes active.
+__device__ __forceinline__ uint64_t wave_walk_entry(const uint8_t* d, uint64_t L, uint64_t last_end, bool skip_to_nl,
+                                                   uint32_t lane) {
+  if (last_end == 0) return 0;
+  if (!skip_to_nl) return last_end;
+  const int64_t nl = wave_first_newline_in(d, last_end, L, lane);
+  return nl < 0 ? UINT64_MAX : (uint64_t)nl + 1u;
+}
+
+constexpr uint32_t kZoneStage = 96;  // bytes of a chunk's tail zone staged in LDS: <= 64 positions + 2 x 15 of alignment
+
+// The tail zone of one chunk, decided by the whole wave (xsg_tail.h, tail_walk_masks): lane i owns position Z + i,
+// computes how many leading pattern bytes match there (from the zone's bytes staged in LDS -- a byte-by-byte walk
+// by one lane through global memory cost ~10 us per chunk in dependent loads), ballots give the masks and the walk
+// itself runs on the scalar unit.  Returns (wave-uniform) the matches of the match-mode walk from `entry_m` and
+// of the line-mode walk from `entry_l`.  plen <= kTailMaskMaxPlen; all 64 lanes active.
+__device__ __forceinline__ void wave_tail_counts(const uint8_t* d, uint64_t L, const uint8_t* s_pat, uint32_t plen,
+                                                 bool icase, uint8_t* zone, uint32_t lane, bool want_m, uint64_t entry_m,
+                                                 bool want_l, uint64_t entry_l, uint32_t* n_m, uint32_t* n_l,
+                                                 uint64_t* out = nullptr, uint32_t out_cap = 0) {
+  const uint64_t Z = tail_zone_begin(L, plen);
+  const uint32_t n = (uint32_t)(L - Z);  // <= plen + 31 <= 64
+  const uint64_t Zal = Z & ~(uint64_t)15;
+  const uint64_t Lr = (L + 15u) & ~(uint64_t)15u;
+  const uint32_t off = (uint32_t)(Z - Zal);
+  if (Zal + (uint64_t)lane * kUnit < Lr && lane < kZoneStage / kUnit)
+    *reinterpret_cast<uint4*>(zone + lane * kUnit) = *reinterpret_cast<const uint4*>(d + Zal + (uint64_t)lane * kUnit);
+  // the zone row belongs to this wave alone: a wavefront-scope release/acquire orders its lanes' LDS accesses
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool in_zone = lane < n;
+  const bool room = in_zone && (L - (Z + lane) >= plen);
+  uint32_t k = 0;
+  bool alive = room;
+  for (uint32_t j = 0; j < plen; ++j) {
+    if (!__any(alive)) break;
+    if (alive) {
+      if (fold(zone[off + lane + j], icase) == s_pat[j])
+        k = j + 1u;
+      else
+        alive = false;
+    }
+  }
+  const unsigned long long full = __ballot(room && k == plen);
+  const unsigned long long nz = __ballot(k != 0);
+  const unsigned long long nlm = __ballot(in_zone && zone[off + lane] == '\n');
+  auto k_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)k, (int)__builtin_amdgcn_readfirstlane(j)); };
+  // (out: the positions of the ONE walk asked for -- the list kernels want either the match-mode or the line-mode walk)
+  *n_m = want_m ? tail_walk_masks(L, plen, entry_m, false, full, nz, nlm, k_at, want_l ? nullptr : out, out_cap) : 0u;
+  *n_l = want_l ? tail_walk_masks(L, plen, entry_l, true, full, nz, nlm, k_at, out, out_cap) : 0u;
 }
 
 }  // namespace xsg

@@ -852,10 +852,13 @@ static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
       at += lens[i];
     }
   } else {
+    // the result is read where the search left it: the shard's pinned buffer (stored there by the kernels on the
+    // one-sync route, one pinned D2H copy otherwise) -- no second trip through the device queue per chunk
     uint64_t n = 0;
+    const uint64_t* view = nullptr;
     XSG_TRY(xsg_search(l.shard, mode, &n));
-    p.u64.resize(n);
-    XSG_TRY(xsg_result_u64(l.shard, p.u64.data(), n));
+    XSG_TRY(xsg_result_u64_view(l.shard, &view, &n));
+    p.u64.assign(view, view + n);
     if (mode == XSG_LINE_INDICES && fc.first_line == XSG_LINE_BASE_AUTO) {
       p.indices_local = true;
       XSG_TRY(xsg_result_newlines(l.shard, &p.newlines));

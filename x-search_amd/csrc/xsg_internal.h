@@ -103,6 +103,11 @@ struct ScanArgs {
   const uint64_t* tile_off;  // exclusive prefix of tile_cnt
   uint64_t* m_pos;           // chunk-local offset of every match, ascending
   uint32_t* m_chunk;         // its chunk
+  // emit pass over the tiles that hold a match only (the one-sync list route): the ordered list of those tiles and
+  // where its length lives; null: one workgroup per tile of the shard, each leaving at once if its count is 0
+  const uint32_t* hit_tiles;
+  const uint64_t* n_hits_dev;
+  uint64_t hit_cap;
 };
 
 constexpr int kFinishBlocks = 2048;  // upper bound of k_count_finish's grid (size of FinishArgs::partials / 3)
@@ -170,6 +175,49 @@ uint64_t scan_tmp_elems(uint64_t n);
 hipError_t launch_exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s);
 hipError_t launch_exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t s);
 
+// ---- the one-sync list route (xsg_api.cpp: run_list_fast) ---------------------------------------------------
+// Every size the host used to fetch between the stages of a list search (raw occurrences, kept ones, tail matches,
+// line bytes) stays on the device: arrays have CAPACITIES, kernels read the counts they need from this block of
+// device words and bound themselves by the capacities, and the kernels that produce a count also store it in a
+// pinned host mirror.  The host syncs once, at the end, and reads the mirror; kTotOverflow != 0 means a capacity
+// was too small and the search is repeated on the exact route (which sizes every array from a fetched count).
+enum FastTot : int {
+  kTotRaw = 0,        // raw bulk occurrences = sum of tile_cnt
+  kTotHits = 1,       // tiles that hold at least one
+  kTotKept = 2,       // raw occurrences the reference walk reports
+  kTotFinal = 3,      // kept + end-of-chunk matches = length of the list
+  kTotNewlines = 4,   // '\n' in the shard (xs::line_indices)
+  kTotLineBytes = 5,  // xs::lines: packed bytes
+  kTotOverflow = 6,   // != 0: some capacity was exceeded (bit 0 raw, 1 list, 2 line bytes)
+  kTotWords = 8
+};
+
+// exclusive prefix sums in two launches with the count on the device: k_scan2_a (block sums; the last workgroup to
+// arrive scans them and publishes the total), k_scan2_b (writes out[0..n)); out[n] = total.
+struct Scan2Args {
+  const void* in;          // uint32 or uint64 (UINT64_MAX scans as 0: dropped lines)
+  uint64_t* out;           // n + 1 entries
+  uint64_t n_cap;          // the grids cover this many entries
+  const uint64_t* n_dev;   // optional: n = min(*n_dev, n_cap); null: n = n_cap
+  uint64_t* blk;           // scratch: 2 x (blocks + 1) words
+  uint32_t* ticket;        // zero at rest
+  uint64_t* tot_dev;       // optional: the grand total (device word) ...
+  uint64_t* tot_host;      // ... and its pinned mirror
+  // HITS: the ordered list of indices with a non-zero entry
+  uint32_t* hit_idx;
+  uint64_t hit_cap;
+  uint64_t* hits_dev;
+  uint64_t* hits_host;
+  uint64_t* ovf_dev;       // optional: |= ovf_bit when the total exceeds total_cap (or the hits exceed hit_cap)
+  uint64_t* ovf_host;
+  uint64_t total_cap;
+  uint64_t ovf_bit;
+  uint32_t ovf_init;       // the first producer of a search: the overflow word is STORED (bit or 0), not OR-ed into
+};
+uint64_t scan2_tmp_elems(uint64_t n_cap);
+hipError_t launch_scan2_u32(const Scan2Args& a, bool hits, hipStream_t s);
+hipError_t launch_scan2_u64(const Scan2Args& a, hipStream_t s);
+
 struct ListArgs {
   const uint8_t* base;
   const ChunkDev* chunks;
@@ -196,6 +244,15 @@ struct ListArgs {
   uint64_t* f_match;  // chunk-local offset of the (first) match of that line
   uint32_t* f_chunk;
   uint64_t total;
+  // one-sync route
+  uint32_t keep_all;         // every raw occurrence is reported (no keep[] / keep_pre[]: entry i stays entry i)
+  uint64_t* tot_dev;         // FastTot words
+  uint64_t* tot_host;        // pinned mirror
+  uint32_t* ticket;          // zero at rest
+  uint64_t f_cap;            // entries f_pos / f_match / f_chunk / out arrays can hold
+  uint64_t* out_u64;         // k_list_out: global offset of every final entry (match / line-start tags) ...
+  uint64_t* out_host;        // ... and its pinned mirror (may be null)
+  uint32_t want_f;           // k_list_out: also write f_pos / f_match / f_chunk (line indices, lines)
 };
 
 // mask[tile of the line start] = 1 for every kept entry of a candidate list (ListArgs after launch_line_starts_keep)
@@ -210,6 +267,10 @@ hipError_t launch_assemble(const ListArgs& a, hipStream_t s);
 // all four UINT64_MAX if *M_dev exceeds the capacity (the caller falls back to the synchronous route) or the scan
 // raised flags bit 0 (ascii_only expression on non-ASCII data).  counters must be zero on entry.
 hipError_t launch_bordered_total(const ListArgs& a, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, hipStream_t s);
+// one-sync route: chunk_shift0 + tail walk by one wave per chunk, the prefix of the tail counts and kTotFinal by the
+// last workgroup to arrive; then the final list (k_assemble + k_globalize in one)
+hipError_t launch_chunk_tail(const ListArgs& a, hipStream_t s);
+hipError_t launch_list_out(const ListArgs& a, hipStream_t s);
 
 struct LineOutArgs {
   const uint8_t* base;
@@ -230,11 +291,19 @@ struct LineOutArgs {
   uint64_t* line_len;  // length without '\n'; UINT64_MAX marks "no terminating newline" (dropped)
   const uint64_t* line_out_off;
   uint8_t* line_bytes;
+  // one-sync route: `total` is the capacity, the length of the list is tot_dev[kTotFinal]
+  const uint64_t* tot_dev;
+  uint64_t* out_host;        // pinned mirror of out_u64 (may be null)
+  uint64_t* line_len_host;   // pinned mirror of line_len (xs::lines)
+  uint8_t* line_bytes_host;  // pinned mirror of line_bytes
+  uint64_t line_bytes_cap;   // bytes line_bytes (and its mirror) can hold
 };
 hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_nl_delta(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_indices(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_lengths(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s);
+// one-sync route: the line index of every entry by one wave per entry (sparse lists: no prefix pass over the entries)
+hipError_t launch_line_index_waves(const LineOutArgs& a, hipStream_t s);
 
 }  // namespace xsg

@@ -461,7 +461,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
 // rank (tile_off[tile] + rank inside the tile).
 // ---------------------------------------------------------------------------
 template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, int LOADS, bool ICASE, bool ALIGNED>
-__device__ __forceinline__ void scan_tile(const ScanArgs& A) {
+__device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile) {
   constexpr int kLoads = LOADS;                          // 16-byte units per lane
   constexpr uint32_t kWaveSpan = kWaveLoad * kLoads;     // contiguous bytes per wave
   constexpr uint32_t kTile = kWaveSpan * kWaves;         // bytes per workgroup
@@ -470,7 +470,6 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A) {
   __shared__ __attribute__((aligned(16))) uint8_t s_pat[is_cls(KIND) ? 2048 : KIND == kLong ? XSG_MAX_PATTERN : 16];
   __shared__ __attribute__((aligned(16))) uint8_t s_view[is_cls(KIND) ? kBlock * 48 : 16];  // match_mask16<kClass>
 
-  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (tile >= A.ntiles) return;
   if (EMIT && A.tile_cnt[tile] == 0) return;
 
@@ -548,8 +547,10 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A) {
 
   // The loop body exists twice: a wave whose whole span lies inside the chunk (all
   // but the last tile of a chunk) skips every end-of-chunk check.
+  // (The emit pass has only the careful body: it visits few tiles, and what it costs there is the FETCH of its code --
+  // 23 KB with both bodies -- by every compute unit that gets a workgroup, not the end-of-chunk checks.)
   WaveState st;
-  if (wbase + kWaveSpan <= L) {
+  if (!EMIT && wbase + kWaveSpan <= L) {
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
@@ -653,7 +654,21 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A) {
 // and `[0-9]{4}-[0-9]{2}` (6.50 against 6.88, 6.52 against 6.94): not adopted.  scripts/ab_waves.sh.)
 template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, int LOADS, bool ICASE, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void k_scan(const ScanArgs A) {
-  scan_tile<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE, ALIGNED>(A);
+  if (EMIT) {
+    if (A.hit_tiles) {
+      // the one-sync list route: the tiles that hold a match are listed (in order) on the device and so is their
+      // number; a bounded grid strides over the list -- a workgroup per tile of the shard, each leaving at once
+      // unless its count is non-zero, costs 150 us on a 10 GiB shard whatever the number of matches
+      uint64_t H = *A.n_hits_dev;
+      H = H < A.hit_cap ? H : A.hit_cap;
+      for (uint64_t h = blockIdx.x; h < H; h += gridDim.x) {
+        scan_tile<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE, ALIGNED>(A, (uint64_t)A.hit_tiles[h]);
+        __syncthreads();  // the tile's LDS words are reused by the next one
+      }
+      return;
+    }
+  }
+  scan_tile<KIND, WANT_NL, WANT_LINES, EMIT, LOADS, ICASE, ALIGNED>(A, (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x);
 }
 
 template <int KIND, bool ICASE, bool ALIGNED>
@@ -731,7 +746,8 @@ static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_line
   if (a_in.ntiles == 0) return hipSuccess;
   ScanArgs a = a_in;
   a.tune = pick_stagger(a_in, want_nl, want_lines, emit);
-  const dim3 grid = tile_grid(a.ntiles);
+  const dim3 grid = (emit && a.hit_tiles) ? dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(a.hit_cap, 1), 16384), 1, 1)
+                                         : tile_grid(a.ntiles);
   switch (a.pat.kind) {
     case kMask1: return launch_scan_loads<kMask1>(a, want_nl, want_lines, emit, grid, s);
     case kOne: return launch_scan_loads<kOne>(a, want_nl, want_lines, emit, grid, s);
@@ -762,59 +778,6 @@ hipError_t launch_scan_emit(const ScanArgs& a, hipStream_t s) {
 // partial sums and writes the four counters (device and, if given, a pinned
 // host mirror), so the counters need no zeroing either.
 // ---------------------------------------------------------------------------
-
-// where the reference walk stands when it reaches the tail zone of a chunk: after the last bulk match (match
-// modes), at the start of the line after the last bulk matching line (line modes; UINT64_MAX if that line has
-// no '\n': the walk ended).  Wave-uniform arguments, all lanes active.
-__device__ __forceinline__ uint64_t wave_walk_entry(const uint8_t* d, uint64_t L, uint64_t last_end, bool skip_to_nl,
-                                                   uint32_t lane) {
-  if (last_end == 0) return 0;
-  if (!skip_to_nl) return last_end;
-  const int64_t nl = wave_first_newline_in(d, last_end, L, lane);
-  return nl < 0 ? UINT64_MAX : (uint64_t)nl + 1u;
-}
-
-constexpr uint32_t kZoneStage = 96;  // bytes of a chunk's tail zone staged in LDS: <= 64 positions + 2 x 15 of alignment
-
-// The tail zone of one chunk, decided by the whole wave (xsg_tail.h, tail_walk_masks): lane i owns position Z + i,
-// computes how many leading pattern bytes match there (from the zone's bytes staged in LDS -- a byte-by-byte walk
-// by one lane through global memory cost ~10 us per chunk in dependent loads), ballots give the masks and the walk
-// itself runs on the scalar unit.  Returns (wave-uniform) the matches of the match-mode walk from `entry_m` and
-// of the line-mode walk from `entry_l`.  plen <= kTailMaskMaxPlen; all 64 lanes active.
-__device__ __forceinline__ void wave_tail_counts(const uint8_t* d, uint64_t L, const uint8_t* s_pat, uint32_t plen,
-                                                 bool icase, uint8_t* zone, uint32_t lane, bool want_m, uint64_t entry_m,
-                                                 bool want_l, uint64_t entry_l, uint32_t* n_m, uint32_t* n_l) {
-  const uint64_t Z = tail_zone_begin(L, plen);
-  const uint32_t n = (uint32_t)(L - Z);  // <= plen + 31 <= 64
-  const uint64_t Zal = Z & ~(uint64_t)15;
-  const uint64_t Lr = (L + 15u) & ~(uint64_t)15u;
-  const uint32_t off = (uint32_t)(Z - Zal);
-  if (Zal + (uint64_t)lane * kUnit < Lr && lane < kZoneStage / kUnit)
-    *reinterpret_cast<uint4*>(zone + lane * kUnit) = *reinterpret_cast<const uint4*>(d + Zal + (uint64_t)lane * kUnit);
-  // the zone row belongs to this wave alone: a wavefront-scope release/acquire orders its lanes' LDS accesses
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const bool in_zone = lane < n;
-  const bool room = in_zone && (L - (Z + lane) >= plen);
-  uint32_t k = 0;
-  bool alive = room;
-  for (uint32_t j = 0; j < plen; ++j) {
-    if (!__any(alive)) break;
-    if (alive) {
-      if (fold(zone[off + lane + j], icase) == s_pat[j])
-        k = j + 1u;
-      else
-        alive = false;
-    }
-  }
-  const unsigned long long full = __ballot(room && k == plen);
-  const unsigned long long nz = __ballot(k != 0);
-  const unsigned long long nlm = __ballot(in_zone && zone[off + lane] == '\n');
-  auto k_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)k, (int)__builtin_amdgcn_readfirstlane(j)); };
-  *n_m = want_m ? tail_walk_masks(L, plen, entry_m, false, full, nz, nlm, k_at) : 0u;
-  *n_l = want_l ? tail_walk_masks(L, plen, entry_l, true, full, nz, nlm, k_at) : 0u;
-}
 
 __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
   __shared__ uint64_t sh[kWaves];

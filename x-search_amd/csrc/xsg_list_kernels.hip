@@ -122,6 +122,147 @@ hipError_t launch_exclusive_scan_u64(const uint64_t* in, uint64_t* out, uint64_t
 }
 
 // ---------------------------------------------------------------------------
+// The same prefix sums in TWO launches and with the element count on the device (the one-sync list route): the
+// last workgroup of the first launch to arrive (a ticket) scans the block sums and publishes the total -- to a
+// device word the following kernels read, and to a pinned host mirror the host reads after its one sync.  With
+// HITS the second launch also writes the ordered list of the indices whose entry is not zero (the tiles that
+// hold a match: the emit pass visits only those).
+// ---------------------------------------------------------------------------
+uint64_t scan2_tmp_elems(uint64_t n_cap) { return 2 * ((n_cap + kScanBlockElems - 1) / kScanBlockElems + 1); }
+
+__device__ __forceinline__ uint64_t scan2_count(const Scan2Args& A) {
+  if (!A.n_dev) return A.n_cap;
+  const uint64_t n = *A.n_dev;
+  return n < A.n_cap ? n : A.n_cap;
+}
+
+// Both kernels stride over VIRTUAL blocks of kScanBlockElems entries (as many as the count on the device needs), so the
+// grid can be much smaller than the capacity asks for: a list of a few thousand entries in arrays of a million is
+// four virtual blocks, and a ticket over 64 workgroups is drawn faster than one over 512.
+template <typename T, bool HITS>
+__global__ __launch_bounds__(kBlock) void k_scan2_a(const Scan2Args A) {
+  __shared__ uint64_t sh[kWaves];
+  __shared__ uint32_t s_is_last;
+  const T* in = static_cast<const T*>(A.in);
+  const uint64_t n = scan2_count(A);
+  const uint64_t nb_cap = (A.n_cap + kScanBlockElems - 1) / kScanBlockElems;  // layout of the scratch
+  const uint64_t nvb = (n + kScanBlockElems - 1) / kScanBlockElems;
+  uint64_t* blk_sum = A.blk;
+  uint64_t* blk_hit = A.blk + (nb_cap + 1);
+  for (uint64_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    const uint64_t b0 = vb * kScanBlockElems + (uint64_t)threadIdx.x * kScanItems;
+    uint64_t v = 0, h = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (b0 + k < n) {
+        const uint64_t x = scan_val(in[b0 + k]);
+        v += x;
+        if (HITS) h += x != 0;
+      }
+    }
+    uint64_t tot;
+    block_excl_scan_u64(v, sh, &tot);
+    uint64_t toth = 0;
+    if (HITS) block_excl_scan_u64(h, sh, &toth);
+    if (threadIdx.x == 0) {
+      blk_sum[vb] = tot;
+      if (HITS) blk_hit[vb] = toth;
+    }
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_is_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  if (!s_is_last) return;
+  __threadfence();
+  // exclusive scan of the block sums in place, the totals behind them
+  uint64_t carry = 0, carryh = 0;
+  for (uint64_t i0 = 0; i0 < nvb; i0 += kBlock) {
+    const uint64_t i = i0 + threadIdx.x;
+    const uint64_t x = i < nvb ? __hip_atomic_load(blk_sum + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    uint64_t t;
+    const uint64_t ex = block_excl_scan_u64(x, sh, &t);
+    if (i < nvb) blk_sum[i] = carry + ex;
+    carry += t;
+    if (HITS) {
+      const uint64_t y = i < nvb ? __hip_atomic_load(blk_hit + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      const uint64_t exh = block_excl_scan_u64(y, sh, &t);
+      if (i < nvb) blk_hit[i] = carryh + exh;
+      carryh += t;
+    }
+  }
+  if (threadIdx.x == 0) {
+    A.out[n] = carry;
+    if (A.tot_dev) *A.tot_dev = carry;
+    if (A.tot_host) *A.tot_host = carry;
+    if (HITS) {
+      if (A.hits_dev) *A.hits_dev = carryh;
+      if (A.hits_host) *A.hits_host = carryh;
+    }
+    if (A.ovf_dev) {
+      const uint64_t over = (carry > A.total_cap || (HITS && carryh > A.hit_cap)) ? A.ovf_bit : 0u;
+      const uint64_t w = A.ovf_init ? over : (*A.ovf_dev | over);
+      *A.ovf_dev = w;
+      if (A.ovf_host) *A.ovf_host = w;
+    }
+    *A.ticket = 0u;  // at rest for the next launch (stream order)
+  }
+}
+
+template <typename T, bool HITS>
+__global__ __launch_bounds__(kBlock) void k_scan2_b(const Scan2Args A) {
+  __shared__ uint64_t sh[kWaves];
+  const T* in = static_cast<const T*>(A.in);
+  const uint64_t n = scan2_count(A);
+  const uint64_t nb_cap = (A.n_cap + kScanBlockElems - 1) / kScanBlockElems;
+  const uint64_t nvb = (n + kScanBlockElems - 1) / kScanBlockElems;
+  for (uint64_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {  // (workgroup-uniform)
+    const uint64_t b0 = vb * kScanBlockElems + (uint64_t)threadIdx.x * kScanItems;
+    uint64_t x[kScanItems];
+    uint64_t v = 0, h = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      x[k] = b0 + k < n ? scan_val(in[b0 + k]) : 0;
+      v += x[k];
+      if (HITS) h += x[k] != 0;
+    }
+    uint64_t tot;
+    uint64_t run = A.blk[vb] + block_excl_scan_u64(v, sh, &tot);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (b0 + k < n) A.out[b0 + k] = run;
+      run += x[k];
+    }
+    if (HITS) {
+      uint64_t hr = A.blk[(nb_cap + 1) + vb] + block_excl_scan_u64(h, sh, &tot);
+#pragma unroll
+      for (int k = 0; k < kScanItems; ++k) {
+        if (x[k] != 0) {
+          if (hr < A.hit_cap) A.hit_idx[hr] = (uint32_t)(b0 + k);
+          ++hr;
+        }
+      }
+    }
+  }
+}
+
+// grid: one workgroup per virtual block when the count is the host's (n_dev null: the per-tile arrays), a bounded
+// number when it lives on the device and is, on this route, far below the capacity
+template <typename T, bool HITS>
+static hipError_t scan2_impl(const Scan2Args& a, hipStream_t s) {
+  uint64_t nb = std::max<uint64_t>(1, (a.n_cap + kScanBlockElems - 1) / kScanBlockElems);
+  nb = std::min<uint64_t>(nb, a.n_dev ? 64 : 2048);
+  hipLaunchKernelGGL((k_scan2_a<T, HITS>), dim3((unsigned)nb), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL((k_scan2_b<T, HITS>), dim3((unsigned)nb), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_scan2_u32(const Scan2Args& a, bool hits, hipStream_t s) {
+  return hits ? scan2_impl<uint32_t, true>(a, s) : scan2_impl<uint32_t, false>(a, s);
+}
+hipError_t launch_scan2_u64(const Scan2Args& a, hipStream_t s) { return scan2_impl<uint64_t, false>(a, s); }
+
+// ---------------------------------------------------------------------------
 // list post-processing: one thread per raw match / per chunk.  Matches are
 // sparse at text densities (~5e-7 per byte), so these are latency-, not
 // bandwidth-bound and deliberately simple.
@@ -130,6 +271,13 @@ static inline dim3 grid_for(uint64_t n) {
   uint64_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
   return dim3((unsigned)b);
+}
+
+// grids of the one-sync route cover a CAPACITY (the count is on the device): a bounded number of workgroups that
+// stride over the entries there are
+static inline dim3 grid_capped(uint64_t n) {
+  const dim3 g = grid_for(n);
+  return dim3(g.x < 256u ? g.x : 256u);
 }
 
 // number of raw entries the list kernels work on: the host's value, or the device's bounded by the arrays' capacity
@@ -195,19 +343,24 @@ __global__ void k_greedy_keep(const ListArgs A) {
 // scans of one chunk are disjoint: O(chunk) bytes in total however long the lines
 // are (a walk back to the line start per match would be quadratic on one huge line).
 __global__ __launch_bounds__(kBlock) void k_line_starts_keep(const ListArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool live = i < A.M;  // no early return: the wave finishes long scans together (newline_query)
-  const uint32_t c = live ? A.m_chunk[i] : 0u;
-  const uint8_t* d = A.base + A.chunks[c].offset;
-  const bool first_in_chunk = live && (i == 0 || A.m_chunk[i - 1] != c);
-  const uint64_t lo = (!live || first_in_chunk) ? 0 : A.m_pos[i - 1];
-  const uint64_t hi = live ? A.m_pos[i] : 0;
-  // the newline that opens the match's line, if it lies in [lo, match)
-  const int64_t nl = newline_query<false>(live, d, lo, hi, threadIdx.x & 63u);
-  if (!live) return;
-  const bool found_nl = nl >= 0;
-  A.keep[i] = (found_nl || first_in_chunk) ? 1u : 0u;
-  A.m_ls[i] = found_nl ? (uint64_t)nl + 1u : lo;  // meaningful for kept matches only (0 for a first match on the chunk's first line)
+  const uint64_t M = list_count(A);
+  // grid-stride by whole waves (the one-sync route sizes the grid by the arrays' capacity, not by M); no early
+  // return for a lane without an entry: the wave finishes long scans together (newline_query)
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); i0 < M; i0 += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = i0 + (threadIdx.x & 63u);
+    const bool live = i < M;
+    const uint32_t c = live ? A.m_chunk[i] : 0u;
+    const uint8_t* d = A.base + A.chunks[c].offset;
+    const bool first_in_chunk = live && (i == 0 || A.m_chunk[i - 1] != c);
+    const uint64_t lo = (!live || first_in_chunk) ? 0 : A.m_pos[i - 1];
+    const uint64_t hi = live ? A.m_pos[i] : 0;
+    // the newline that opens the match's line, if it lies in [lo, match)
+    const int64_t nl = newline_query<false>(live, d, lo, hi, threadIdx.x & 63u);
+    if (!live) continue;
+    const bool found_nl = nl >= 0;
+    A.keep[i] = (found_nl || first_in_chunk) ? 1u : 0u;
+    A.m_ls[i] = found_nl ? (uint64_t)nl + 1u : lo;  // meaningful for kept matches only (0 for a first match on the chunk's first line)
+  }
 }
 
 // per chunk: where the walk enters the tail zone, from the last kept bulk match
@@ -247,6 +400,184 @@ __global__ void k_tail_list(const ListArgs A) {
                   A.tail_pos + c * A.tail_cap, A.tail_cap, A.pat.icase != 0);
   }
   A.tail_cnt[c] = n;
+}
+
+// ---- one-sync route: k_chunk_shift0 + k_tail_list + the prefix of the tail counts, one launch ------------------
+// One WAVE per chunk: where the reference walk stands when it reaches the chunk's tail zone (behind the last raw
+// occurrence it reports; line modes: at the start of the line after it), then the zone itself on bit masks
+// (wave_tail_counts: the zone's bytes in LDS, one position per lane, the walk on the scalar unit -- the
+// one-thread-per-chunk walk through global memory, k_tail_list, takes 35-40 us whatever the number of chunks).
+// The last workgroup to arrive turns tail_cnt into its exclusive prefix and publishes kTotKept / kTotFinal.
+__global__ __launch_bounds__(kBlock) void k_chunk_tail(const ListArgs A) {
+  __shared__ uint64_t sh[kWaves];
+  __shared__ __attribute__((aligned(16))) uint8_t s_zone[kWaves][kZoneStage];
+  __shared__ uint8_t s_pat[kTailMaskMaxPlen + 3];
+  __shared__ uint32_t s_is_last;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t plen = A.pat.plen;
+  const bool need_tail = !A.pat.exact_tail && plen > 1;
+  const bool mask_tail = need_tail && plen <= kTailMaskMaxPlen;
+  if (mask_tail) {
+    if (threadIdx.x < plen) s_pat[threadIdx.x] = A.pat.d_pat[threadIdx.x];
+    __syncthreads();
+  }
+  const uint64_t M = list_count(A);
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWaves;
+  for (uint64_t c = (uint64_t)blockIdx.x * kWaves + wave; c < A.nchunks; c += nwaves) {  // wave-uniform
+    uint64_t r0 = A.tile_off[A.chunk_tile0[c]], r1 = A.tile_off[A.chunk_tile0[c + 1]];
+    r0 = r0 < M ? r0 : M;  // entries beyond the capacity do not exist (the search is repeated on the exact route)
+    r1 = r1 < M ? r1 : M;
+    const ChunkDev ch = A.chunks[c];
+    const uint8_t* d = A.base + ch.offset;
+    // last raw occurrence of the chunk the walk reports, 64 entries a step from the back
+    uint64_t last_end = 0;
+    if (A.keep_all) {
+      if (r1 > r0) last_end = A.m_pos[r1 - 1] + plen;
+    } else {
+      for (uint64_t hi = r1; hi > r0 && last_end == 0;) {
+        const uint64_t lo = hi - r0 >= 64 ? hi - 64 : r0;
+        const uint64_t i = lo + lane;
+        const unsigned long long kb = __ballot(i < hi && A.keep[i] != 0);
+        if (kb) last_end = A.m_pos[lo + (uint64_t)(63 - __clzll((long long)kb))] + plen;
+        hi = lo;
+      }
+    }
+    const bool lm = A.line_mode != 0;
+    const uint64_t entry = lm ? wave_walk_entry(d, ch.length, last_end, true, lane) : last_end;
+    uint32_t n = 0;
+    if (need_tail && ch.length) {
+      uint64_t* out = A.tail_pos + c * A.tail_cap;
+      if (mask_tail) {
+        uint32_t nm = 0, nl = 0;
+        wave_tail_counts(d, ch.length, s_pat, plen, A.pat.icase != 0, s_zone[wave], lane, !lm, entry, lm, entry, &nm, &nl,
+                         lane == 0 ? out : nullptr, A.tail_cap);
+        n = lm ? nl : nm;
+      } else {
+        // long patterns: the zone does not fit one position per lane; lane 0 walks it after a coalesced sweep of
+        // the whole wave has pulled it into the caches
+        const uint64_t Lr = (ch.length + 15u) & ~(uint64_t)15u;
+        for (uint64_t off = (tail_zone_begin(ch.length, plen) & ~(uint64_t)15u) + (uint64_t)lane * kUnit; off < Lr; off += kWaveLoad) {
+          const uint4 v = *reinterpret_cast<const uint4*>(d + off);
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        }
+        if (lane == 0) n = tail_walk(d, ch.length, A.pat.d_pat, plen, entry, lm, out, A.tail_cap, A.pat.icase != 0);
+        n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+      }
+    }
+    if (lane == 0) {
+      A.tail_cnt[c] = n;
+      A.chunk_shift0[c] = entry;
+    }
+  }
+  // ---- ticket: the last workgroup scans the tail counts (every wave's stores first, then the workgroup's ticket)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_is_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1u;
+  __syncthreads();
+  if (!s_is_last) return;
+  __threadfence();
+  uint64_t* tail_pre = const_cast<uint64_t*>(A.tail_pre);
+  uint64_t carry = 0;
+  for (uint64_t i0 = 0; i0 < A.nchunks; i0 += kBlock) {
+    const uint64_t i = i0 + threadIdx.x;
+    const uint64_t x = i < A.nchunks ? __hip_atomic_load(A.tail_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    uint64_t t;
+    const uint64_t ex = block_excl_scan_u64(x, sh, &t);
+    if (i < A.nchunks) tail_pre[i] = carry + ex;
+    carry += t;
+  }
+  if (threadIdx.x == 0) {
+    tail_pre[A.nchunks] = carry;
+    const uint64_t kept = A.keep_all ? M : A.keep_pre[M];
+    const uint64_t fin = kept + carry;
+    A.tot_dev[kTotKept] = kept;
+    A.tot_dev[kTotFinal] = fin;
+    A.tot_host[kTotKept] = kept;
+    A.tot_host[kTotFinal] = fin;
+    if (fin > A.f_cap) {
+      A.tot_dev[kTotOverflow] |= 2u;
+      A.tot_host[kTotOverflow] = A.tot_dev[kTotOverflow];
+    }
+    *A.ticket = 0u;
+  }
+}
+
+// ---- one-sync route: k_assemble + k_globalize in one, plus the pinned mirror of the result -----------------------
+// final list = per chunk: kept bulk matches, then the tail walk's matches.  Thread i handles raw entry i
+// (grid-stride: the grid covers the capacity) and, as chunk i's thread, that chunk's tail matches.
+__global__ __launch_bounds__(kBlock) void k_list_out(const ListArgs A) {
+  const uint64_t M = list_count(A);
+  const uint64_t fin = A.tot_dev[kTotFinal];
+  if (fin > A.f_cap) return;  // refused: the host repeats the search on the exact route
+  const bool lm = A.line_mode != 0;
+  const uint64_t n = M > A.nchunks ? M : A.nchunks;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); i0 < n; i0 += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = i0 + (threadIdx.x & 63u);
+    if (i < M && (A.keep_all || A.keep[i])) {
+      const uint32_t c = A.m_chunk[i];
+      const uint64_t dst = (A.keep_all ? i : A.keep_pre[i]) + A.tail_pre[c];
+      const uint64_t pos = lm ? A.m_ls[i] : A.m_pos[i];
+      if (A.want_f) {
+        A.f_pos[dst] = pos;
+        A.f_match[dst] = A.m_pos[i];
+        A.f_chunk[dst] = c;
+      }
+      if (A.out_u64) {
+        const uint64_t g = A.chunks[c].global_offset + pos;
+        A.out_u64[dst] = g;
+        if (A.out_host) A.out_host[dst] = g;
+      }
+    }
+    // the tail walk's matches of chunk i; their line starts may lie a whole huge line back, so the loop runs
+    // wave-uniformly (up to the largest count in the wave) and the wave shares long scans
+    const bool has_chunk = i < A.nchunks;
+    const uint64_t c = has_chunk ? i : 0;
+    const uint32_t nt = has_chunk ? A.tail_cnt[c] : 0u;
+    uint32_t nmax = nt;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)nmax, sft);
+      nmax = o > nmax ? o : nmax;
+    }
+    if (nmax) {
+      uint64_t r1 = has_chunk ? A.tile_off[A.chunk_tile0[c + 1]] : 0;
+      r1 = r1 < M ? r1 : M;
+      const uint64_t dst0 = has_chunk ? (A.keep_all ? r1 : A.keep_pre[r1]) + A.tail_pre[c] : 0;
+      const ChunkDev ch = A.chunks[c];
+      const uint8_t* d = A.base + ch.offset;
+      for (uint32_t k = 0; k < nmax; ++k) {
+        const bool live = k < nt && k < A.tail_cap;
+        const uint64_t m = live ? A.tail_pos[c * A.tail_cap + k] : 0;
+        const int64_t nl = newline_query<false>(live && lm, d, 0, m, threadIdx.x & 63u);
+        if (live) {
+          const uint64_t pos = !lm ? m : nl < 0 ? 0u : (uint64_t)nl + 1u;
+          if (A.want_f) {
+            A.f_pos[dst0 + k] = pos;
+            A.f_match[dst0 + k] = m;
+            A.f_chunk[dst0 + k] = (uint32_t)c;
+          }
+          if (A.out_u64) {
+            const uint64_t g = ch.global_offset + pos;
+            A.out_u64[dst0 + k] = g;
+            if (A.out_host) A.out_host[dst0 + k] = g;
+          }
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_chunk_tail(const ListArgs& a, hipStream_t s) {
+  uint64_t blocks = (a.nchunks + kWaves - 1) / kWaves;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_chunk_tail, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_list_out(const ListArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_list_out, grid_capped(std::max<uint64_t>(a.M, a.nchunks)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
 }
 
 // final list = per chunk: kept bulk matches, then the tail walk's matches
@@ -331,7 +662,7 @@ hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s) {
 }
 hipError_t launch_line_starts_keep(const ListArgs& a, hipStream_t s) {
   if (!a.M) return hipSuccess;
-  hipLaunchKernelGGL(k_line_starts_keep, grid_for(a.M), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(k_line_starts_keep, a.M_dev ? grid_capped(a.M) : grid_for(a.M), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s) {
@@ -457,50 +788,123 @@ __global__ void k_line_indices(const LineOutArgs A) {
     A.out_u64[i] = ch.line_base + (n - A.tile_nl_off[A.chunk_tile0[c]]);
 }
 
+// length of the final list: the host's value, or (one-sync route) the device's bounded by the arrays' capacity
+__device__ __forceinline__ uint64_t out_count(const LineOutArgs& A) {
+  if (!A.tot_dev) return A.total;
+  const uint64_t n = A.tot_dev[kTotFinal];
+  return n <= A.total ? n : 0;  // over capacity: nothing is produced, the host repeats the search on the exact route
+}
+
+// xs::line_indices on the one-sync route: the list is short (it fits the route's capacity), so instead of the
+// difference / prefix-sum passes above every entry gets a WAVE: newlines before the line's tile from the prefix of
+// the per-tile counts, plus the newlines between the tile start and the line start counted by 64 lanes, 4 KiB a step
+// (one thread walking up to a whole tile took 150 us for 7 000 entries).
+__global__ __launch_bounds__(kBlock) void k_line_index_waves(const LineOutArgs A) {
+  const uint64_t total = out_count(A);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t sh = 31u - (uint32_t)__clz(A.tile_bytes);  // tiles are a power of two
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWaves;
+  for (uint64_t i = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); i < total; i += nwaves) {  // wave-uniform
+    const uint32_t c = A.f_chunk[i];
+    const ChunkDev ch = A.chunks[c];
+    const uint8_t* d = A.base + ch.offset;
+    const uint64_t b = A.f_pos[i];
+    const uint64_t tl = b >> sh;
+    const uint64_t from = tl << sh;
+    uint32_t cnt = 0;
+    for (uint64_t p = from + (uint64_t)lane * kUnit; p < b; p += 4u * kWaveLoad) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t q = p + (uint64_t)u * kWaveLoad;
+        if (q + kUnit <= b)
+          cnt += unit_newlines(d + q);
+        else if (q < b)
+          cnt += unit_newlines_masked(d + q, 0u, (uint32_t)(b - q));
+      }
+    }
+    cnt = wave_sum_u32(cnt);
+    if (lane == 0) {
+      const uint64_t n = A.tile_nl_off[A.chunk_tile0[c] + tl] + cnt;
+      const uint64_t v = ch.line_base == XSG_LINE_BASE_AUTO ? A.shard_line_base + n
+                                                            : ch.line_base + (n - A.tile_nl_off[A.chunk_tile0[c]]);
+      A.out_u64[i] = v;
+      if (A.out_host) A.out_host[i] = v;
+    }
+  }
+}
+
 // xs::lines: [line start, next '\n' after the match); a line without '\n' is
 // dropped (search_wrappers.h:199-202)
 __global__ __launch_bounds__(kBlock) void k_line_lengths(const LineOutArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool live = i < A.total;  // no early return: see newline_query
-  const ChunkDev ch = A.chunks[live ? A.f_chunk[i] : 0u];
-  const uint8_t* d = A.base + ch.offset;
-  const int64_t e = newline_query<true>(live, d, live ? A.f_match[i] + A.pat.plen : 0, ch.length, threadIdx.x & 63u);
-  if (!live) return;
-  A.line_len[i] = e < 0 ? UINT64_MAX : (uint64_t)e - A.f_pos[i];
-  A.out_u64[i] = ch.global_offset + A.f_pos[i];
+  const uint64_t total = out_count(A);
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); i0 < total; i0 += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = i0 + (threadIdx.x & 63u);
+    const bool live = i < total;  // no early exit of a lane: see newline_query
+    const ChunkDev ch = A.chunks[live ? A.f_chunk[i] : 0u];
+    const uint8_t* d = A.base + ch.offset;
+    const int64_t e = newline_query<true>(live, d, live ? A.f_match[i] + A.pat.plen : 0, ch.length, threadIdx.x & 63u);
+    if (!live) continue;
+    const uint64_t len = e < 0 ? UINT64_MAX : (uint64_t)e - A.f_pos[i];
+    const uint64_t g = ch.global_offset + A.f_pos[i];
+    A.line_len[i] = len;
+    A.out_u64[i] = g;
+    if (A.line_len_host) A.line_len_host[i] = len;
+    if (A.out_host) A.out_host[i] = g;
+  }
 }
 
 // xs::lines: the bytes of every reported line, packed.  One THREAD per line: a line of text is a few dozen bytes,
 // which a lane moves with one or two 16-byte loads and stores (unaligned global accesses are native on gfx950) --
 // a wave per line, the first version, kept 64 lanes busy with 30 bytes (19 ms for the 66 M lines that contain
 // `She` in 10 GiB).  Lines over 256 bytes wait until the wave has finished its short ones and are then copied by
-// all 64 lanes together, 1 KiB a step.
+// all 64 lanes together, 1 KiB a step.  One-sync route: the packed bytes also go to their pinned mirror, and
+// nothing is written if they exceed the capacity (line_out_off[total] is their number).
 typedef unsigned int uint4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 __global__ __launch_bounds__(kBlock) void k_line_gather(const LineOutArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t total = out_count(A);
   const uint32_t lane = threadIdx.x & 63u;
-  uint64_t len = i < A.total ? A.line_len[i] : UINT64_MAX;
-  const bool live = len != UINT64_MAX;  // UINT64_MAX: no terminating newline -> not reported
-  const uint8_t* src = live ? A.base + A.chunks[A.f_chunk[i]].offset + A.f_pos[i] : nullptr;
-  uint8_t* dst = live ? A.line_bytes + A.line_out_off[i] : nullptr;
-  if (!live) len = 0;
-  const bool big = len > 256;
-  if (!big) {
-    uint64_t k = 0;
-    for (; k + 16 <= len; k += 16) *reinterpret_cast<uint4_unaligned*>(dst + k) = *reinterpret_cast<const uint4_unaligned*>(src + k);
-    for (; k < len; ++k) dst[k] = src[k];
-  }
-  unsigned long long pend = __ballot(big);
-  while (pend) {  // wave-uniform
-    const int L = __builtin_ctzll(pend);
-    pend &= pend - 1ull;
-    const uint8_t* s2 = reinterpret_cast<const uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)src, L));
-    uint8_t* d2 = reinterpret_cast<uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)dst, L));
-    const uint64_t n2 = (uint64_t)__shfl((long long)len, L);
-    const uint64_t whole = n2 & ~(uint64_t)15;
-    for (uint64_t k = (uint64_t)lane * 16u; k < whole; k += 64u * 16u)
-      *reinterpret_cast<uint4_unaligned*>(d2 + k) = *reinterpret_cast<const uint4_unaligned*>(s2 + k);
-    if (whole + lane < n2) d2[whole + lane] = s2[whole + lane];
+  if (A.line_bytes_cap && A.line_out_off[total] > A.line_bytes_cap) return;
+  uint8_t* const mirror = A.line_bytes_host;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); i0 < total; i0 += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = i0 + lane;
+    uint64_t len = i < total ? A.line_len[i] : UINT64_MAX;
+    const bool live = len != UINT64_MAX;  // UINT64_MAX: no terminating newline -> not reported
+    const uint8_t* src = live ? A.base + A.chunks[A.f_chunk[i]].offset + A.f_pos[i] : nullptr;
+    const uint64_t doff = live ? A.line_out_off[i] : 0;
+    uint8_t* dst = live ? A.line_bytes + doff : nullptr;
+    if (!live) len = 0;
+    const bool big = len > 256;
+    if (!big) {
+      uint64_t k = 0;
+      for (; k + 16 <= len; k += 16) {
+        const uint4_unaligned v = *reinterpret_cast<const uint4_unaligned*>(src + k);
+        *reinterpret_cast<uint4_unaligned*>(dst + k) = v;
+        if (mirror) *reinterpret_cast<uint4_unaligned*>(mirror + doff + k) = v;
+      }
+      for (; k < len; ++k) {
+        dst[k] = src[k];
+        if (mirror) mirror[doff + k] = src[k];
+      }
+    }
+    unsigned long long pend = __ballot(big);
+    while (pend) {  // wave-uniform
+      const int L = __builtin_ctzll(pend);
+      pend &= pend - 1ull;
+      const uint8_t* s2 = reinterpret_cast<const uint8_t*>((uintptr_t)__shfl((long long)(uintptr_t)src, L));
+      const uint64_t o2 = (uint64_t)__shfl((long long)doff, L);
+      uint8_t* d2 = A.line_bytes + o2;
+      const uint64_t n2 = (uint64_t)__shfl((long long)len, L);
+      const uint64_t whole = n2 & ~(uint64_t)15;
+      for (uint64_t k = (uint64_t)lane * 16u; k < whole; k += 64u * 16u) {
+        const uint4_unaligned v = *reinterpret_cast<const uint4_unaligned*>(s2 + k);
+        *reinterpret_cast<uint4_unaligned*>(d2 + k) = v;
+        if (mirror) *reinterpret_cast<uint4_unaligned*>(mirror + o2 + k) = v;
+      }
+      if (whole + lane < n2) {
+        d2[whole + lane] = s2[whole + lane];
+        if (mirror) mirror[o2 + whole + lane] = s2[whole + lane];
+      }
+    }
   }
 }
 
@@ -522,12 +926,19 @@ hipError_t launch_line_indices(const LineOutArgs& a, hipStream_t s) {
 }
 hipError_t launch_line_lengths(const LineOutArgs& a, hipStream_t s) {
   if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_line_lengths, grid_for(a.total), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(k_line_lengths, a.tot_dev ? grid_capped(a.total) : grid_for(a.total), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_line_index_waves(const LineOutArgs& a, hipStream_t s) {
+  if (!a.total) return hipSuccess;
+  uint64_t blocks = (a.total + kWaves - 1) / kWaves;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_line_index_waves, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s) {
   if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_line_gather, grid_for(a.total), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(k_line_gather, a.tot_dev ? grid_capped(a.total) : grid_for(a.total), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 

@@ -147,6 +147,21 @@ struct xsg_shard {
   bool begin_sync_result = false;  // xsg_count_begin had to run synchronously: _end hands out begin_counters
   uint64_t begin_counters[XSG_NUM_COUNTERS] = {0, 0, 0, 0};
 
+  // The one-sync list route (xsg_api.cpp: run_list_fast): capacities instead of fetched sizes, totals and results
+  // mirrored in pinned host memory by the kernels, one stream sync per search.
+  DevBuf d_tot;                    // FastTot words, then u32 ticket words
+  DevBuf d_hit;                    // tiles that hold a match, in order
+  DevBuf d_scan2;                  // scratch of the two-launch scans
+  uint64_t* h_tot = nullptr;       // pinned mirror of the FastTot words (+ one word for the scan flags)
+  uint64_t* hp_line_len = nullptr; // pinned: xs::lines lengths (UINT64_MAX = dropped)
+  size_t hp_line_len_cap = 0;      // entries
+  uint8_t* hp_line_bytes = nullptr;
+  size_t hp_line_bytes_cap = 0;
+  uint64_t fast_dense_serial = 0;  // ctx->pattern_serial whose result did not fit the route's capacity on this binding (0: none)
+  bool fast_result = false;        // the pending result lives in the pinned mirrors (h_result, hp_line_*)
+  uint64_t fast_raw_lines = 0;     // xs::lines on that route: entries of hp_line_len (dropped lines included)
+  uint64_t nl_total = 0;           // '\n' in the shard, valid while nl_off_cached
+
   uint64_t pre_dense_serial = 0;  // the ctx->pattern_serial whose prefilter candidates were found dense on this binding (0: none)
   bool pre_off = false;        // run_list: this call must not take the prefilter route (its verification budget ran out)
   bool want_nl_total = false;  // run_list: also leave the shard's newline total in last_newlines (xsg_count on the prefilter route)
@@ -162,13 +177,20 @@ struct xsg_shard {
                      &d_counters, &d_finish, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls,
                      &d_keep, &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
                      &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes, &d_c_pos, &d_c_chunk, &d_c_len, &d_c_keep,
-                     &d_c_pre, &d_tile_mask};
+                     &d_c_pre, &d_tile_mask, &d_tot, &d_hit, &d_scan2};
     for (DevBuf* b : all) b->release();
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_counters) (void)hipHostFree(h_counters);
     if (h_result) (void)hipHostFree(h_result);
     h_result = nullptr;
     h_result_cap = 0;
+    if (h_tot) (void)hipHostFree(h_tot);
+    if (hp_line_len) (void)hipHostFree(hp_line_len);
+    if (hp_line_bytes) (void)hipHostFree(hp_line_bytes);
+    h_tot = nullptr;
+    hp_line_len = nullptr;
+    hp_line_bytes = nullptr;
+    hp_line_len_cap = hp_line_bytes_cap = 0;
     if (table_ev) (void)hipEventDestroy(table_ev);
     h_stage = nullptr;
     h_counters = nullptr;

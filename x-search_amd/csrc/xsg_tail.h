@@ -136,9 +136,10 @@ XSG_HD int64_t lossy_scalar_find_masks(uint64_t cur, uint64_t L, uint64_t Z, uin
   }
 }
 
+// out (optional): receives up to cap match offsets (chunk-local), as tail_walk's does.
 template <typename KAt>
 XSG_HD uint32_t tail_walk_masks(uint64_t L, uint32_t plen, uint64_t shift0, bool skip_to_nl, uint64_t full, uint64_t nz,
-                                uint64_t nlm, KAt k_at) {
+                                uint64_t nlm, KAt k_at, uint64_t* out = nullptr, uint32_t cap = 0) {
   if (plen <= 1 || shift0 == UINT64_MAX) return 0;
   const uint64_t Z = tail_zone_begin(L, plen);
   uint32_t n = 0;
@@ -156,6 +157,7 @@ XSG_HD uint32_t tail_walk_masks(uint64_t L, uint32_t plen, uint64_t shift0, bool
       m = exact ? (int64_t)(Z + (uint32_t)__builtin_ctzll(exact)) : lossy_scalar_find_masks(T, L, Z, plen, full, nz, k_at);
     }
     if (m < 0) break;
+    if (out && n < cap) out[n] = (uint64_t)m;
     ++n;
     shift = (uint64_t)m + plen;
     if (skip_to_nl) {
