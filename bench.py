@@ -60,6 +60,9 @@ def parse():
                     help="size of the tmpfs file of the end-to-end (file -> result) leg; 0 = skip")
     ap.add_argument("--no-tune", action="store_true", help="keep the per-variant default stagger")
     ap.add_argument("--no-regex", action="store_true", help="skip the regex leg (N=1: a few expressions on the resident shard)")
+    ap.add_argument("--configs-gib", type=float, default=10.0,
+                    help="N=1: size of the sub-shard of the resident buffer on which BASELINE configs 2 and 4 (the list "
+                         "tags) are timed and checked element by element; 0 = skip")
     return ap.parse_args()
 
 
@@ -89,7 +92,7 @@ def template_blocks(args, pattern: bytes):
     blocks = []
     for i in range(args.templates):
         extra = 1 + (corpus._mix(args.seed, 1000 + i) % 61)  # fixtures: 16 MiB extended to just past the next '\n'
-        blocks.append(corpus.text_block(args.seed, i, target + extra, needle=pattern))
+        blocks.append(corpus.text_block(args.seed, i, target + extra, needle=pattern, lexicon=getattr(args, "lexicon", None)))
     return blocks
 
 
@@ -239,8 +242,13 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         want_total = int(sum(tcount[int(c)] for c in plan))
         lo, hi = (n * rank) // world, (n * (rank + 1)) // world
         want_local = int(sum(tcount[int(c)] for c in plan[lo:hi]))
-        nthreads = int(os.environ.get("XSG_E2E_WORKERS", "4"))
-        nreaders = int(os.environ.get("XSG_E2E_READERS", "8"))
+        # threads from the CPU time this process group may use (cgroup quota, else hardware threads), shared by the
+        # ranks of the node: 4 device workers + 8 readers per GPU when there is room (one GPU in a 16-CPU cgroup), one
+        # of each when 8 ranks share 16 CPUs
+        topo = host_topology()
+        budget = max(2, int((topo["cgroup_cpu_quota"] or topo["hw_threads"]) // max(world, 1)))
+        nthreads = int(os.environ.get("XSG_E2E_WORKERS", str(max(1, min(4, budget // 3)))))
+        nreaders = int(os.environ.get("XSG_E2E_READERS", str(max(1, min(8, budget - max(1, min(4, budget // 3)))))))
 
         def run(mode, meta=None, data=None):
             if dist is not None:
@@ -284,7 +292,7 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         nsmall = min(max(world, n // 4), 128)
         lo, hi = (nsmall * rank) // world, (nsmall * (rank + 1)) // world
         want_l = int(sum(tcount[int(c)] for c in plan[lo:hi]))
-        nreaders = int(os.environ.get("XSG_E2E_DECODERS", "12"))
+        nreaders = int(os.environ.get("XSG_E2E_DECODERS", str(max(1, min(12, budget - nthreads)))))
         run(xsg.COUNT_MATCHES, mp, dp)
         r, dt = run(xsg.COUNT_MATCHES, mp, dp)
         if r != want_l:
@@ -293,7 +301,8 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         out["lz4_metafile_count_gib_s"] = round(small_bytes / dt / 2**30, 2)
         out["lz4_compressed_fraction"] = round(os.path.getsize(dp) / small_bytes, 3) if rank == 0 else None
         out["file_gib"] = round(size / 2**30, 2)
-        out["threads"] = f"{nthreads} device workers + 8 readers per GPU (12 reader/decoder threads for LZ4)"
+        out["threads"] = (f"{nthreads} device workers + {max(1, min(8, budget - nthreads)) if 'XSG_E2E_READERS' not in os.environ else os.environ['XSG_E2E_READERS']} readers per GPU "
+                          f"({nreaders} reader/decoder threads for LZ4); CPU budget per rank {budget}")
         out["what"] = ("wall time from xsg_job_start to join on a tmpfs file (page-cache read -> pinned buffers -> "
                        "hipMemcpyAsync -> scan -> ordered result); bounded by PCIe Gen5 x16 and the host read path, "
                        "not by HBM")
@@ -346,6 +355,72 @@ def regex_leg(xsg, torch, ctx, shard, stream, shard_bytes):
                     "kernel": shard.scan_kernel_name(xsg.COUNT_MATCHES)})
     return {"what": "whole synchronous xsg_count(COUNT_MATCHES) calls with XSG_FLAG_REGEX on the same resident shard; "
                     "each count equals the one xsg_count_async computes on its own route", "cases": out}
+
+
+def configs_leg(xsg, ctx, orc, shard_t, cap, chunks, plan, blocks, ln, pattern, gib):
+    """BASELINE configs 2 and 4 device-resident (N=1, never `value`): xs::match_byte_offsets, xs::line_byte_offsets,
+    xs::line_indices and xs::lines on the first `gib` GiB of the resident shard, whole calls at the C ABI (search +
+    the result in host memory, scripts/config_times.py), next to xs::count on the same sub-shard.  Every result is
+    compared element by element with the oracle's results on the template chunks (chunks are independent units:
+    offsets = template-local offsets + the chunk's global offset, line indices = local indices + newlines before the
+    chunk, lines = the template's lines), as tests/test_gpu_fullsize.py does."""
+    import ctypes as C
+    sys.path.insert(0, str(ROOT / "scripts"))
+    from config_times import timed_calls
+    n = min(len(plan), max(1, int(round(gib * 2**30 / (16 << 20)))))
+    sub = chunks[:n].copy()
+    sub["global_offset"] = np.concatenate([[0], np.cumsum(ln[:n])[:-1]]).astype(np.uint64)
+    nbytes = int(ln[:n].sum())
+    sh = xsg.Shard(ctx, shard_t.data_ptr(), cap, sub)
+    lib = xsg.load()
+    ctx.set_pattern(pattern)
+    out = {"what": f"whole C-ABI calls (search + result in host memory) on the first {n} chunks = {nbytes / 2**30:.2f} GiB of "
+                   f"the resident shard; every list compared element by element with the oracle", "bytes": nbytes, "tags": {}}
+    # first xs::line_indices of a binding also counts the newlines per tile (cached afterwards)
+    t0 = time.perf_counter()
+    first_idx = sh.search_u64_view(xsg.LINE_INDICES).copy()
+    out["line_indices_first_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    r = timed_calls(lib, sh, 7)
+    base = r["count"][1]
+    for tag, (cnt, ms) in r.items():
+        out["tags"][tag] = {"results": cnt, "ms": round(ms, 4), "gbs": round(nbytes / ms / 1e6, 1),
+                            "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "vs_count": round(ms / base, 3)}
+    # ---- element-wise check
+    goffs = sub["global_offset"]
+    pl = plan[:n]
+    nl_t = np.array([orc.count_newlines(b) for b in blocks], dtype=np.uint64)
+    nl_before = np.concatenate([[0], np.cumsum(nl_t[pl])[:-1]]).astype(np.uint64)
+    want_m = np.concatenate([orc.byte_offsets_match(blocks[int(c)], pattern) + goffs[i] for i, c in enumerate(pl)])
+    lo_t = [orc.byte_offsets_line(b, pattern) for b in blocks]
+    want_lo = np.concatenate([lo_t[int(c)] + goffs[i] for i, c in enumerate(pl)])
+    li_t = [orc.line_indices(b, pattern, 0) for b in blocks]
+    want_li = np.concatenate([li_t[int(c)] + nl_before[i] for i, c in enumerate(pl)])
+    lines_t = [orc.lines(b, pattern) for b in blocks]
+    want_lines = [l for c in pl for l in lines_t[int(c)]]
+    bad = []
+    if not np.array_equal(sh.search_u64(xsg.MATCH_BYTE_OFFSETS), want_m):
+        bad.append("match_byte_offsets")
+    if not np.array_equal(sh.search_u64(xsg.LINE_BYTE_OFFSETS), want_lo):
+        bad.append("line_byte_offsets")
+    if not (np.array_equal(sh.search_u64(xsg.LINE_INDICES), want_li) and np.array_equal(first_idx, want_li)):
+        bad.append("line_indices")
+    got_lines, got_off = sh.search_lines()
+    if got_lines != want_lines or not np.array_equal(got_off, want_lo):
+        bad.append("lines")
+    if bad:
+        raise SystemExit(f"configs PARITY FAILURE: {bad}")
+    out["parity"] = f"{want_m.size} offsets, {want_lo.size} line offsets, {want_li.size} line indices, {len(want_lines)} lines == oracle"
+    # ---- a needle that is in most lines: the list tags are then bound by what they write and move, not by the scan
+    ctx.set_pattern(b"She")
+    d = timed_calls(lib, sh, 3)
+    out["dense_needle"] = {"pattern": "She", "tags": {t: {"results": c, "ms": round(ms, 3)} for t, (c, ms) in d.items()},
+                           "note": "tens of millions of results: D2H of the lists (xs::lines: into pageable caller memory) dominates"}
+    tm = np.array([orc.count(b, b"She", False) for b in blocks], dtype=np.int64)
+    if d["count"][0] != int(tm[pl].sum()) or d["match_byte_offsets"][0] != int(tm[pl].sum()):
+        raise SystemExit("configs PARITY FAILURE: dense needle count")
+    ctx.set_pattern(pattern)
+    sh.close()
+    return out
 
 
 def main():
@@ -429,6 +504,26 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
+    # What a caller WITHOUT xsg_shard_tune gets, first call included (N=1; never `value`): a fresh binding, the
+    # synchronous xsg_count -- the first call also runs the library's hot-filter probe.
+    untuned = None
+    if world == 1:
+        su = xsg.Shard(ctx, shard_t.data_ptr(), cap, chunks)
+        t0 = time.perf_counter()
+        got = int(su.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
+        first_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        for _ in range(5):
+            got = int(su.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        if got != expected_local:
+            raise SystemExit(f"PARITY FAILURE (untuned xsg_count): {got} != {expected_local}")
+        untuned = {"first_call_ms": round(first_ms, 3), "first_call_gib_s": round(shard_bytes / first_ms / 2**30 * 1e3, 1),
+                   "ms_per_call": round(ms, 4), "gib_s": round(shard_bytes / ms / 2**30 * 1e3, 1),
+                   "kernel": su.scan_kernel_name(xsg.COUNT_MATCHES),
+                   "what": "synchronous xsg_count on a fresh binding, no xsg_shard_tune: the first call includes the "
+                           "library's per-(binding, pattern) probe, later calls use the default stagger"}
+        su.close()
     # the wave stagger of the bulk kernel: measured on this shard (a few launches), not a constant
     stagger = None if args.no_tune else shard.tune(xsg.COUNT_MATCHES)
     stagger_strong = stagger if (world == 1 or args.no_tune) else shard_strong.tune(xsg.COUNT_MATCHES)
@@ -441,20 +536,6 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
-
-    # XSG_BENCH_COLL=xsg (opt-in): the per-step all-reduce goes through the LIBRARY's RCCL communicator
-    # (include/xsg.h: xsg_comm_create_rank / xsg_reduce_counts_async) instead of torch.distributed's; torch only
-    # carries the 128-byte id to the ranks.  Every rank first agrees that it has a librccl, so that no rank waits
-    # in ncclCommInitRank for one that cannot come.
-    lib_comm = None
-    if dist is not None and backend == "nccl" and os.environ.get("XSG_BENCH_COLL") == "xsg":
-        have = torch.tensor([1 if xsg.comm_library() else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(have, op=dist.ReduceOp.MIN)
-        if int(have.item()) == 1:
-            box = [xsg.comm_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
-            lib_comm = xsg.Comm.rank(ctx, world, rank, box[0])
 
     def all_reduce_(t, op=None):
         """in-place all-reduce of a device tensor (through host memory only in the gloo rehearsal)"""
@@ -487,17 +568,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(sh, expected, steps, warmup):
-        """W untimed + exactly K timed steps on shard `sh`; -> seconds of the K steps (max over ranks)"""
+    def measure(sh, expected, steps, warmup, lib_comm=None):
+        """W untimed + exactly K timed steps on shard `sh`; -> seconds of the K steps (max over ranks).
+        lib_comm: the per-step all-reduce goes through the library's own RCCL communicator instead of torch's"""
         def step(i, results=None):
             b = i & 1
             c = counters[b]
             if dist is None:
+                c.fill_(-1)  # poison on the scan's stream (32 bytes): a stale value of two steps ago cannot pass the check
                 sh.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
                 if results is not None:
                     results[i] = c[xsg.CTR_MATCHES]
                 return
             stream.wait_event(coll_done[b])  # the all_reduce that used this buffer two steps ago
+            c.fill_(-1)
             sh.count_async(xsg.COUNT_MATCHES, stream.cuda_stream, c.data_ptr())
             scan_done[b].record(stream)
             with torch.cuda.stream(coll_stream):
@@ -600,6 +684,11 @@ def main():
     if args.e2e_gib > 0:
         e2e = e2e_leg(args, blocks, pattern, tcount, rank, world, dist, dev_index)
 
+    configs = None
+    if world == 1 and args.configs_gib > 0:
+        configs = configs_leg(xsg, ctx, orc, shard_t, cap, chunks, plan, blocks, ln, pattern, args.configs_gib)
+
+    line = None
     if rank == 0:
         line = {
             "metric": "GiB/s scanned, xs::count literal on plain text resident in HBM",
@@ -616,7 +705,8 @@ def main():
             "data": "synthetic",
             "matches_per_s": round(expected_total * args.steps / elapsed, 1),
             "matches_per_step": expected_total,
-            "parity": "count of every timed step == oracle-derived expected count",
+            "parity": "count of every timed step == oracle-derived expected count (the counter buffer is poisoned on the "
+                      "scan's stream before every step)",
             "config": {
                 "workload": f"xs::count literal '{args.pattern}' on {args.gib_per_gpu:g} GiB plain text per GPU "
                             f"({nchunks} newline-aligned {args.chunk_mib} MiB chunks), device-resident",
@@ -632,9 +722,12 @@ def main():
             "strong": strong,
             "rccl_ranks": (world if (dist is not None and backend == "nccl") else 0),
             "collective_backend": (backend if dist is not None else None),
-            "collective_through": (None if dist is None else "libxsg (xsg_reduce_counts_async)" if lib_comm is not None
-                                   else "torch.distributed"),
+            "collective_through": None if dist is None else "torch.distributed",
             "allreduce_us": None if allreduce_us is None else round(allreduce_us, 1),
+            # N > 1: the same strong-form steps with the per-step all-reduce on the LIBRARY's RCCL communicator
+            # (xsg_comm_create_rank + xsg_reduce_counts_async); null when a rank has no librccl or the leg did not finish
+            "strong_lib": None,
+            "allreduce_us_lib": None,
             "roofline": {
                 "bound": "hbm",
                 "kernel": kernel_name,  # from the library: the instantiation this pattern and mode launch
@@ -649,16 +742,71 @@ def main():
                 "algorithmic_bytes_per_launch": shard_bytes,
             },
         }
+        if untuned is not None:
+            line["untuned"] = untuned
+        if configs is not None:
+            line["configs"] = configs
         if regex is not None:
             line["regex"] = regex
         if e2e is not None:
             line["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, blocks, pattern)
+
+    # ---- N > 1, last: the product's own exchange step (include/xsg.h "Multi-GPU"; reference: the only parallelism is
+    # include/xsearch/Searcher.h:141-145).  Everything above is already measured; this leg runs under a watchdog so
+    # that a communicator that never forms (it has never met 8 GPUs before the driver's run) costs the two lib
+    # fields, not the record: after 120 s every rank gives up, rank 0 prints the line with nulls.
+    if dist is not None and backend == "nccl" and world > 1 and os.environ.get("XSG_BENCH_LIB_COLL", "1") != "0":
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["strong_lib_note"] = "the library-communicator leg did not finish within 120 s"
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(120.0, give_up)
+        dog.daemon = True
+        dog.start()
+        lib_comm = None
+        try:
+            have = torch.tensor([1 if xsg.comm_library() else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+            if int(have.item()) == 1:  # every rank agrees it has a librccl: nobody waits in ncclCommInitRank for a rank that cannot come
+                box = [xsg.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ok = torch.ones(1, dtype=torch.int64, device=dev)
+                try:
+                    lib_comm = xsg.Comm.rank(ctx, world, rank, box[0])
+                except Exception:
+                    ok.zero_()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    el = measure(shard_strong, expected_strong, args.steps, args.warmup, lib_comm=lib_comm)
+                    c = counters[0]
+                    for _ in range(5):
+                        lib_comm.reduce_counts_async(c.data_ptr(), xsg.NUM_COUNTERS, stream.cuda_stream)
+                    sync_all()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        lib_comm.reduce_counts_async(c.data_ptr(), xsg.NUM_COUNTERS, stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    us = (time.perf_counter() - t0) / 50 * 1e6
+                    if rank == 0:
+                        line["strong_lib"] = {"value": round(strong_total * args.steps / el / 2**30, 2), "unit": "GiB/s",
+                                              "ms_per_step": round(el / args.steps * 1e3, 4),
+                                              "through": "libxsg: xsg_comm_create_rank + xsg_reduce_counts_async "
+                                                         f"({xsg.comm_library()})"}
+                        line["allreduce_us_lib"] = round(us, 1)
+                if lib_comm is not None:
+                    torch.cuda.synchronize()
+                    lib_comm.close()
+        finally:
+            dog.cancel()
+
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    if lib_comm is not None:
-        torch.cuda.synchronize()
-        lib_comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

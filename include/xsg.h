@@ -107,6 +107,13 @@ enum xsg_mode {
  * (slow), and serves XSG_COUNT_MATCHES / XSG_MATCH_BYTE_OFFSETS only.  Refused on
  * this route (XSG_ENOTSUP from xsg_set_pattern, never approximated): expressions
  * that can match the empty string, automata over 16384 table entries.  Refused on both routes: anchors ^ $ \b \A \z, (?flags), \p, \C.
+ * CAPTURE GROUPS: the reference's walk is RE2::PartialMatch(input, pattern, &match) (search_wrappers.h:71-75,
+ * 254-257), where `match` receives capture group ONE; its tests hand over an expression that IS one group,
+ * re2::RE2("(a[n|m]t)") (test/src/string_search/search_wrappersTest.cpp:78).  XSG_FLAG_REGEX(expr) is that call with
+ * "(" + expr + ")": offset, length and resume point are those of the WHOLE match; groups inside `expr` only group
+ * (`Sher(lock|wood)` reports where `Sher` starts, not where `lock` does; an expression the caller already wrapped,
+ * `(a[n|m]t)`, is the same search).  A maintainer who binds this flag passes the expression without relying on an inner
+ * group being reported (tests/test_oracle_regex.py::test_the_whole_match_is_group_one_of_the_wrapped_expression).
  * No tail quirk applies (RE2 is exact); XSG_FLAG_IGNORE_CASE folds ASCII letters in
  * the data and in every class, as for literals (automaton route: the classes are
  * closed under case instead, the same thing). */
@@ -205,7 +212,12 @@ int xsg_regex_factor(const void* expr, size_t n, uint32_t flags, uint32_t* posit
 
 /* ---- shards ---------------------------------------------------------------- */
 /* d_base/capacity: device memory owned by the caller (hipMalloc, a torch
- * tensor's data_ptr(), ...), must stay valid and unchanged while searches run.
+ * tensor's data_ptr(), ...), must stay valid, and its BYTES ARE IMMUTABLE FOR THE LIFETIME OF THE BINDING: the library
+ * keeps results derived from them per binding (newline counts per tile, the measured hot filter and filter window of
+ * a pattern, the tile marks and density verdicts of the regex prefilters, whether a pattern's lists fit the one-sync
+ * route) and every later pass -- the stream-ordered xsg_count_async included -- relies on them.  A caller that refills
+ * the buffer in place calls xsg_shard_rebind (same pointer and table are fine) or xsg_shard_invalidate before the
+ * next search; searching rewritten bytes under an old binding can silently lose matches.
  * Requirements: d_base 16-byte aligned; for every chunk offset % 16 == 0 and
  * offset + round_up(length,16) <= capacity; chunks must not overlap and must
  * be listed in increasing offset order.  The table is copied. */
@@ -215,6 +227,9 @@ int xsg_shard_create(xsg_ctx* ctx, const void* d_base, uint64_t capacity, const 
  * without re-allocating its scratch when the new table is not larger. */
 int xsg_shard_rebind(xsg_shard* shard, const void* d_base, uint64_t capacity, const xsg_chunk* chunks,
                      uint64_t nchunks);
+/* The bytes behind the binding were rewritten in place (same buffer, same chunk table): forget everything derived
+ * from the old bytes.  Cheaper than a rebind (no table upload); a rebind implies it. */
+int xsg_shard_invalidate(xsg_shard* shard);
 void xsg_shard_destroy(xsg_shard* shard);
 /* line-index base of the whole shard for XSG_LINE_BASE_AUTO chunks (default 0):
  * the number of '\n' in all shards that precede this one in the file. */

@@ -49,11 +49,14 @@ def main():
     ap.add_argument("--gib", type=float, default=20.0)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--tune", action="store_true")
+    ap.add_argument("--lexicon", choices=["bench", "plain"], default="bench",
+                    help="plain: the bench lexicon without the words that are pieces of the needle (She, lock, locked, Sher)")
     a = ap.parse_args()
     import torch
     import corpus
     import xsg
-    args = argparse.Namespace(chunk_mib=16, templates=32, seed=0x5EED)
+    args = argparse.Namespace(chunk_mib=16, templates=32, seed=0x5EED,
+                              lexicon=corpus.LEXICON_PLAIN if a.lexicon == "plain" else None)
     blocks = bench.template_blocks(args, b"Sherlock")
     tbytes = np.array([b.size for b in blocks], dtype=np.int64)
     nchunks = int(round(a.gib * 2**30 / (16 << 20)))
@@ -82,7 +85,9 @@ def main():
         ctx.set_pattern(pat.encode(), flags)
         st = sh.tune(modes[mode]) if a.tune else None
         ms = sh.time_scan_kernel(modes[mode], a.iters)
-        print(json.dumps({"case": name, "pattern": pat, "flags": fl, "mode": mode, "gib": a.gib, "bytes": nbytes,
+        cm = int(sh.count(modes[mode])[xsg.CTR_LINES if mode == "count_lines" else xsg.CTR_MATCHES])
+        print(json.dumps({"case": name, "pattern": pat, "flags": fl, "mode": mode, "gib": a.gib, "bytes": nbytes, "lexicon": a.lexicon,
+                          "result": cm, "bytes_per_result": round(nbytes / max(cm, 1), 1),
                           "kernel": sh.scan_kernel_name(modes[mode]), "tuned_stagger": st, "ms": round(ms, 4),
                           "tb_s": round(nbytes / ms / 1e9, 3), "frac_of_8tbs": round(nbytes / ms / 1e9 / 8.0, 4)}), flush=True)
 

@@ -408,6 +408,31 @@ def test_long_patterns_with_a_shifted_filter_window(gs, oracle):
         assert oracle_all_modes(oracle, blocks, p, True)["count_matches"] > 15
 
 
+def test_a_64_mib_run_of_one_byte_is_resolved_in_parallel(gs, oracle):
+    """64 MiB of `a` searched for `aa` / `aaaa`: 67 million raw occurrences in ONE chain.  The chain head's thread
+    gives up after its budget and the chain is finished by pointer jumping over next-reported links (k_greedy_links /
+    k_greedy_jump, ~25 rounds); the list must equal the reference's sequential walk (simd_search.cpp:324-336,
+    search_wrappers.h:29-52), end-of-chunk behaviour included, and come back in well under the seconds one lane
+    would need."""
+    import time
+    n = 64 << 20
+    run = np.full(n + 1, ord("a"), dtype=np.uint8)
+    run[-1] = 10
+    blocks = [run, np.concatenate([np.frombuffer(b"xa", dtype=np.uint8), run[:5_000_001], np.frombuffer(b"b aa\n", dtype=np.uint8)])]
+    gs.bind(blocks)
+    for pat in (b"aa", b"aaaa"):
+        gs.ctx.set_pattern(pat)
+        gs.shard.search_u64_view(xsg.MATCH_BYTE_OFFSETS)  # warm: buffers
+        t0 = time.perf_counter()
+        got = gs.shard.search_u64_view(xsg.MATCH_BYTE_OFFSETS)
+        dt = time.perf_counter() - t0
+        want = np.concatenate([oracle.byte_offsets_match(blocks[0], pat), oracle.byte_offsets_match(blocks[1], pat) + np.uint64(blocks[0].size)])
+        assert got.size == want.size >= n // len(pat)
+        assert np.array_equal(got, want), pat
+        assert int(gs.shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == want.size
+        assert dt < 1.0, dt
+
+
 def test_half_a_gigabyte_without_a_newline(gs, oracle):
     """One 512 MiB chunk that is a single unterminated line, needles at both ends and in the middle, then the
     same with one newline in the middle: the line tags have to find a line start / line end half a gigabyte

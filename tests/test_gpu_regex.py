@@ -422,3 +422,44 @@ def test_factor_prefilter_of_expressions_without_a_selective_start(gs, oracle, m
                 assert int(c[xsg.CTR_MATCHES]) == res[-1]["count_matches"], (name, expr, fac)
             assert res[0] == res[1] and res[0] is not None
     monkeypatch.delenv("XSG_RX_FAC")
+
+
+def test_rewritten_bytes_need_a_rebind_or_invalidate(gs, oracle, monkeypatch):
+    """include/xsg.h: the bytes of a binding are immutable; a caller that refills the buffer in place re-binds (or calls
+    xsg_shard_invalidate) and every per-binding result derived from the old bytes -- here the factor prefilter's tile
+    marks, which make k_rx_scan skip tiles -- is rebuilt.  (Without that call the old marks would hide the new matches:
+    that is the documented contract, not tested as behaviour.)"""
+    import torch
+    monkeypatch.setenv("XSG_RX_FAC", "1")
+    a = corpus.text_block(71, 0, 400_000, needle_rate=0.0)
+    b = a.copy()
+    b[300_000:300_009] = np.frombuffer(b" somewere", dtype=np.uint8)  # a match of \w+ere in a tile that had none
+    b[100_000:100_008] = np.frombuffer(b" nowhere", dtype=np.uint8)
+    expr = b"\\w+ere"
+    gs.bind([a])
+    gs.ctx.set_pattern(expr, xsg.FLAG_REGEX)
+    from xs_oracle import RegexProgram
+    prog = RegexProgram(expr)
+    n_a = int(gs.shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
+    assert n_a == oracle.rx_count(a, prog, False)
+    assert "factor prefilter" in gs.shard.scan_kernel_name(xsg.COUNT_MATCHES)
+    want_b = oracle.rx_count(b, prog, False)
+    assert want_b == n_a + 2
+    c = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    for how in ("invalidate", "rebind"):
+        gs.keep[:a.size].copy_(torch.from_numpy(a))          # back to the old bytes, marks rebuilt for them
+        torch.cuda.synchronize()
+        gs.shard.invalidate()
+        assert int(gs.shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == n_a
+        gs.keep[:b.size].copy_(torch.from_numpy(b))          # the caller rewrites the buffer in place ...
+        torch.cuda.synchronize()
+        if how == "invalidate":                               # ... and says so
+            gs.shard.invalidate()
+        else:
+            chunks = xsg.make_chunks([0], [b.size])
+            gs.shard.rebind(gs.keep.data_ptr(), gs.keep.numel(), chunks)
+        assert int(gs.shard.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == want_b, how
+        gs.shard.count_async(xsg.COUNT_MATCHES, 0, c.data_ptr())
+        torch.cuda.synchronize()
+        assert int(c[xsg.CTR_MATCHES]) == want_b, how
+        assert gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist() == oracle.rx_byte_offsets(b, prog, False).tolist()

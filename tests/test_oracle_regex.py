@@ -225,3 +225,43 @@ def test_parsers_and_walk_against_cpython_re(oracle):
             assert oracle.regex_count(hay, cs, True) == len(per_line)
         done += 1
     assert done > 450
+
+
+def test_the_whole_match_is_group_one_of_the_wrapped_expression(oracle):
+    """The reference's walk is RE2::PartialMatch(input, pattern, &match) (search_wrappers.h:71): `match` receives
+    capture group ONE, and its own tests hand over an expression that is one group -- re2::RE2("(a[n|m]t)")
+    (search_wrappersTest.cpp:78).  XSG_FLAG_REGEX(expr) is defined as that call with "(" + expr + ")": the reported
+    offset and the resume point are those of the WHOLE match, and groups inside `expr` group only.  Pinned here
+    against an independent engine: CPython's `re` on the wrapped expression, group 1, under the same walk."""
+    from xs_oracle import RegexProgram
+    text = (b"Sherlock and Sherwood locked the lock, locks and colours; the ant, the amt, ants\n"
+            b"Sherwoodlock Sherlocks relocked unlock lockeds\nan amt and an ant\n") * 3
+    for expr in (b"Sher(lock|wood)", b"lock(ed|s)?", b"(a[n|m]t)", b"((a[n|m]t))", b"(Sher)(lock|wood)s?", b"col(ou?)r(s)?"):
+        wrapped = re.compile(b"(" + expr + b")", re.DOTALL)
+        for skip in (False, True):
+            want, pos = [], 0
+            while True:
+                m = wrapped.search(text, pos)
+                if m is None:
+                    break
+                want.append(m.start(1))          # :72 shift = match.data() - input.data()
+                pos = m.end(1)                   # :74 shift += match.size()
+                if skip:
+                    nl = text.find(b"\n", pos)
+                    if nl < 0:
+                        break
+                    pos = nl + 1
+            try:
+                got = oracle.regex_byte_offsets_match(text, compile_class_sequence(expr)) if not skip else None
+            except UnsupportedRegex:
+                got = None
+            prog_got = oracle.rx_byte_offsets(text, RegexProgram(expr), skip)
+            assert prog_got.tolist() == want, (expr, skip)
+            if got is not None:
+                assert got.tolist() == want, (expr, "class sequence")
+    # ... and NOT the reference's answer for an unwrapped expression with an inner group: there group 1 is the inner
+    # group, e.g. `Sher(lock|wood)` reports where `lock` / `wood` starts.  Callers wrap (as the reference's tests do).
+    inner = re.compile(b"Sher(lock|wood)")
+    m = inner.search(text)
+    assert m.start(1) == m.start() + 4
+    assert oracle.rx_byte_offsets(text, RegexProgram(b"Sher(lock|wood)"), False)[0] == m.start()

@@ -21,6 +21,12 @@ LEXICON = [
 ]
 
 
+# The same lexicon without the four decoys that are pieces of the bench needle (`She`, `locked`, `Sher`, `lock`): text
+# in which `She[r ]lock` and friends occur only where the needle was planted.  Separates what a kernel costs from
+# what this corpus makes it do.
+LEXICON_PLAIN = [w for w in LEXICON if w not in (b"She", b"locked", b"Sher", b"lock")]
+
+
 def _mix(seed: int, index: int) -> int:
     # splitmix64 of (seed, index) -> independent stream per block
     z = (seed + 0x9E3779B97F4A7C15 * (index + 1)) & 0xFFFFFFFFFFFFFFFF
@@ -30,7 +36,7 @@ def _mix(seed: int, index: int) -> int:
 
 
 def text_block(seed: int, index: int, nbytes: int, needle: bytes = b"Sherlock", needle_rate: float = 4.6e-7 * 6.0,
-               words_per_line: float = 6.0) -> np.ndarray:
+               words_per_line: float = 6.0, lexicon=None) -> np.ndarray:
     """One '\\n'-terminated block of EXACTLY `nbytes` bytes (uint8 array).
 
     needle_rate is the probability that a word is replaced by the needle
@@ -38,13 +44,14 @@ def text_block(seed: int, index: int, nbytes: int, needle: bytes = b"Sherlock", 
     """
     assert nbytes >= 2
     rng = np.random.Generator(np.random.PCG64(_mix(seed, index)))
-    lex = [np.frombuffer(w, dtype=np.uint8) for w in LEXICON] + [np.frombuffer(needle, dtype=np.uint8)]
+    words = LEXICON if lexicon is None else lexicon
+    lex = [np.frombuffer(w, dtype=np.uint8) for w in words] + [np.frombuffer(needle, dtype=np.uint8)]
     lens = np.array([len(w) for w in lex], dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
     flat = np.concatenate(lex)
     mean = float(lens[:-1].mean()) + 1.0
     nwords = int(nbytes / mean * 1.15) + 16
-    ids = rng.integers(0, len(LEXICON), size=nwords)
+    ids = rng.integers(0, len(words), size=nwords)
     plant = rng.random(nwords) < needle_rate
     ids[plant] = len(lex) - 1
     seps = np.where(rng.random(nwords) < 1.0 / words_per_line, 10, 32).astype(np.uint8)

@@ -544,6 +544,17 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
 // ---------------------------------------------------------------------------
 // shards
 // ---------------------------------------------------------------------------
+// whatever was derived from the bytes of a binding is void once they change (re-bind, xsg_shard_invalidate)
+static void forget_derived(xsg_shard* s) {
+  s->nl_cached = s->nl_off_cached = false;  // newline counts per tile and their prefix
+  s->hot_serial = 0;                         // measured hot filter / filter window of a pattern
+  s->koff_chosen = false;
+  s->pre_dense_serial = 0;                   // regex prefilter: candidates found dense
+  s->mask_serial = s->mask_dense_serial = 0; // regex factor prefilter: tile marks
+  s->fast_dense_serial = 0;                  // a pattern whose lists did not fit the one-sync route
+  s->fast_result = false;
+}
+
 static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const xsg_chunk* chunks, uint64_t nchunks) {
   xsg_ctx* c = s->ctx;
   if (nchunks && !chunks) return fail(XSG_EINVAL, "chunks is null");
@@ -582,13 +593,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   s->last_mode = -1;
   s->total = 0;
 
-  // whatever was derived from the old binding's bytes is void
-  s->nl_cached = s->nl_off_cached = false;
-  s->hot_serial = 0;
-  s->pre_dense_serial = 0;
-  s->mask_serial = s->mask_dense_serial = 0;
-  s->fast_dense_serial = 0;
-  s->fast_result = false;
+  forget_derived(s);
   bool grew = false;
   XSG_TRY(s->d_chunks.ensure(sizeof(ChunkDev) * std::max<uint64_t>(nchunks, 1)));
   XSG_TRY(s->d_chunk_tile0.ensure(8 * (nchunks + 1)));
@@ -630,6 +635,14 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
   if (ntiles) HIP_TRY(hipMemcpyAsync(s->d_tile_chunk.p, map.data(), 4 * ntiles, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // `map` is a local
   s->table_pending = false;
+  return XSG_OK;
+}
+
+extern "C" int xsg_shard_invalidate(xsg_shard* s) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  forget_derived(s);
+  s->last_mode = -1;
+  s->total = 0;
   return XSG_OK;
 }
 
@@ -1304,6 +1317,9 @@ static int run_list_fast(xsg_shard* s, uint32_t mode) {
   XSG_TRY(s->d_tile_off.ensure(8 * (ntiles + 1)));
   XSG_TRY(s->d_scan2.ensure(8 * scan2_tmp_elems(std::max<uint64_t>(ntiles, fcap) + 1)));
   XSG_TRY(s->d_hit.ensure(4 * cap));
+  grew = false;
+  XSG_TRY(s->d_wmask.ensure(4 * (ntiles / 4 + 1), &grew));
+  if (grew) HIP_TRY(hipMemsetAsync(s->d_wmask.p, 0, s->d_wmask.cap, st));
   XSG_TRY(s->d_m_pos.ensure(8 * cap));
   XSG_TRY(s->d_m_chunk.ensure(4 * cap));
   if (line_mode) {
@@ -1350,6 +1366,7 @@ static int run_list_fast(xsg_shard* s, uint32_t mode) {
   XSG_TRY(choose_hot_filter(s, st));
   XSG_TRY(prepare_tiles(s, false, st));
   ScanArgs a = scan_args(s);
+  a.tile_wmask = s->d_wmask.as<uint32_t>();  // the count pass marks the waves that found something, the emit pass reads only those
   s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them
   const bool scan_nl = want_nl && !s->nl_cached;
   HIP_TRY(launch_scan_count(a, scan_nl, false, st));
@@ -1426,8 +1443,14 @@ static int run_list_fast(xsg_shard* s, uint32_t mode) {
   l.f_match = s->d_f_match.as<uint64_t>();
   l.f_chunk = s->d_f_chunk.as<uint32_t>();
   l.want_f = want_f ? 1u : 0u;
-  l.out_u64 = want_f ? nullptr : s->d_out_u64.as<uint64_t>();
-  l.out_host = want_f ? nullptr : static_cast<uint64_t*>(s->h_result);
+  // the global offsets of the final entries leave with k_list_out for every tag but xs::line_indices (whose values
+  // are indices); xs::lines also gets its line lengths there
+  l.out_u64 = mode == XSG_LINE_INDICES ? nullptr : s->d_out_u64.as<uint64_t>();
+  l.out_host = mode == XSG_LINE_INDICES ? nullptr : static_cast<uint64_t*>(s->h_result);
+  if (mode == XSG_LINES) {
+    l.line_len = s->d_line_len.as<uint64_t>();
+    l.line_len_host = s->hp_line_len;
+  }
   if (line_mode) {
     HIP_TRY(launch_line_starts_keep(l, st));
     Scan2Args k{};
@@ -1468,8 +1491,7 @@ static int run_list_fast(xsg_shard* s, uint32_t mode) {
       o.line_bytes = s->d_line_bytes.as<uint8_t>();
       o.line_bytes_host = s->hp_line_bytes;
       o.line_bytes_cap = bytes_cap;
-      HIP_TRY(launch_line_lengths(o, st));
-      Scan2Args b{};
+      Scan2Args b{};  // (the lengths came with k_list_out)
       b.in = o.line_len;
       b.out = s->d_line_off.as<uint64_t>();
       b.n_cap = fcap;
@@ -1682,7 +1704,36 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   if (line_mode) {
     HIP_TRY(launch_line_starts_keep(l, st));
   } else if (c->bordered) {
+    // chain heads walk their chains (a few entries at text densities); a chain over the budget -- a long run of one
+    // byte searched for `aa` is ONE chain per chunk -- raises a flag and is finished by pointer jumping, log2(length)
+    // parallel rounds (xsg_list_kernels.hip: k_greedy_links / k_greedy_jump)
+    uint32_t* words = reinterpret_cast<uint32_t*>(s->d_finish.as<uint64_t>() + 3 * (size_t)kFinishBlocks) + 2;  // behind ticket and scan flags
+    const bool can_jump = M < 0xffffffffull;
+    if (M) HIP_TRY(hipMemsetAsync(l.keep, 0, 4 * M, st));
+    HIP_TRY(hipMemsetAsync(words, 0, 8, st));
+    l.long_flag = can_jump ? words : nullptr;
     HIP_TRY(launch_greedy_keep(l, st));
+    uint32_t is_long = 0;
+    if (can_jump) {
+      HIP_TRY(hipMemcpyAsync(&is_long, words, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (is_long) {
+      XSG_TRY(s->d_c_pos.ensure(4 * M));  // the link arrays borrow the prefilter route's candidate buffers (unused by literals)
+      XSG_TRY(s->d_c_pre.ensure(4 * M));
+      uint32_t* J = s->d_c_pos.as<uint32_t>();
+      uint32_t* J2 = s->d_c_pre.as<uint32_t>();
+      HIP_TRY(launch_greedy_links(l, J, st));
+      for (int round = 0; round < 40; ++round) {  // 2^40 entries would not fit the index type anyway
+        uint32_t changed = 0;
+        HIP_TRY(hipMemsetAsync(words + 1, 0, 4, st));
+        HIP_TRY(launch_greedy_jump(l, J, J2, words + 1, st));
+        HIP_TRY(hipMemcpyAsync(&changed, words + 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!changed) break;
+        std::swap(J, J2);
+      }
+    }
   } else {
     HIP_TRY(launch_keep_all(l, st));
   }

@@ -108,6 +108,10 @@ struct ScanArgs {
   const uint32_t* hit_tiles;
   const uint64_t* n_hits_dev;
   uint64_t hit_cap;
+  // one byte per tile (four tiles a word): bit w = wave w of the tile found something.  Set by a count pass that is
+  // followed by an emit pass over the hit list (null otherwise), read and cleared by that emit pass; a stale bit is
+  // harmless (the wave reads its 4 KiB and finds nothing), so the array is only ever zeroed when it is (re)allocated
+  uint32_t* tile_wmask;
 };
 
 constexpr int kFinishBlocks = 2048;  // upper bound of k_count_finish's grid (size of FinishArgs::partials / 3)
@@ -253,11 +257,17 @@ struct ListArgs {
   uint64_t* out_u64;         // k_list_out: global offset of every final entry (match / line-start tags) ...
   uint64_t* out_host;        // ... and its pinned mirror (may be null)
   uint32_t want_f;           // k_list_out: also write f_pos / f_match / f_chunk (line indices, lines)
+  uint32_t* long_flag;       // k_greedy_keep: if set, a chain over its budget is left unfinished and this word raised
+  uint64_t* line_len;        // k_list_out, xs::lines: length of every final entry's line (UINT64_MAX: unterminated -> dropped) ...
+  uint64_t* line_len_host;   // ... and its pinned mirror
 };
 
 // mask[tile of the line start] = 1 for every kept entry of a candidate list (ListArgs after launch_line_starts_keep)
 hipError_t launch_rx_mark_tiles(const ListArgs& a, uint32_t* mask, hipStream_t s);
 hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s);
+// long chains: J[i] = nxt(i) (uint32 index or 0xffffffff), then rounds of "mark J(marked), square J" until *changed stays 0
+hipError_t launch_greedy_links(const ListArgs& a, uint32_t* J, hipStream_t s);
+hipError_t launch_greedy_jump(const ListArgs& a, const uint32_t* J, uint32_t* J2, uint32_t* changed, hipStream_t s);
 hipError_t launch_line_starts_keep(const ListArgs& a, hipStream_t s);
 hipError_t launch_keep_all(const ListArgs& a, hipStream_t s);
 hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s);

@@ -21,6 +21,7 @@
 // Everything else (exact verification, popcounts, ordered compaction, line
 // summaries) lives in a wave-uniform slow path.
 #include <algorithm>
+#include <cstdlib>
 
 #include "xsg_devutil.h"
 #include "xsg_linesum.h"
@@ -471,7 +472,9 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   __shared__ __attribute__((aligned(16))) uint8_t s_view[is_cls(KIND) ? kBlock * 48 : 16];  // match_mask16<kClass>
 
   if (tile >= A.ntiles) return;
-  if (EMIT && A.tile_cnt[tile] == 0) return;
+  // (a tile from the hit list holds a match by construction: no look at its count -- the emit pass over a sparse list
+  // is a chain of dependent memory round trips per tile, 2048 tiles resident at a time, and this was one of them)
+  if (EMIT && !A.hit_tiles && A.tile_cnt[tile] == 0) return;
 
   const PatternDev P = A.pat;
   const uint32_t tid = threadIdx.x;
@@ -510,9 +513,23 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   const uint64_t last_unit = Lr - kUnit;  // L >= 1 here: a chunk of length 0 has no tiles
   uint4 v[kLoads];
   uint4 edge;
+  // Emit pass with wave marks (the one-sync list route): the count pass left one bit per wave that found something,
+  // and a wave without its bit has nothing to emit -- it reads nothing (a sparse list re-reads 4 KiB per match
+  // instead of the tile's 16: the emit pass over 7 000 tiles of a 10 GiB shard is a 118 MB random read otherwise) and
+  // contributes 0 to the ranks.  A stale bit of an older pass only costs its 4 KiB.
+  bool wave_on = true;
+  uint32_t wm_word = 0;
+  if (EMIT && A.tile_wmask) {
+    wm_word = A.tile_wmask[tile >> 2];
+    wave_on = ((wm_word >> (((uint32_t)tile & 3u) * 8u + wave)) & 1u) != 0;
+  }
   // non-temporal: every byte is read once, so keeping it out of L2/MALL allocation
   // is worth +8 % on this stream (7.1 vs 6.55 TB/s, scripts/read_variants.py)
-  if (wbase + kWaveSpan + kUnit <= Lr) {  // wave-uniform: span and edge inside the chunk -> no clamping
+  if (EMIT && !wave_on) {
+#pragma unroll
+    for (int j = 0; j < kLoads; ++j) v[j] = make_uint4(0u, 0u, 0u, 0u);
+    edge = make_uint4(0u, 0u, 0u, 0u);
+  } else if (wbase + kWaveSpan + kUnit <= Lr) {  // wave-uniform: span and edge inside the chunk -> no clamping
     const uint8_t* p0 = cbase + wbase + (uint64_t)lane * kUnit;
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
@@ -550,7 +567,9 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   // (The emit pass has only the careful body: it visits few tiles, and what it costs there is the FETCH of its code --
   // 23 KB with both bodies -- by every compute unit that gets a workgroup, not the end-of-chunk checks.)
   WaveState st;
-  if (!EMIT && wbase + kWaveSpan <= L) {
+  if (EMIT && !wave_on) {
+    // nothing to decide
+  } else if (!EMIT && wbase + kWaveSpan <= L) {
 #pragma unroll
     for (int j = 0; j < kLoads; ++j) {
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
@@ -600,6 +619,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
         // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
         // cut dense patterns to a third)
         atomicAdd(A.tile_cnt + tile, wc);
+        if (A.tile_wmask) atomicOr(A.tile_wmask + (tile >> 2), 1u << (((uint32_t)tile & 3u) * 8u + wave));  // for the emit pass
         // end of the last match relative to the tile start (1 .. tile + plen < 2^16), tagged with this pass's
         // epoch: a word of an older pass loses the max, so the array is never reset
         atomicMax(A.tile_last + tile, (A.epoch << 16) | rel);
@@ -620,6 +640,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
     const uint32_t wc = wave_sum_u32(cnt);
     if (lane == 0) s_cnt[wave] = wc;
     __syncthreads();
+    if (A.tile_wmask && tid == 0 && ((wm_word >> (((uint32_t)tile & 3u) * 8u)) & 0xffu) != 0)
+      atomicAnd(A.tile_wmask + (tile >> 2), ~(0xffu << (((uint32_t)tile & 3u) * 8u)));  // at rest for the next pass
     uint64_t rank = A.tile_off[tile];
     for (uint32_t w = 0; w < wave; ++w) rank += s_cnt[w];
 #pragma unroll
@@ -746,7 +768,8 @@ static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_line
   if (a_in.ntiles == 0) return hipSuccess;
   ScanArgs a = a_in;
   a.tune = pick_stagger(a_in, want_nl, want_lines, emit);
-  const dim3 grid = (emit && a.hit_tiles) ? dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(a.hit_cap, 1), 16384), 1, 1)
+  static const uint64_t emit_grid = [] { const char* e = getenv("XSG_EMIT_GRID"); return e && atoll(e) > 0 ? (uint64_t)atoll(e) : 16384ull; }();
+  const dim3 grid = (emit && a.hit_tiles) ? dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(a.hit_cap, 1), emit_grid), 1, 1)
                                          : tile_grid(a.ntiles);
   switch (a.pat.kind) {
     case kMask1: return launch_scan_loads<kMask1>(a, want_nl, want_lines, emit, grid, s);

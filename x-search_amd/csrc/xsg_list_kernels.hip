@@ -292,6 +292,9 @@ __global__ void k_keep_all(const ListArgs A) {
   if (i < list_count(A)) A.keep[i] = 1u;
 }
 
+constexpr uint64_t kChainBudget = 4096;  // entries one thread walks before the chain is handed to the parallel passes
+constexpr uint32_t kNoLink = 0xffffffffu;
+
 // Greedy non-overlap (shift = match + plen, simd_search.cpp:333 /
 // search_wrappers.h:42): only patterns with a border can overlap themselves.
 // An occurrence >= plen after its predecessor is always kept and starts a
@@ -309,7 +312,14 @@ __global__ void k_greedy_keep(const ListArgs A) {
   // The walk is a chain of dependent decisions, but not of dependent LOADS: eight entries are fetched at a time
   // (independent loads, one latency) and decided from registers -- a long chain (a run of one byte searched for
   // `aa` is one chain per chunk) moves at ~6 ns per occurrence instead of ~50.
+  // With A.long_flag set the thread gives up after kChainBudget entries and raises the flag: what it has marked
+  // stands (every mark is a reported occurrence), the rest of the chain is resolved by pointer jumping
+  // (k_greedy_links / k_greedy_jump) -- a multi-megabyte run of one byte is ONE chain and would be one lane's work.
   for (uint64_t j = i + 1; j < M;) {
+    if (A.long_flag && j - i > kChainBudget) {
+      *A.long_flag = 1u;
+      break;
+    }
     uint64_t p[8];
     uint32_t ch[8];
 #pragma unroll
@@ -334,6 +344,57 @@ __global__ void k_greedy_keep(const ListArgs A) {
     if (done) break;
     j += 8;
   }
+}
+
+// ---- long chains, in parallel ------------------------------------------------------------------------------
+// nxt(i) = the first occurrence of i's chunk that starts at or behind the END of occurrence i: if i is reported, nxt(i)
+// is the next one reported (shift = match + plen).  The reported set is the closure of the chain heads under nxt.
+// Pointer jumping: J = nxt; every round marks J(i) for every marked i and squares J (J2 = J o J), so after round k the
+// closure holds nxt^m(head) for all m < 2^(k+1): log2(chain length) rounds of two coalesced passes each instead of
+// one lane walking the chain.  A mark is only ever set on an element of the closure (a marked element's image under
+// any power of nxt is reported too), so marks of an unfinished sequential walk, of earlier rounds and of this round
+// mix freely, and a round that marks nothing new means the closure is complete.
+__global__ void k_greedy_links(const ListArgs A, uint32_t* J) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t M = list_count(A);
+  if (i >= M) return;
+  const uint32_t plen = A.pat.plen;
+  const uint32_t c = A.m_chunk[i];
+  const uint64_t want = A.m_pos[i] + plen;
+  // occurrences are distinct offsets, so nxt(i) <= i + plen: lower bound in (i, i + plen] of "another chunk, or far enough"
+  uint64_t lo = i + 1, hi = i + 1 + plen < M ? i + 1 + plen : M;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    const bool f = A.m_chunk[mid] != c || A.m_pos[mid] >= want;
+    if (f) hi = mid; else lo = mid + 1;
+  }
+  J[i] = (lo < M && A.m_chunk[lo] == c) ? (uint32_t)lo : kNoLink;
+}
+
+__global__ void k_greedy_jump(const ListArgs A, const uint32_t* J, uint32_t* J2, uint32_t* changed) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= list_count(A)) return;
+  const uint32_t j = J[i];
+  uint32_t jj = kNoLink;
+  if (j != kNoLink) {
+    if (A.keep[i] && !A.keep[j]) {
+      A.keep[j] = 1u;
+      *changed = 1u;
+    }
+    jj = J[j];
+  }
+  J2[i] = jj;
+}
+
+hipError_t launch_greedy_links(const ListArgs& a, uint32_t* J, hipStream_t s) {
+  if (!a.M) return hipSuccess;
+  hipLaunchKernelGGL(k_greedy_links, grid_for(a.M), dim3(kBlock), 0, s, a, J);
+  return hipGetLastError();
+}
+hipError_t launch_greedy_jump(const ListArgs& a, const uint32_t* J, uint32_t* J2, uint32_t* changed, hipStream_t s) {
+  if (!a.M) return hipSuccess;
+  hipLaunchKernelGGL(k_greedy_jump, grid_for(a.M), dim3(kBlock), 0, s, a, J, J2, changed);
+  return hipGetLastError();
 }
 
 // Which raw matches survive the skip_to_nl walk, and their line starts
@@ -511,22 +572,37 @@ __global__ __launch_bounds__(kBlock) void k_list_out(const ListArgs A) {
   const uint64_t fin = A.tot_dev[kTotFinal];
   if (fin > A.f_cap) return;  // refused: the host repeats the search on the exact route
   const bool lm = A.line_mode != 0;
+  const uint32_t lane = threadIdx.x & 63u;
   const uint64_t n = M > A.nchunks ? M : A.nchunks;
   for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); i0 < n; i0 += (uint64_t)gridDim.x * kBlock) {
-    const uint64_t i = i0 + (threadIdx.x & 63u);
-    if (i < M && (A.keep_all || A.keep[i])) {
-      const uint32_t c = A.m_chunk[i];
-      const uint64_t dst = (A.keep_all ? i : A.keep_pre[i]) + A.tail_pre[c];
-      const uint64_t pos = lm ? A.m_ls[i] : A.m_pos[i];
-      if (A.want_f) {
-        A.f_pos[dst] = pos;
-        A.f_match[dst] = A.m_pos[i];
-        A.f_chunk[dst] = c;
-      }
-      if (A.out_u64) {
-        const uint64_t g = A.chunks[c].global_offset + pos;
-        A.out_u64[dst] = g;
-        if (A.out_host) A.out_host[dst] = g;
+    const uint64_t i = i0 + lane;
+    {
+      const bool kept = i < M && (A.keep_all || A.keep[i]);
+      const uint32_t c = kept ? A.m_chunk[i] : 0u;
+      const uint64_t mpos = kept ? A.m_pos[i] : 0;
+      const ChunkDev ch = A.chunks[c];
+      // xs::lines: the line's length right here (k_line_lengths' work: [line start, next '\n' behind the match)) --
+      // one launch and one chain of memory latencies less; the wave shares long scans, so no lane leaves early
+      int64_t e = -1;
+      if (A.line_len) e = newline_query<true>(kept, A.base + ch.offset, mpos + A.pat.plen, ch.length, lane);
+      if (kept) {
+        const uint64_t dst = (A.keep_all ? i : A.keep_pre[i]) + A.tail_pre[c];
+        const uint64_t pos = lm ? A.m_ls[i] : mpos;
+        if (A.want_f) {
+          A.f_pos[dst] = pos;
+          A.f_match[dst] = mpos;
+          A.f_chunk[dst] = c;
+        }
+        if (A.out_u64) {
+          const uint64_t g = ch.global_offset + pos;
+          A.out_u64[dst] = g;
+          if (A.out_host) A.out_host[dst] = g;
+        }
+        if (A.line_len) {
+          const uint64_t len = e < 0 ? UINT64_MAX : (uint64_t)e - pos;  // UINT64_MAX: no terminating newline -> dropped
+          A.line_len[dst] = len;
+          if (A.line_len_host) A.line_len_host[dst] = len;
+        }
       }
     }
     // the tail walk's matches of chunk i; their line starts may lie a whole huge line back, so the loop runs
@@ -549,7 +625,9 @@ __global__ __launch_bounds__(kBlock) void k_list_out(const ListArgs A) {
       for (uint32_t k = 0; k < nmax; ++k) {
         const bool live = k < nt && k < A.tail_cap;
         const uint64_t m = live ? A.tail_pos[c * A.tail_cap + k] : 0;
-        const int64_t nl = newline_query<false>(live && lm, d, 0, m, threadIdx.x & 63u);
+        const int64_t nl = newline_query<false>(live && lm, d, 0, m, lane);
+        int64_t e = -1;
+        if (A.line_len) e = newline_query<true>(live, d, m + A.pat.plen, ch.length, lane);
         if (live) {
           const uint64_t pos = !lm ? m : nl < 0 ? 0u : (uint64_t)nl + 1u;
           if (A.want_f) {
@@ -561,6 +639,11 @@ __global__ __launch_bounds__(kBlock) void k_list_out(const ListArgs A) {
             const uint64_t g = ch.global_offset + pos;
             A.out_u64[dst0 + k] = g;
             if (A.out_host) A.out_host[dst0 + k] = g;
+          }
+          if (A.line_len) {
+            const uint64_t len = e < 0 ? UINT64_MAX : (uint64_t)e - pos;
+            A.line_len[dst0 + k] = len;
+            if (A.line_len_host) A.line_len_host[dst0 + k] = len;
           }
         }
       }

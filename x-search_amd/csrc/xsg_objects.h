@@ -152,6 +152,7 @@ struct xsg_shard {
   DevBuf d_tot;                    // FastTot words, then u32 ticket words
   DevBuf d_hit;                    // tiles that hold a match, in order
   DevBuf d_scan2;                  // scratch of the two-launch scans
+  DevBuf d_wmask;                  // ScanArgs::tile_wmask
   uint64_t* h_tot = nullptr;       // pinned mirror of the FastTot words (+ one word for the scan flags)
   uint64_t* hp_line_len = nullptr; // pinned: xs::lines lengths (UINT64_MAX = dropped)
   size_t hp_line_len_cap = 0;      // entries
@@ -177,7 +178,7 @@ struct xsg_shard {
                      &d_counters, &d_finish, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls,
                      &d_keep, &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
                      &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes, &d_c_pos, &d_c_chunk, &d_c_len, &d_c_keep,
-                     &d_c_pre, &d_tile_mask, &d_tot, &d_hit, &d_scan2};
+                     &d_c_pre, &d_tile_mask, &d_tot, &d_hit, &d_scan2, &d_wmask};
     for (DevBuf* b : all) b->release();
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_counters) (void)hipHostFree(h_counters);

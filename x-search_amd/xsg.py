@@ -114,6 +114,7 @@ def load():
         "xsg_regex_dfa_info": (ci, [C.c_char_p, sz, u32, C.POINTER(RegexDfaInfo), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), sz]),
         "xsg_shard_create": (ci, [vp, vp, u64, vp, u64, C.POINTER(vp)]),
         "xsg_shard_rebind": (ci, [vp, vp, u64, vp, u64]),
+        "xsg_shard_invalidate": (ci, [vp]),
         "xsg_shard_destroy": (None, [vp]),
         "xsg_shard_set_line_base": (ci, [vp, u64]),
         "xsg_count_async": (ci, [vp, u32, vp, vp]),
@@ -180,7 +181,7 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
            "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
            "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info", "xsg_regex_dfa_info", "xsg_regex_prefix", "xsg_regex_factor",
-           "xsg_result_u64_view"]
+           "xsg_result_u64_view", "xsg_shard_invalidate"]
 
 
 def _check(rc):
@@ -332,6 +333,10 @@ class Shard:
         chunks = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
         _check(self._lib.xsg_shard_rebind(self.h, C.c_void_p(d_base), capacity, chunks.ctypes.data, len(chunks)))
         self.nchunks = len(chunks)
+
+    def invalidate(self):
+        """the bytes behind the binding were rewritten in place: forget what was derived from them"""
+        _check(self._lib.xsg_shard_invalidate(self.h))
 
     def set_line_base(self, base: int):
         _check(self._lib.xsg_shard_set_line_base(self.h, base))
