@@ -259,6 +259,24 @@ static void class_fields(const xsg::ClassExpr& ex, bool icase, PatternDev* Pout,
   P.exact_tail = 1u;
   P.icase = icase ? 1u : 0u;
   P.nalt = (uint32_t)ex.alts.size();
+  // Up to 8 positions: the filter window is the whole expression and candidates are decided in registers.  A position
+  // needs no look at its set when the hot filter's compare already decides it exactly: one alternative, and the set
+  // is precisely the bytes that agree with `value` under `agree` (a literal; [Ss]; [a-z] is not: 0x60-0x7f pass the
+  // compare) -- and, under the 16 + 32 bit filter, the position is not one of the two that filter leaves out.
+  // With several alternatives only a position that is one byte in all of them is decided (the compare sees the union).
+  {
+    const char* ir = getenv("XSG_CLS_INREG");
+    P.cls_inreg = (plen <= 8 && koff == 0 && !(ir && *ir == '0')) ? 1u : 0u;
+    P.cls_chk = 0;
+    for (size_t k = 0; k < plen && k < 8; ++k) {
+      bool decided = true;
+      for (uint32_t b = 0; b < 256 && decided; ++b)
+        decided = xsg::set_has(seq[k], b) == ((b & agree[k]) == value[k]);
+      if (ex.alts.size() > 1 && agree[k] != 0xff) decided = false;
+      if (P.cls_fast && (k == 2 || k == 3)) decided = false;  // (the aligned trigger's slow path uses the full masks, but one table serves both)
+      if (!decided) P.cls_chk |= 1u << k;
+    }
+  }
   P.ascii_only = ex.ascii_only ? 1u : 0u;
   P.has_newline = 0;
   for (const xsg::ByteSet& st : seq) P.has_newline |= xsg::set_has(st, '\n') ? 1u : 0u;

@@ -61,6 +61,9 @@ struct PatternDev {
                             // exact folded compare and its results stand (no second, properly folded pass over the window)
   uint32_t hot;             // window kinds (kTwo, kLong, kClass): 1 = aligned-dword trigger, 0 = window filter (k_scan<..., ALIGNED>)
   uint32_t cls_fast;        // kClass: m1 is all ones and the low half of m0 too: the window filter compares 16 + 32 exact bits
+  uint32_t cls_inreg;       // kClass, plen <= 8 (koff = 0): candidates are decided in registers (k_scan: cls_verify_at) ...
+  uint32_t cls_chk;         // ... looking up only these positions (bit k) in the sets: the ones the hot filter's compare does
+                            // not already decide exactly
   uint32_t nalt;            // kClass: alternatives (d_pat holds nalt x plen sets, alternative-major); 0/1 otherwise
   uint32_t ascii_only;      // kClass: the expression is exact on ASCII data only ('.', negated classes): k_scan raises
                             // ScanArgs::flags bit 0 when it meets a byte >= 0x80

@@ -224,6 +224,61 @@ __device__ __forceinline__ uint32_t match_mask16(const uint32_t (&d)[8], const P
   return match_mask16_from<KIND, ICASE>(cand_mask16<KIND>(d, P), d, P, cbase, unit_off, limit, lds_pat, lds_view);
 }
 
+// Class sequences of at most 8 positions (the window IS the expression: koff = 0) decide their candidates in
+// registers, position by position of the unit.  `cm` is the lane mask of the candidates at byte b of the unit
+// (wave-uniform: most of the 16 are zero and cost a scalar test); the window's 8 bytes are w[b], w[b + 4] -- STATIC
+// registers, no view in LDS, no per-lane bit loop -- and only the positions the hot filter did not already decide
+// exactly (PatternDev::cls_chk; `She[r ]lock` under the 16 + 32 bit filter: two of eight) are looked up in the
+// 256-bit sets.  Lanes outside `cm` compute along (their lookups stay inside the sets) and are masked at the end.
+// Replaces, for these expressions, the LDS-view verification of match_mask16_from: 250 VALU + 22 LDS instructions
+// per wave-load that entered the slow path became ~40 (profiles/r03_class_ab.txt).
+// window dword at byte B of the lane's view, on demand (B static: one v_alignbyte, no array of windows kept alive)
+template <int B>
+__device__ __forceinline__ uint32_t win_at(const uint32_t (&d)[8]) {
+  constexpr int q = B >> 2, r = B & 3;
+  return r ? __builtin_amdgcn_alignbyte(d[q + 1], d[q], (uint32_t)r) : d[q];
+}
+// does some lane hold a candidate at byte B of its unit?  (behind the aligned trigger, or refolded under ignore_case:
+// the masked window compare itself)
+template <int B>
+__device__ __forceinline__ uint32_t cls_any_at(const uint32_t (&d)[8], const PatternDev& P) {
+  const bool lo = (win_at<B>(d) & P.m0) == P.p0, hi = (win_at<B + 4>(d) & P.m1) == P.p1;
+  return __ballot(lo && hi) != 0 ? 1u << B : 0u;
+}
+// The candidates at the positions of `pm` (bit b: some lane of the wave has a candidate at byte b of its unit), decided
+// in registers.  One loop iteration per such position, b wave-uniform: the 8 bytes at byte b of the lane's 24-byte view
+// are picked with scalar-controlled selects (no array indexed by a register, nothing for the compiler to put in
+// scratch) and aligned with v_alignbyte; a lane is a candidate there iff the masked window compare passes, and only
+// the positions that compare does not decide exactly (PatternDev::cls_chk) are looked up in the 256-bit sets.
+__device__ __forceinline__ uint32_t cls_verify_positions(uint32_t pm, const uint32_t (&d)[8], const PatternDev& P,
+                                                         const uint32_t* sets) {
+  uint32_t m = 0;
+  for (pm = __builtin_amdgcn_readfirstlane(pm); pm; pm &= pm - 1u) {  // scalar loop
+    const uint32_t b = (uint32_t)__builtin_ctz(pm);
+    const uint32_t q = b >> 2, r = b & 3u;
+    const uint32_t x0 = q == 0 ? d[0] : q == 1 ? d[1] : q == 2 ? d[2] : d[3];
+    const uint32_t x1 = q == 0 ? d[1] : q == 1 ? d[2] : q == 2 ? d[3] : d[4];
+    const uint32_t x2 = q == 0 ? d[2] : q == 1 ? d[3] : q == 2 ? d[4] : d[5];
+    const uint32_t wlo = __builtin_amdgcn_alignbyte(x1, x0, r);  // r == 0: x0
+    const uint32_t whi = __builtin_amdgcn_alignbyte(x2, x1, r);
+    const uint32_t cand = ((wlo & P.m0) == P.p0 && (whi & P.m1) == P.p1) ? 1u : 0u;
+    const uint64_t W = ((uint64_t)whi << 32) | wlo;
+    uint32_t any = 0;
+    for (uint32_t a = 0; a < P.nalt; ++a) {  // scalar loop; one alternative must accept every position
+      uint32_t ok = 1u;
+      const uint32_t* sa = sets + a * P.plen * 8u;
+      for (uint32_t chk = P.cls_chk; chk; chk &= chk - 1u) {  // scalar loop over the undecided positions
+        const uint32_t k = (uint32_t)__builtin_ctz(chk);
+        const uint32_t x = (uint32_t)(W >> (8u * k)) & 0xffu;
+        ok &= sa[k * 8u + (x >> 5)] >> (x & 31u);
+      }
+      any |= ok;
+    }
+    m |= (any & cand & 1u) << b;
+  }
+  return m;
+}
+
 // per-wave running state of k_scan
 struct WaveState {
   uint32_t cnt = 0;       // matches found by this lane
@@ -406,6 +461,31 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         d[4] = from_next_lane(f0, fold4(e0r), lane);
         d[5] = from_next_lane(f1, fold4(e1r), lane);
       }
+      if (is_cls(KIND) && P.cls_inreg) {
+        // expressions of up to 8 positions: candidates decided in registers (d is the exact view by now).  Which of
+        // the 16 positions hold a candidate in SOME lane is wave-uniform knowledge: the hot filter's lane masks, or --
+        // behind the aligned trigger / under ignore_case -- the window compare run here.
+        const uint32_t* sets = reinterpret_cast<const uint32_t*>(s_pat);
+        uint32_t pm = 0;
+        if (KIND == kClassFast && kReuse) {
+#pragma unroll
+          for (int b = 0; b < 16; ++b) pm |= cmk[b] != 0 ? 1u << b : 0u;
+        } else if (kReuse) {
+#pragma unroll
+          for (int b = 0; b < 16; ++b) pm |= __ballot(cb[b]) != 0 ? 1u << b : 0u;
+        } else {
+          pm = cls_any_at<0>(d, P) | cls_any_at<1>(d, P) | cls_any_at<2>(d, P) | cls_any_at<3>(d, P) | cls_any_at<4>(d, P) |
+               cls_any_at<5>(d, P) | cls_any_at<6>(d, P) | cls_any_at<7>(d, P) | cls_any_at<8>(d, P) | cls_any_at<9>(d, P) |
+               cls_any_at<10>(d, P) | cls_any_at<11>(d, P) | cls_any_at<12>(d, P) | cls_any_at<13>(d, P) |
+               cls_any_at<14>(d, P) | cls_any_at<15>(d, P);
+        }
+        m = cls_verify_positions(pm, d, P, sets);
+        // positions at or beyond the limit belong to the end-of-chunk walk (koff = 0 here)
+        if (unit_off >= limit)
+          m = 0;
+        else if (unit_off + kUnit > limit)
+          m &= (1u << (uint32_t)(limit - unit_off)) - 1u;
+      } else {
       if (is_cls(KIND)) {
         // class sequences verify their candidates in the lane's view: the rest of the neighbour's unit joins it
         // (raw own bytes go out -- a lane's own view of them may be cleared at the chunk end, the reader's not)
@@ -430,6 +510,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         m = match_mask16_from<KIND, ICASE>(m0, d, P, cbase, unit_off, limit, s_pat, s_view);
       } else {
         m = match_mask16<KIND, ICASE>(d, P, cbase, unit_off, limit, s_pat, s_view);
+      }
       }
     }
   }
