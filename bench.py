@@ -664,15 +664,13 @@ def main():
             tj = json.loads(tfile.read_text())
         except Exception:
             continue
-        # only a record of THIS workload and kernel variant counts (same bytes, same pattern, same instantiation up
-        # to the hot filter -- the last template argument -- which does not change what is read)
-        def variant(name):
-            return str(name).split(" stagger")[0].rsplit(",", 1)[0]
-        if (tj.get("bytes_per_gpu") == shard_bytes and tj.get("pattern", "Sherlock") == args.pattern
-                and variant(tj.get("kernel", "")) == variant(kernel_name)):
-            traffic = tj.get("hbm_bytes_per_launch")
-            traffic_source = f"profiles/{tfile.name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command " \
-                             f"(separate runs; not measured in this run)"
+        # only a record of THIS workload and of the very instantiation timed here counts (profiles/r03_pmc_traffic.json
+        # holds both hot-filter instantiations of the plain count; what xsg_shard_tune picks moves from box to box)
+        rec = tj.get("by_kernel", {}).get(kernel_name.split(" stagger")[0])
+        if rec and tj.get("bytes_per_gpu") == shard_bytes and tj.get("pattern", "Sherlock") == args.pattern:
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/{tfile.name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with " \
+                             f"this instantiation (separate runs; not measured in this run)"
             break
 
     regex = None

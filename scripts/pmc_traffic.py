@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from the two rocprofv3 --pmc passes of scripts/gpu_bench.sh
-(FETCH_SIZE and WRITE_SIZE, collected separately): HBM bytes per k_scan launch, with the
-gfx950 correction of MI355X_MICROARCH.md's HBM section (FETCH_SIZE counts a 128-byte
-request as 64 bytes -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact).
-Usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <BENCH json> [tag]"""
+"""profiles/<tag>_pmc_traffic.json from the rocprofv3 --pmc passes of scripts/gpu_profiles.sh (FETCH_SIZE and WRITE_SIZE,
+collected separately, one pair of passes per kernel instantiation): HBM bytes per k_scan launch, with the gfx950
+correction of MI355X_MICROARCH.md's HBM section (FETCH_SIZE counts a 128-byte request as 64 bytes -> read bytes =
+2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact).
+Usage: pmc_traffic.py <BENCH json> <tag> <fetch csv> <write csv> [<fetch csv> <write csv> ...]"""
 import csv
 import json
 import sys
@@ -29,28 +29,35 @@ def avg_counter(path, counter):
 
 
 def main():
-    fetch_csv, write_csv, bench_json = sys.argv[1:4]
-    tag = sys.argv[4] if len(sys.argv) > 4 else ""
+    bench_json, tag = sys.argv[1:3]
+    pairs = sys.argv[3:]
     bench = json.loads(Path(bench_json).read_text().splitlines()[-1])
     alg = bench["roofline"]["algorithmic_bytes_per_launch"]
-    fetch_kb, nf, names = avg_counter(fetch_csv, "FETCH_SIZE")
-    write_kb, nw, _ = avg_counter(write_csv, "WRITE_SIZE")
-    rd, wr = 2.0 * fetch_kb * 1024.0, write_kb * 1024.0
+    by = {}
+    for fetch_csv, write_csv in zip(pairs[0::2], pairs[1::2]):
+        fetch_kb, nf, names = avg_counter(fetch_csv, "FETCH_SIZE")
+        write_kb, nw, _ = avg_counter(write_csv, "WRITE_SIZE")
+        if len(names) != 1:
+            raise SystemExit(f"{fetch_csv}: full-shard launches of more than one instantiation: {names}")
+        rd, wr = 2.0 * fetch_kb * 1024.0, write_kb * 1024.0
+        key = names[0].replace("void ", "").split("(")[0]  # "xsg::k_scan<3, false, false, false, 4, false, true>"
+        by[key] = {"FETCH_SIZE_KB_avg": fetch_kb, "WRITE_SIZE_KB_avg": write_kb, "launches_averaged": [nf, nw],
+                   "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                   "ratio_traffic_over_algorithmic": (rd + wr) / alg}
     out = {
-        "kernel": bench["roofline"]["kernel"],
-        "kernels_profiled": names,
+        "timed_kernel": bench["roofline"]["kernel"],
         "pattern": bench["config"]["pattern"],
         "config": bench["config"]["workload"],
         "bytes_per_gpu": bench["config"]["bytes_per_gpu"],
-        "FETCH_SIZE_KB_avg": fetch_kb, "WRITE_SIZE_KB_avg": write_kb, "launches_averaged": [nf, nw],
+        "algorithmic_bytes_per_launch": alg,
         "correction": "HBM read bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-B requests as 64 B, "
                       "MI355X_MICROARCH.md HBM section); WRITE_SIZE x 1024 exact",
-        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-        "algorithmic_bytes_per_launch": alg, "ratio_traffic_over_algorithmic": (rd + wr) / alg,
-        "collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (scripts/gpu_profiles.sh {tag})",
+        "by_kernel": by,
+        "collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes per instantiation, pinned with "
+                     f"XSG_HOT / XSG_TUNE at the timed run's stagger (scripts/gpu_profiles.sh {tag}); written by this script, "
+                     f"nothing edited by hand",
     }
-    name = f"{tag}_pmc_traffic.json" if tag else "pmc_traffic.json"
-    (ROOT / "profiles" / name).write_text(json.dumps(out, indent=1) + "\n")
+    (ROOT / "profiles" / f"{tag}_pmc_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
     print(json.dumps(out))
 
 
