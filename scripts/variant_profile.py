@@ -49,14 +49,14 @@ def main():
     ap.add_argument("--gib", type=float, default=20.0)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--tune", action="store_true")
-    ap.add_argument("--lexicon", choices=["bench", "plain"], default="bench",
+    ap.add_argument("--lexicon", choices=["bench", "plain", "nosh"], default="bench",
                     help="plain: the bench lexicon without the words that are pieces of the needle (She, lock, locked, Sher)")
     a = ap.parse_args()
     import torch
     import corpus
     import xsg
     args = argparse.Namespace(chunk_mib=16, templates=32, seed=0x5EED,
-                              lexicon=corpus.LEXICON_PLAIN if a.lexicon == "plain" else None)
+                              lexicon={"plain": corpus.LEXICON_PLAIN, "nosh": corpus.LEXICON_NOSH}.get(a.lexicon))
     blocks = bench.template_blocks(args, b"Sherlock")
     tbytes = np.array([b.size for b in blocks], dtype=np.int64)
     nchunks = int(round(a.gib * 2**30 / (16 << 20)))

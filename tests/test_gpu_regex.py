@@ -463,3 +463,42 @@ def test_rewritten_bytes_need_a_rebind_or_invalidate(gs, oracle, monkeypatch):
         torch.cuda.synchronize()
         assert int(c[xsg.CTR_MATCHES]) == want_b, how
         assert gs.shard.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist() == oracle.rx_byte_offsets(b, prog, False).tolist()
+
+
+def test_tiles_without_a_trigger_byte(gs, oracle):
+    """k_rx_scan leaves a tile that holds none of the expression's (few) trigger bytes without staging it; the one
+    line that starts in such a tile and runs on behind it is followed from the tile's end.  Text without capital
+    S / H, needles planted so that matches begin just before, at and just behind tile borders (16 KiB), in lines that
+    cross one or several tiles, at the very end of a chunk without a final newline -- all tags, both count routes."""
+    import torch
+    rng = np.random.default_rng(77)
+    words = [w for w in corpus.LEXICON_NOSH]
+    def text(n, nl_every):
+        out = bytearray()
+        while len(out) < n:
+            out += words[int(rng.integers(0, len(words)))]
+            out += b"\n" if int(rng.integers(0, nl_every)) == 0 else b" "
+        return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
+    T = 16384
+    b0 = text(5 * T + 1000, 6)
+    for pos, w in ((T - 3, b"Sherlock"), (2 * T, b"Holmes"), (3 * T + 1, b"Sherlock Holmes"), (4 * T - 8, b"Sherlock"), (4 * T + 600, b"Holmes")):
+        b0[pos:pos + len(w)] = np.frombuffer(w, dtype=np.uint8)
+    b1 = text(4 * T, 4000)                         # lines of tens of KB: a line start is followed over several tiles
+    b1[100] = 10
+    for pos, w in ((T + 5000, b"Sherlock"), (3 * T - 2, b"Holmes"), (3 * T + 9000, b"Sher and then mes")):
+        b1[pos:pos + len(w)] = np.frombuffer(w, dtype=np.uint8)
+    b2 = text(2 * T + 77, 6)
+    b2[-8:] = np.frombuffer(b"Sherlock", dtype=np.uint8)  # the chunk ends in a match, no final newline
+    b3 = text(3 * T, 6)                            # no needle at all
+    blocks = [b0, b1, b2, b3]
+    gs.bind(blocks)
+    c = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    for expr, icase in ((b"Sherlock|Holmes", False), (b"Sher.*mes", False), (b"Holmes?", False), (b"sherlock|holmes", True), (b"Sherlocks?( Holmes)?", False)):
+        assert xsg.regex_dfa(expr, xsg.FLAG_IGNORE_CASE if icase else 0)[0].ncls > 0
+        res = check(gs, oracle, blocks, expr, icase, "no-trigger tiles")
+        assert res["count_matches"] >= 3
+        for mode, key in ((xsg.COUNT_MATCHES, "count_matches"), (xsg.COUNT_LINES, "count_lines")):
+            gs.shard.count_async(mode | xsg.WITH_NEWLINES, 0, c.data_ptr())  # k_rx_scan itself, newline counts included
+            torch.cuda.synchronize()
+            assert int(c[xsg.CTR_MATCHES if mode == xsg.COUNT_MATCHES else xsg.CTR_LINES]) == res[key], (expr, key)
+            assert int(c[xsg.CTR_NEWLINES]) == res["newlines"], expr

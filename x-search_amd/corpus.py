@@ -27,6 +27,11 @@ LEXICON = [
 LEXICON_PLAIN = [w for w in LEXICON if w not in (b"She", b"locked", b"Sher", b"lock")]
 
 
+# ... and without any word that begins with a capital S or H (`She`, `Sher`, `Holmes`): the trigger bytes of
+# `Sherlock|Holmes` / `Sher.*mes` then occur only where the needle was planted
+LEXICON_NOSH = [w for w in LEXICON if w[:1] not in (b"S", b"H")]
+
+
 def _mix(seed: int, index: int) -> int:
     # splitmix64 of (seed, index) -> independent stream per block
     z = (seed + 0x9E3779B97F4A7C15 * (index + 1)) & 0xFFFFFFFFFFFFFFFF

@@ -344,6 +344,22 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   P.rx_rev_start = dfa.rev_start * dfa.ncls;
   P.rx_rev_acc = dfa.rev_first_acc * dfa.ncls;
   P.rx_skip = skip ? 1u : 0u;
+  // few trigger byte values (`Sherlock|Holmes`: S, H; `Sher.*mes`: S; closed under case: up to four): k_rx_scan looks for
+  // them with byte-parallel compares on its loads and does not stage a tile that holds none (XSG_RX_TRIG=0 switches it off)
+  if (skip) {
+    const char* te = getenv("XSG_RX_TRIG");
+    uint32_t n = 0, packed = 0;
+    for (uint32_t b = 0; b < 256; ++b)
+      if (b != '\n' && (blob[b] & 0x80u)) {
+        if (n < 4) packed |= b << (8 * n);
+        ++n;
+      }
+    if (n >= 1 && n <= 4 && !(te && *te == '0')) {
+      for (uint32_t k = n; k < 4; ++k) packed |= (packed & 0xffu) << (8 * k);  // unused slots repeat the first value
+      P.rx_ntrig = n;
+      P.rx_trig4 = packed;
+    }
+  }
   P.rx_anc_n = (uint32_t)dfa.anc.size();
   P.rx_anc_start = dfa.anc_start * dfa.ncls;
   P.rx_anc_acc = dfa.anc_first_acc * dfa.ncls;

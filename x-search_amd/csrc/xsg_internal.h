@@ -74,6 +74,8 @@ struct PatternDev {
   uint32_t rx_rev_start, rx_rev_acc;
   uint32_t rx_anc_n, rx_anc_start, rx_anc_acc;  // the ANCHORED forward automaton (behind the reverse table in d_pat): k_rx_verify
   uint32_t rx_multiline;           // a set of the expression accepts '\n': the chunk, not the line, is the unit (k_rx_chunk)
+  uint32_t rx_ntrig, rx_trig4;     // rx_skip and at most four trigger byte values besides '\n' (packed in rx_trig4): k_rx_scan tests
+                                   // the tile for them on the 16-byte loads and leaves a tile that holds none without staging it
   uint32_t rx_skip;                // bit 7 of every class_of[] entry flags a TRIGGER byte: one that moves the forward automaton
                                    // out of its start state, or '\n' (needs ncls <= 128; XSG_RX_SKIP=0 switches it off)
 };

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kBlock) void k_rx_scan(const ScanArgs A, const uint
   __shared__ uint8_t s_lastnl[kBlock];  // does the lane's segment end in '\n'?  (the next lane's first byte is a line start then)
   __shared__ unsigned long long s_trig[kBlock];
   __shared__ uint32_t s_w[kWaves];
+  __shared__ uint32_t s_tail[16];  // the 64 bytes behind the tile (no-trigger tiles: where the line that runs on ends)
 
   const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
   if (tile >= A.ntiles) return;
@@ -173,36 +174,156 @@ __global__ __launch_bounds__(kBlock) void k_rx_scan(const ScanArgs A, const uint
   const uint64_t Lr = (L + 15u) & ~(uint64_t)15u;
   const uint64_t toff = (tile - A.chunk_tile0[c]) * (uint64_t)kRxTile;
 
-  // ---- stage: class map, forward table, the tile (bytes at or beyond L read as '\n': every line ends in one)
+  // ---- the tile's bytes, in registers first (bytes at or beyond L read as '\n': every line ends in one).  With few
+  // trigger byte values (PatternDev::rx_ntrig: `Sherlock|Holmes` has S and H) the loads are tested for them
+  // byte-parallel, as k_scan tests for a one-byte needle: a tile that holds none cannot begin a match, and it leaves
+  // here -- nothing staged in LDS (not the class map, not the automaton, not the tile), no class translation (64
+  // table reads per lane: 1122 VALU + 132 LDS instructions per 4 KiB before a single line was walked,
+  // profiles/r02_rx_pmc.txt) -- except for the one line that starts in it and runs on behind it (below).
+  const bool quick = P.rx_ntrig != 0 && !EMIT;
+  uint32_t dd[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t off = toff + ((uint64_t)j * kBlock + tid) * kUnit;
+    dd[j][0] = dd[j][1] = dd[j][2] = dd[j][3] = 0x0a0a0a0au;
+    if (off < Lr) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(cbase + off));  // read once: as k_scan
+      dd[j][0] = v.x, dd[j][1] = v.y, dd[j][2] = v.z, dd[j][3] = v.w;
+    }
+  }
+  uint32_t prev_byte = '\n';  // the byte in front of the tile (lane 0; fetched with the tile's loads, not behind the barrier)
+  if (quick && tid == 0 && toff != 0) prev_byte = cbase[toff - 1];
+  if (quick && tid < 4u) {  // four lanes fetch the 64 bytes behind the tile together with the tile's own loads
+    const uint64_t off = toff + kRxTile + (uint64_t)tid * kUnit;
+    uint32_t t[4] = {0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au};  // at or beyond the chunk's end: '\n'
+    if (off < Lr) {
+      const uint4 v = *reinterpret_cast<const uint4*>(cbase + off);
+      t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint64_t o = off + 4u * q;
+        const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+        t[q] = (t[q] & keep) | (0x0a0a0a0au & ~keep);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_tail[tid * 4u + q] = t[q];
+  }
+  uint32_t hi = 0, any_trig = 0, any_nl = 0, nl_cnt = 0;
+  const uint32_t tv0 = (P.rx_trig4 & 0xffu) * 0x01010101u, tv1 = ((P.rx_trig4 >> 8) & 0xffu) * 0x01010101u;
+  const uint32_t tv2 = ((P.rx_trig4 >> 16) & 0xffu) * 0x01010101u, tv3 = (P.rx_trig4 >> 24) * 0x01010101u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t off = toff + ((uint64_t)j * kBlock + tid) * kUnit;
+    if (off < Lr && off + kUnit > L) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint64_t o = off + 4u * q;
+        const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+        dd[j][q] = (dd[j][q] & keep) | (0x0a0a0a0au & ~keep);
+      }
+    }
+    hi |= dd[j][0] | dd[j][1] | dd[j][2] | dd[j][3];
+    if (quick) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // bit 7 of some byte set <=> some byte equals the value (exact as an existence test); unused slots repeat value 0
+        const uint32_t x0 = dd[j][q] ^ tv0, x1 = dd[j][q] ^ tv1;
+        any_trig |= ((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1);
+        if (P.rx_ntrig > 2u) {  // (scalar)
+          const uint32_t x2 = dd[j][q] ^ tv2, x3 = dd[j][q] ^ tv3;
+          any_trig |= ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3);
+        }
+        const uint32_t y = dd[j][q] ^ 0x0a0a0a0au;
+        any_nl |= (y - 0x01010101u) & ~y;
+      }
+    }
+  }
+  if (P.ascii_only && __any((hi & 0x80808080u) != 0) && lane == 0) atomicOr(A.flags, 1u);  // the search must refuse
+  if (quick) {
+    // one barrier: every wave's verdicts (bit 0: a trigger, bit 1: a '\n') through LDS
+    // (bit 2: the tile's last byte is a '\n' -- lane 255 holds it; bit 3: its first byte opens a line -- lane 0)
+    const uint32_t wf = (__ballot((any_trig & 0x80808080u) != 0) != 0 ? 1u : 0u) | (__ballot((any_nl & 0x80808080u) != 0) != 0 ? 2u : 0u) |
+                        (__ballot(tid == (uint32_t)kBlock - 1u && (dd[3][3] >> 24) == 0x0au) != 0 ? 4u : 0u) |
+                        (__ballot(tid == 0u && prev_byte == 0x0au) != 0 ? 8u : 0u);
+    if (lane == 0) s_w[wave] = wf;
+    __syncthreads();
+    const uint32_t tf = s_w[0] | s_w[1] | s_w[2] | s_w[3];
+    if (!(tf & 1u)) {
+      if (want_nl) {  // bytes at or beyond L were replaced by '\n': count inside the chunk only
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t off = toff + ((uint64_t)j * kBlock + tid) * kUnit;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint64_t o = off + 4u * q;
+            const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+            const uint32_t y = (dd[j][q] & keep) ^ (0x0a0a0a0au & keep) ^ ~keep;  // bytes outside the chunk: not a newline
+            nl_cnt += (uint32_t)__popc(~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu));
+          }
+        }
+        const uint32_t wn = rx_wave_sum(nl_cnt);
+        __syncthreads();  // every wave has read the verdicts
+        if (lane == 0) s_w[wave] = wn;
+        __syncthreads();
+        if (tid == 0) A.tile_nl[tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+      }
+      // does a line START in this tile and run on behind it?  It does iff the tile does not end the chunk, its last byte
+      // is no '\n', and it holds a line start: a '\n' somewhere, or its first byte opens the chunk / follows a '\n'.
+      if (tid == 0) {
+        const uint64_t tend = toff + kRxTile;
+        if (tend < L && !(tf & 4u) && (tf & (2u | 8u))) {
+          // Inside the tile the line holds no trigger: the automaton reaches the tile's end in its start state.  Nearly
+          // always the line ends within the next few dozen bytes without a trigger either -- decided on the 64 bytes
+          // fetched with the tile, a few LDS reads; stepping the automaton through global memory byte by byte, one
+          // dependent load each, held the workgroup's slot for ~15 us per tile (2.2 TB/s whatever the text).
+          bool walk = true;
+          for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t x = s_tail[k];
+            const uint32_t y = x ^ 0x0a0a0a0au;
+            const uint32_t nf = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);  // 0x80 in every byte that is '\n' (exact)
+            uint32_t tg = 0;
+            for (uint32_t v = 0; v < P.rx_ntrig; ++v) {
+              const uint32_t z = x ^ (((P.rx_trig4 >> (8u * v)) & 0xffu) * 0x01010101u);
+              tg |= ~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu);
+            }
+            if (nf) {  // the line ends in this dword: a trigger before its '\n'?
+              walk = (tg & ((nf & (0u - nf)) - 1u)) != 0u;
+              break;
+            }
+            if (tg) break;  // a trigger, and the line goes on: walk it
+          }
+          if (walk) {  // rare: the automaton's tables straight from global memory (nothing was staged)
+            RxCtx X;
+            X.tilew = nullptr, X.cls = P.d_pat, X.fwd = reinterpret_cast<const uint16_t*>(P.d_pat + 256);
+            X.trig = nullptr, X.skip = P.rx_skip, X.cmask = 0x7fu;
+            X.rev = nullptr;
+            X.cbase = cbase, X.toff = toff, X.L = L;
+            X.fwd_start = P.rx_fwd_start, X.fwd_acc = P.rx_fwd_acc, X.rev_start = P.rx_rev_start, X.rev_acc = P.rx_rev_acc;
+            uint64_t rank = 0;
+            const uint32_t n = rx_walk_line<false, LINES>(X, tend, A, c, rank);
+            if (n) atomicAdd(A.tile_cnt + tile, n);
+          }
+        }
+      }
+      return;
+    }
+    __syncthreads();  // s_w is reused below
+  }
+  // ---- stage: class map, forward table, the tile
   s_cls[tid] = P.d_pat[tid];
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(P.d_pat + 256);
     uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
     for (uint32_t k = tid; k < (P.rx_fwd_n + 1u) / 2u; k += kBlock) dst[k] = src[k];
   }
-  uint32_t hi = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t p = ((uint32_t)j * kBlock + tid) * kUnit;  // tile-relative
-    const uint64_t off = toff + p;
-    uint32_t d[4] = {0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au};
-    if (off < Lr) {
-      const uint4 v = *reinterpret_cast<const uint4*>(cbase + off);
-      d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-      if (off + kUnit > L) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint64_t o = off + 4u * q;
-          const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
-          d[q] = (d[q] & keep) | (0x0a0a0a0au & ~keep);
-        }
-      }
-    }
-    hi |= d[0] | d[1] | d[2] | d[3];
+    const uint32_t p = ((uint32_t)j * kBlock + tid) * kUnit;
     uint32_t* w = reinterpret_cast<uint32_t*>(s_tile + rx_addr(p));
-    w[0] = d[0], w[1] = d[1], w[2] = d[2], w[3] = d[3];
+    w[0] = dd[j][0], w[1] = dd[j][1], w[2] = dd[j][2], w[3] = dd[j][3];
   }
-  if (P.ascii_only && __any((hi & 0x80808080u) != 0) && lane == 0) atomicOr(A.flags, 1u);  // the search must refuse
   __syncthreads();
 
   // ---- this lane's 64-byte segment: where its lines start (a position < L that follows a '\n' or opens the chunk),
