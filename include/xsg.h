@@ -426,6 +426,9 @@ int xsg_comm_unique_id(void* id, size_t cap);
 int xsg_comm_create_rank(xsg_ctx* ctx, int nranks, int rank, const void* id, xsg_comm** out);
 /* local form (one process, n GPUs): one communicator over the devices of ctxs[0..n), all distinct. */
 int xsg_comm_create_local(xsg_ctx* const* ctxs, int n, xsg_comm** out);
+/* Destroy a communicator BEFORE the contexts it was made from are used for nothing else: the collectives run on the
+ * contexts' streams, so a ctx must outlive every collective still queued on it (destroying the ctx first is tolerated by
+ * xsg_comm_destroy itself -- it keeps the device numbers by value -- but not by a collective in flight). */
 void xsg_comm_destroy(xsg_comm* comm);
 int xsg_comm_size(xsg_comm* comm, int* nranks, int* rank /* -1 in the local form */);
 /* path of the librccl in use ("" if none) */

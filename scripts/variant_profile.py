@@ -24,6 +24,9 @@ CASES = {
     "mask1_e": ("e", 0, "count"),
     "mask1_the": ("the", 0, "count"),
     "lines_e": ("e", 0, "count_lines"),
+    "lines_the": ("the", 0, "count_lines"),
+    "lines_She": ("She", 0, "count_lines"),
+    "icase_lines_the": ("the", "icase", "count_lines"),
     "one_that": ("that", 0, "count"),
     "mask2_Sherl": ("Sherl", 0, "count"),
     "long_Sherlock_Holmes": ("Sherlock Holmes", 0, "count"),

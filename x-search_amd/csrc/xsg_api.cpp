@@ -266,7 +266,6 @@ static void class_fields(const xsg::ClassExpr& ex, bool icase, PatternDev* Pout,
   // With several alternatives only a position that is one byte in all of them is decided (the compare sees the union).
   {
     const char* ir = getenv("XSG_CLS_INREG");
-    P.cls_inreg = (plen <= 8 && koff == 0 && !(ir && *ir == '0')) ? 1u : 0u;
     P.cls_chk = 0;
     for (size_t k = 0; k < plen && k < 8; ++k) {
       bool decided = true;
@@ -276,6 +275,14 @@ static void class_fields(const xsg::ClassExpr& ex, bool icase, PatternDev* Pout,
       if (P.cls_fast && (k == 2 || k == 3)) decided = false;  // (the aligned trigger's slow path uses the full masks, but one table serves both)
       if (!decided) P.cls_chk |= 1u << k;
     }
+    // Measured on whole calls (scripts/ab_inreg.py, 20 GiB): one alternative with something left to look up wins
+    // (`She[r ]lock` 4.38 -> 4.05 ms); several alternatives lose (the candidate scan of `Sherlock|Holmes`, two
+    // alternatives, dense candidates: 33 -> 61 ms: a scalar loop per alternative and position); and an expression the
+    // compare decides completely (one alternative, nothing to look up: `Sher`, `[Ss]herlock`) needs no verification
+    // at all -- its candidate bits ARE its matches (cls_exact).
+    const bool one = ex.alts.size() == 1 && plen <= 8 && koff == 0;
+    P.cls_inreg = (one && P.cls_chk != 0 && !(ir && *ir == '0')) ? 1u : 0u;
+    P.cls_exact = (one && P.cls_chk == 0 && !P.cls_fast && !(ir && *ir == '0')) ? 1u : 0u;
   }
   P.ascii_only = ex.ascii_only ? 1u : 0u;
   P.has_newline = 0;
@@ -1649,10 +1656,16 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     // lines once (k_rx_scan + finish, no list at all) than by listing, verifying and packing tens of millions of
     // entries -- measured on the bench corpus, where `Sher` is a lexicon word: count_lines of `lock(ed|s)?` 18 ms
     // by candidates against 10 ms by k_rx_scan (8 GiB).  The caller takes the other route.
-    if (!outputs && !c->pat.rx_multiline && M * 128 > s->total_bytes) {
+    if (!c->pat.rx_multiline && M * 128 > s->total_bytes) {
       s->cnt_clean = false;
       s->pre_dense_serial = c->pattern_serial;  // later counts of this pattern on this binding go straight to k_rx_scan
-      return kDenseCandidates;
+      if (!outputs) return kDenseCandidates;
+      // a list: the same verdict (tens of millions of anchored scans, each up to 4 KiB, and chains between them, against
+      // one walk of the text) -- redone on the line-walking route
+      s->pre_off = true;
+      const int rr = run_list(s, mode, outputs);
+      s->pre_off = false;
+      return rr;
     }
     // M candidates so far: emit them, run the anchored automaton at each, walk every chunk's occurrences as the
     // reference does, pack what it reports -- then M is the number of matches and the list is what the emit pass

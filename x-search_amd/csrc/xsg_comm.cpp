@@ -73,7 +73,10 @@ int need_rccl() {
       if (h) loaded = *n;
     }
   }
-  if (!h) return fail(XSG_ENOTSUP, "librccl not found (%s)", dlerror());
+  if (!h) {
+    g_tried = getenv("XSG_RCCL_LIB") == nullptr;  // with an explicit path the next call looks again (it may have been corrected)
+    return fail(XSG_ENOTSUP, "librccl not found (%s)", dlerror());
+  }
   Rccl r;
   r.h = h;
   r.path = loaded;
@@ -87,8 +90,11 @@ int need_rccl() {
   r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.AllGather ||
-      !r.GroupStart || !r.GroupEnd || !r.GetErrorString)
+      !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+    dlclose(h);
+    g_tried = false;  // a later call may find another copy (XSG_RCCL_LIB set in the meantime)
     return fail(XSG_ENOTSUP, "'%s' lacks the expected RCCL symbols", loaded.c_str());
+  }
   g_rccl = r;
   return XSG_OK;
 }
@@ -108,6 +114,8 @@ int need_rccl() {
 struct xsg_comm {
   std::vector<ncclComm_t> comms;
   std::vector<xsg_ctx*> ctxs;
+  std::vector<int> devices;          // the ctxs' devices, kept by value: xsg_comm_destroy must not look into a ctx that
+                                     // the caller may already have destroyed
   std::vector<uint64_t*> d_scratch;  // per local device: 64 uint64 (gather buffers, staged totals)
   int nranks = 0, rank = 0;
   bool local = false;
@@ -129,6 +137,8 @@ extern "C" const char* xsg_comm_library(void) {
 }
 
 static int comm_scratch(xsg_comm* c) {
+  c->devices.clear();
+  for (xsg_ctx* x : c->ctxs) c->devices.push_back(x->device);
   for (xsg_ctx* x : c->ctxs) {
     HIP_TRY(hipSetDevice(x->device));
     void* p = nullptr;
@@ -141,11 +151,11 @@ static int comm_scratch(xsg_comm* c) {
 extern "C" void xsg_comm_destroy(xsg_comm* c) {
   if (!c) return;
   for (size_t i = 0; i < c->comms.size(); ++i) {
-    if (i < c->ctxs.size()) (void)hipSetDevice(c->ctxs[i]->device);
+    if (i < c->devices.size()) (void)hipSetDevice(c->devices[i]);
     if (c->comms[i]) (void)g_rccl.CommDestroy(c->comms[i]);
   }
   for (size_t i = 0; i < c->d_scratch.size(); ++i) {
-    (void)hipSetDevice(c->ctxs[i]->device);
+    if (i < c->devices.size()) (void)hipSetDevice(c->devices[i]);
     (void)hipFree(c->d_scratch[i]);
   }
   delete c;

@@ -64,6 +64,8 @@ struct PatternDev {
   uint32_t cls_inreg;       // kClass, plen <= 8 (koff = 0): candidates are decided in registers (k_scan: cls_verify_at) ...
   uint32_t cls_chk;         // ... looking up only these positions (bit k) in the sets: the ones the hot filter's compare does
                             // not already decide exactly
+  uint32_t cls_exact;       // kClass, one alternative, plen <= 8, and the masked window compare decides every position exactly:
+                            // a candidate IS a match, nothing is looked up
   uint32_t nalt;            // kClass: alternatives (d_pat holds nalt x plen sets, alternative-major); 0/1 otherwise
   uint32_t ascii_only;      // kClass: the expression is exact on ASCII data only ('.', negated classes): k_scan raises
                             // ScanArgs::flags bit 0 when it meets a byte >= 0x80

@@ -156,7 +156,7 @@ __device__ __forceinline__ uint32_t match_mask16_from(uint32_t m, const uint32_t
       if (diff) m &= ~(1u << b);
     }
   }
-  if (is_cls(KIND)) {
+  if (is_cls(KIND) && !P.cls_exact) {
     // The window compare saw only the bits the members of each set agree on: now every position of the candidate
     // against its 256-bit set in LDS (8 dwords per position).  A candidate whose bytes all lie in the lane's
     // 32-byte view (own unit + the next one, d[0..8)) is decided without touching memory and without an early
@@ -288,7 +288,83 @@ struct WaveState {
   bool run_nl = false;    // the current run of match-less loads holds a newline (wave-uniform)
   uint32_t masks[4] = {0, 0, 0, 0};
   uint32_t hi = 0;        // OR of the lane's bytes (ascii_only expressions: bit 7 of any byte set = non-ASCII data)
+  // count_lines of a 1..3-byte needle (lines_flag_step): matching lines counted per lane, the line state carried on the scalar unit
+  uint32_t lacc = 0;      // segments whose FIRST match start this lane saw
+  uint32_t lcin = 0;      // the line that is open at this point of the span already holds a match (wave-uniform 0 / 1)
+  uint32_t lseen = 0;     // the span has shown a newline (wave-uniform)
+  uint32_t lF = 0;        // a match start before the span's first newline (wave-uniform)
 };
+
+// ---------------------------------------------------------------------------
+// count_lines for needles of 1..3 bytes (kMask1), which are in most lines of a text: the per-unit summaries of
+// xsg_linesum.h (two flag->bit conversions, sum_of_unit, six ballots per wave-load: ~120 VALU instructions per
+// 16 bytes and lane) made that variant run at 0.41 of peak.  Here the unit stays in the byte-flag domain the matcher
+// works in (0x80 per byte, the 16 bytes of the unit read as one 128-bit number):
+//   * a line holds a match iff it holds a FIRST match; with E = M | N (match starts, newlines) and B = the segment
+//     starts (one byte above every newline, plus the unit's first byte), E - B borrows from every segment start up
+//     to the segment's first event, so M & ~(E - B) flags exactly the first match of every segment that has one
+//     (a segment whose first event is its closing newline flags nothing);
+//   * the unit's first segment continues the line that is open when the unit begins: if that line already holds a
+//     match, the unit's first byte is NOT a segment start.  "The open line holds a match" is a carry through the 64
+//     units of the wave-load -- generate: the unit's last event is a match (M > N as numbers); propagate: no newline in
+//     the unit -- and the carries of a 64-bit add ARE that recurrence: two ballots, one s_add, one mask back to the lanes.
+// ~50 VALU instructions per unit on top of the matcher's; the wave's summary (F, L, C of xsg_linesum.h) falls out at the
+// end of the span: T = all counted segments, F = a match before the span's first newline, L = the final carry.
+// ---------------------------------------------------------------------------
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 mk128(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
+  return ((u128)(((uint64_t)a3 << 32) | a2) << 64) | (u128)(((uint64_t)a1 << 32) | a0);
+}
+__device__ __forceinline__ void lines_flag_step(const uint32_t (&fl)[4], const uint32_t (&src)[8], uint32_t lane, WaveState& st) {
+  const unsigned long long Mm = __ballot((fl[0] | fl[1] | fl[2] | fl[3]) != 0);  // units with a match start
+  if (Mm == 0 && st.lcin == 0 && st.lseen != 0) return;  // nothing here can change the state or the counts
+  const uint32_t n0 = nl_flags(src[0]), n1 = nl_flags(src[1]), n2 = nl_flags(src[2]), n3 = nl_flags(src[3]);
+  const unsigned long long Nm = __ballot((n0 | n1 | n2 | n3) != 0);                // units with a newline
+  if (Mm == 0) {  // no match start in the wave-load: a newline closes the open line
+    if (Nm) st.lcin = 0, st.lseen = 1;
+    return;
+  }
+  const u128 M = mk128(fl[0], fl[1], fl[2], fl[3]), N = mk128(n0, n1, n2, n3);
+  const unsigned long long Gm = __ballot(M > N);  // the unit's last event is a match start (no newline: any match start)
+  // carries of a + b + cin with generate = Gm, propagate = no newline in the unit
+  const unsigned long long a = Gm | ~Nm, b = Gm;
+  const unsigned long long s1 = a + b;
+  const uint32_t c1 = s1 < a ? 1u : 0u;
+  const unsigned long long s2 = s1 + st.lcin;
+  const uint32_t c2 = s2 < s1 ? 1u : 0u;
+  const unsigned long long C = s2 ^ a ^ b;  // bit l: the line open at the start of lane l's unit already holds a match
+  if (!st.lseen) {  // a match start before the span's first newline?  (once per span; scalar)
+    if (Nm == 0) {
+      st.lF = 1;  // (Mm != 0 here)
+    } else {
+      const int i0 = __builtin_ctzll(Nm);
+      uint32_t f = (Mm & ((1ull << i0) - 1ull)) != 0 ? 1u : 0u;
+      const uint32_t fq[4] = {(uint32_t)__builtin_amdgcn_readlane((int)fl[0], i0), (uint32_t)__builtin_amdgcn_readlane((int)fl[1], i0),
+                              (uint32_t)__builtin_amdgcn_readlane((int)fl[2], i0), (uint32_t)__builtin_amdgcn_readlane((int)fl[3], i0)};
+      const uint32_t nq[4] = {(uint32_t)__builtin_amdgcn_readlane((int)n0, i0), (uint32_t)__builtin_amdgcn_readlane((int)n1, i0),
+                              (uint32_t)__builtin_amdgcn_readlane((int)n2, i0), (uint32_t)__builtin_amdgcn_readlane((int)n3, i0)};
+      bool open = true;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (open) {
+          if (nq[q]) {
+            f |= (fq[q] & ((nq[q] & (0u - nq[q])) - 1u)) != 0 ? 1u : 0u;  // below the unit's first newline
+            open = false;
+          } else {
+            f |= fq[q] != 0 ? 1u : 0u;
+          }
+        }
+      }
+      st.lF |= f;
+      st.lseen = 1;
+    }
+  }
+  st.lcin = c1 | c2;
+  const uint32_t start = ((uint32_t)(C >> lane) & 1u) ^ 1u;  // 1 unless the unit's first byte continues a line that already holds a match
+  const u128 B = (N << 8) | (u128)(start << 7);
+  const u128 firsts = M & ~((M | N) - B);
+  st.lacc += (uint32_t)__popcll((unsigned long long)firsts) + (uint32_t)__popcll((unsigned long long)(firsts >> 64));
+}
 
 // One wave-load (1 KiB): `cur` is this lane's 16-byte unit, `nx` the unit that
 // follows the wave-load (lane 0's unit of the next load, or the bytes after the
@@ -365,8 +441,8 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
           fl[q] = o >= limit ? 0u : (o + 4u > limit ? fl[q] & ((1u << (8u * (uint32_t)(limit - o))) - 1u) : fl[q]);
         }
       }
-      if (EMIT || WANT_LINES) {
-        // these need the position bits: 0x80-per-byte flags -> one bit per position
+      if (EMIT) {
+        // the emit pass needs the position bits: 0x80-per-byte flags -> one bit per position
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t f = fl[q] >> 7;  // bits 0, 8, 16, 24
@@ -388,9 +464,11 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
             st.last_rel = unit_rel + 1u;  // unused by the finish kernel, but it must stay inside the tile (tile_last's tag)
           }
         }
+        if (WANT_LINES) lines_flag_step(fl, nlsrc, lane, st);
         return 0;
       }
-    } else if (!(EMIT || WANT_LINES)) {
+    } else if (!EMIT) {
+      if (WANT_LINES) lines_flag_step(fl, nlsrc, lane, st);  // (fl is all zero)
       return 0;
     }
   } else {
@@ -674,6 +752,17 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
 #pragma unroll
   for (int j = 0; j < kLoads; ++j) masks[j] = st.masks[j < 4 ? j : 0];
   if (WANT_LINES && !EMIT && run_nl) wsum = sum_combine(wsum, kSumNl);
+  if (WANT_LINES && !EMIT && KIND == kMask1) {
+    // lines_flag_step's state -> the span's summary (xsg_linesum.h): T segments with a match in all; the first one is F
+    // (it lies before the first newline), the last one L (the final carry: the open line holds a match)
+    const uint32_t T = __any(st.lacc != 0) ? wave_sum_u32(st.lacc) : 0u;
+    if (!st.lseen) {
+      const uint32_t f = T != 0 ? 1u : 0u;
+      wsum = (f << 1) | (f << 2);
+    } else {
+      wsum = kSumNl | (st.lF << 1) | (st.lcin << 2) | ((T - st.lF - st.lcin) << kSumCShift);
+    }
+  }
 
   if (is_cls(KIND)) {
     if (P.ascii_only && __any((st.hi & 0x80808080u) != 0) && lane == 0) atomicOr(A.flags, 1u);  // the search must refuse

@@ -557,6 +557,12 @@ __global__ __launch_bounds__(kBlock) void k_rx_verify(const RxPreArgs A) {
   // once (k_rx_scan, k_rx_chunk) is linear.  A candidate still alive after kRxVerifyBudget bytes raises flag bit 1
   // and the host redoes the search on the other route.
   const uint64_t stop_at = ch.length - p0 > kRxVerifyBudget ? p0 + kRxVerifyBudget : ch.length;
+  // once some candidate has outrun its budget the whole pass is void (the host takes the other route): the waves that
+  // start later see the flag and leave instead of scanning their 4 KiB each (M candidates x 4096 steps otherwise)
+  if (__hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2u) {
+    A.c_len[i] = 0u;
+    return;
+  }
   while (q < stop_at) {
     st = anc[st + s_cls[d[q]]];
     if (st == 0) break;
