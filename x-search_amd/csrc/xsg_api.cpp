@@ -877,10 +877,41 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
       ms[hot] = std::min(ms[hot], t);
     }
   }
+  s->hot = ms[1] < 0.97f * ms[0] ? 1u : 0u;  // the aligned trigger has to win clearly
+  // Long patterns also settle their wave stagger here: the default (16) is right for a scan that waits for memory and
+  // costs one that waits for its slow path -- which of the two a long pattern is depends on how often its window occurs
+  // in THIS text (`detective street` on the bench corpus: 5.4 TB/s with the default, 6.1 without; `Sherlock Holmes` the
+  // other way round).  The plain count with the window and filter just chosen, stagger 0 against the default, on the
+  // same prefix; a tie keeps the default.  xsg_shard_tune (all staggers, full size) overrides it.
+  if (rc == XSG_OK && c->pat.kind == kLong && c->tune == kTuneAuto && (s->tune_serial != c->pattern_serial || s->tune_probe)) {
+    float tms[2] = {1e30f, 1e30f};
+    static const uint32_t cand[2] = {kDefaultStagger, 0u};
+    for (int round = 0; round < 2 && rc == XSG_OK; ++round) {
+      for (int k = 0; k < 2 && rc == XSG_OK; ++k) {
+        ScanArgs a = scan_args(s);
+        a.pat.hot = s->hot;
+        a.tune = cand[k];
+        a.ntiles = std::min<uint64_t>(a.ntiles, 131072);
+        hipError_t e = launch_scan_count(a, false, false, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[0], st);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_scan_count(a, false, false, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[1], st);
+        if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
+        float t = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, ev[0], ev[1]);
+        if (e != hipSuccess) rc = fail(XSG_EHIP, "stagger probe failed: %s", hipGetErrorString(e));
+        tms[k] = std::min(tms[k], t);
+      }
+    }
+    if (rc == XSG_OK) {
+      s->tune = tms[1] < 0.97f * tms[0] ? 0u : kTuneAuto;
+      s->tune_serial = s->tune == kTuneAuto ? 0 : c->pattern_serial;
+      s->tune_probe = true;
+    }
+  }
   for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
   if (rc != XSG_OK) return rc;
   HIP_TRY(hipMemsetAsync(scan_args(s).flags, 0, 4, st));
-  s->hot = ms[1] < 0.97f * ms[0] ? 1u : 0u;  // the aligned trigger has to win clearly
   return XSG_OK;
 }
 
@@ -1251,6 +1282,7 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   HIP_TRY(hipSetDevice(c->device));
   s->tune = kTuneAuto;
   s->tune_serial = 0;  // (0: the candidate values set inside the loop below apply whatever the serial)
+  s->tune_probe = false;
   if (chosen) *chosen = kTuneAuto;
   if (c->tune != kTuneAuto || s->total_bytes < (1ull << 30)) return XSG_OK;  // XSG_TUNE wins; too small to measure
   if (c->pat.kind == kDfa) return XSG_OK;  // k_rx_scan has no stagger
@@ -1280,6 +1312,7 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   }
   s->tune = best;
   s->tune_serial = c->pattern_serial;
+  s->tune_probe = false;
   s->hot = best_hot;
   if (chosen) *chosen = best;
   return XSG_OK;

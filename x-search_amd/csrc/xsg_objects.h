@@ -109,6 +109,7 @@ struct xsg_shard {
   uint64_t shard_line_base = 0;
   uint32_t tune = xsg::kTuneAuto;  // wave stagger chosen by xsg_shard_tune (kTuneAuto: per variant / ctx override)
   uint64_t tune_serial = 0;        // ... for this ctx->pattern_serial (0: not bound to a pattern)
+  bool tune_probe = false;         // `tune` came from choose_hot_filter's two-way probe (re-measured after a re-bind), not from xsg_shard_tune
   // hot filter of the window kinds for (this binding, the ctx's current pattern): measured once, see choose_hot_filter
   uint32_t hot = 0;
   uint32_t koff = 0;  // long patterns: the filter window measured best here
