@@ -32,6 +32,14 @@ out.parent.mkdir(exist_ok=True)
 status = {"first_seed": a.first_seed, "seeds_done": 0, "failed": None, "hot": a.hot}
 while time.monotonic() - t0 < a.minutes * 60:
     gs = searchers[a.hot if a.hot >= 0 else seed % 3]
+    # the list tags' routes (x-search_amd/csrc/xsg_api.cpp): one-sync (default), exact only, tiny capacities (overflow -> exact)
+    import os
+    for k in ("XSG_LIST_FAST", "XSG_LIST_CAP"):
+        os.environ.pop(k, None)
+    if seed % 5 == 0:
+        os.environ["XSG_LIST_CAP"] = str(1 + seed % 7)
+    elif seed % 5 == 1:
+        os.environ["XSG_LIST_FAST"] = "0"
     try:
         fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000 if seed % 4 else 600000)
         if seed % 3 == 0:
