@@ -225,8 +225,22 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
     import xsg
     # the file grows with the number of GPUs (every rank gets --e2e-gib of it, 16 GiB at most in all)
     n = max(world, int(min(args.e2e_gib * world, 16.0) * 2**30 / (args.chunk_mib << 20)))
-    plan = chunk_plan(args, 0xE2E, n)
     d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    # the file, a quarter of it again for the LZ4 leg and its compressed copy must fit the tmpfs: rank 0 looks, all ranks agree
+    box = [n]
+    if rank == 0:
+        try:
+            st = os.statvfs(d)
+            room = int(st.f_bavail * st.f_frsize * 0.8)
+            box[0] = min(n, int(room / 1.7) // (args.chunk_mib << 20))
+        except OSError:
+            pass
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    n = int(box[0])
+    if n < max(world, 4):
+        return {"skipped": f"no room in {d} for a file of at least {max(world, 4)} chunks"}
+    plan = chunk_plan(args, 0xE2E, n)
     path = os.path.join(d, f"xsg_bench_e2e_{os.environ.get('MASTER_PORT', os.getpid())}.txt")
     out = {}
     made = []
@@ -678,10 +692,6 @@ def main():
         regex = regex_leg(xsg, torch, ctx, shard, stream, shard_bytes)
         ctx.set_pattern(pattern)
 
-    e2e = None
-    if args.e2e_gib > 0:
-        e2e = e2e_leg(args, blocks, pattern, tcount, rank, world, dist, dev_index)
-
     configs = None
     if world == 1 and args.configs_gib > 0:
         configs = configs_leg(xsg, ctx, orc, shard_t, cap, chunks, plan, blocks, ln, pattern, args.configs_gib)
@@ -746,6 +756,42 @@ def main():
             line["configs"] = configs
         if regex is not None:
             line["regex"] = regex
+
+    # ---- Everything the contract asks for is measured and in `line`.  The legs below add to it; at N > 1 they are
+    # collective (a file all ranks search, a second communicator) and have never met more than one GPU before the
+    # driver's own multi-GPU run, so they run under a watchdog: a rank that waits for one that failed gives up after the
+    # limit, rank 0 prints the line with what it has, every rank exits 0.
+    import threading
+
+    def give_up(what):
+        def fire():
+            if rank == 0:
+                line.setdefault("notes", []).append(f"{what} did not finish within its limit and was abandoned")
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        return fire
+
+    e2e = None
+    if args.e2e_gib > 0:
+        dog = threading.Timer(300.0, give_up("the end-to-end leg")) if world > 1 else None
+        if dog:
+            dog.daemon = True
+            dog.start()
+        try:
+            e2e = e2e_leg(args, blocks, pattern, tcount, rank, world, dist, dev_index)
+        except SystemExit:
+            raise  # a parity failure is a failure
+        except Exception as ex:  # no room in /dev/shm, a job that could not start, ...: reported, not fatal
+            if world > 1:  # the other ranks may be waiting in the leg's barriers: let the watchdog end the run
+                if rank == 0:
+                    line.setdefault("notes", []).append(f"e2e leg failed on rank 0: {type(ex).__name__}: {ex}")
+                dog = None
+                give_up("the end-to-end leg (an exception on this rank)")()
+            e2e = {"error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            if dog:
+                dog.cancel()
+    if rank == 0:
         if e2e is not None:
             line["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline:
@@ -756,15 +802,7 @@ def main():
     # that a communicator that never forms (it has never met 8 GPUs before the driver's run) costs the two lib
     # fields, not the record: after 120 s every rank gives up, rank 0 prints the line with nulls.
     if dist is not None and backend == "nccl" and world > 1 and os.environ.get("XSG_BENCH_LIB_COLL", "1") != "0":
-        import threading
-
-        def give_up():
-            if rank == 0:
-                line["strong_lib_note"] = "the library-communicator leg did not finish within 120 s"
-                print(json.dumps(line), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(120.0, give_up)
+        dog = threading.Timer(120.0, give_up("the library-communicator leg"))
         dog.daemon = True
         dog.start()
         lib_comm = None

@@ -35,7 +35,7 @@ for case in ("rx_none", "rx_alt"):
             nbytes = json.loads(l)["bytes"]
     acc = defaultdict(list)
     for f in glob.glob(d + "/sq/*/*counter_collection.csv"):
-        rows = [r for r in csv.DictReader(open(f)) if "k_rx_scan" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if ("k_rx_scan" in r["Kernel_Name"] or "k_rx_count" in r["Kernel_Name"])]
         if rows:
             g = max(int(r["Grid_Size"]) for r in rows)
             for r in rows:
@@ -50,7 +50,7 @@ for case in ("rx_none", "rx_alt"):
         out["wait_share"] = round(sum(acc["SQ_WAIT_ANY"]) / sum(acc["SQ_WAVE_CYCLES"]), 3)
     fs = []
     for f in glob.glob(d + "/fetch/*/*counter_collection.csv"):
-        rows = [r for r in csv.DictReader(open(f)) if "k_rx_scan" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+        rows = [r for r in csv.DictReader(open(f)) if ("k_rx_scan" in r["Kernel_Name"] or "k_rx_count" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE"]
         if rows:
             g = max(int(r["Grid_Size"]) for r in rows)
             fs += [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == g]

@@ -26,7 +26,7 @@ for d in sorted(glob.glob("$OUT/*/lds")):
     if not fs: continue
     f = max(fs, key=os.path.getmtime)
     acc = collections.defaultdict(list)
-    rows = [r for r in csv.DictReader(open(f)) if "k_rx_scan" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if ("k_rx_scan" in r["Kernel_Name"] or "k_rx_count" in r["Kernel_Name"])]
     if not rows: continue
     g = max(int(r["Grid_Size"]) for r in rows)
     for r in rows:

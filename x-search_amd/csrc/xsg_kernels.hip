@@ -922,8 +922,14 @@ void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, 
   if (!out || !cap) return;
   const char* b[2] = {"false", "true"};
   if (a.pat.kind == kDfa) {
-    snprintf(out, cap, "xsg::k_rx_scan<%s, %s> states=%u classes=%u%s", b[emit], b[emit ? 0 : want_lines],
-             a.pat.rx_ncls ? a.pat.rx_fwd_n / a.pat.rx_ncls : 0u, a.pat.rx_ncls,
+    // count passes: one wave per 4 KiB span (k_rx_count); the emit pass: the tile-cooperative k_rx_scan
+    const char* rw = getenv("XSG_RX_WAVE");
+    char name[48];
+    if (emit || (rw && *rw == '0'))
+      snprintf(name, sizeof name, "xsg::k_rx_scan<%s, %s>", b[emit], b[emit ? 0 : want_lines]);
+    else
+      snprintf(name, sizeof name, "xsg::k_rx_count<%s>", b[want_lines]);
+    snprintf(out, cap, "%s states=%u classes=%u%s", name, a.pat.rx_ncls ? a.pat.rx_fwd_n / a.pat.rx_ncls : 0u, a.pat.rx_ncls,
              a.tile_mask ? " (tiles marked by the factor prefilter only)" : "");
     return;
   }

@@ -22,6 +22,8 @@
 // an occurrence of the factor starts.
 // The staged tile is translated to class codes in place (one table read per byte, off every dependency chain), the
 // walks read four codes at a time, and a walk in the start state skips from trigger byte to trigger byte.
+#include <cstdlib>
+
 #include "xsg_internal.h"
 
 namespace xsg {
@@ -44,12 +46,15 @@ struct RxCtx {
   uint64_t toff;           // chunk-relative offset of the tile
   uint64_t L;              // chunk length
   uint32_t fwd_start, fwd_acc, rev_start, rev_acc;
+  uint32_t tile_bytes = kRxTile;  // bytes staged at `tilew` (k_rx_scan: the 16 KiB tile; k_rx_count: a wave's 4 KiB span)
+  uint32_t nseg = kBlock;         // ... = this many 64-byte segments (trigger words)
+  const uint8_t* la = nullptr;    // LDS: the (up to) 64 RAW bytes behind the staged bytes, '\n' beyond the chunk (k_rx_count)
 };
 
 // class code of the byte at q (< L), wherever it lives
 __device__ __forceinline__ uint32_t rx_class(const RxCtx& X, uint64_t q) {
   const uint64_t rel = q - X.toff;
-  if (rel < kRxTile) {
+  if (rel < X.tile_bytes) {
     const uint32_t r = (uint32_t)rel;
     return (X.tilew[rx_addr(r & ~3u) >> 2] >> (8u * (r & 3u))) & X.cmask;
   }
@@ -69,19 +74,19 @@ __device__ __forceinline__ uint32_t rx_walk_line(const RxCtx& X, uint64_t cur, c
     uint64_t last_end = 0;  // a match ends behind at least one byte: 0 = none yet
     bool stop = false;      // the state died, or (LINES) a match was seen
     uint64_t q = cur;
-    if (cur - X.toff < kRxTile) {
+    if (cur - X.toff < X.tile_bytes) {
       uint32_t rel = (uint32_t)(cur - X.toff);
       uint32_t last_rel = 0;
-      while (rel < kRxTile) {
+      while (rel < X.tile_bytes) {
         // In its start state the automaton only waits for a byte that can begin a match: every other byte leaves it
         // where it is.  Those bytes (and '\n') are the tile's TRIGGERS, flagged for all 16 KiB at once in the staging
         // phase; the walk jumps from one to the next on the bit masks instead of stepping through the text.
         if (X.skip && st == X.fwd_start) {
           uint32_t w = rel >> 6;
           unsigned long long m = X.trig[w] & (~0ull << (rel & 63u));
-          while (!m && ++w < (uint32_t)kBlock) m = X.trig[w];
+          while (!m && ++w < X.nseg) m = X.trig[w];
           if (!m) {  // none left in the tile (the line runs on behind it)
-            rel = kRxTile;
+            rel = X.tile_bytes;
             break;
           }
           rel = w * kRxSeg + (uint32_t)__builtin_ctzll(m);
@@ -112,7 +117,9 @@ __device__ __forceinline__ uint32_t rx_walk_line(const RxCtx& X, uint64_t cur, c
       if (last_rel) last_end = X.toff + last_rel;
     }
     while (!stop && q < X.L) {  // behind the tile
-      st = X.fwd[st + (X.cls[X.cbase[q]] & X.cmask)];
+      const uint64_t bq = q - (X.toff + X.tile_bytes);  // the first 64 of those bytes may be at hand in LDS
+      const uint32_t byte = (X.la && bq < 64u) ? X.la[bq] : X.cbase[q];
+      st = X.fwd[st + (X.cls[byte] & X.cmask)];
       if (st == 0) break;
       ++q;
       if (st >= X.fwd_acc) {
@@ -410,6 +417,253 @@ __global__ __launch_bounds__(kBlock) void k_rx_scan(const ScanArgs A, const uint
     if (cnt)
       for (unsigned long long m = starts; m; m &= m - 1ull)
         (void)rx_walk_line<true, false>(X, seg_off + (uint32_t)__builtin_ctzll(m), A, c, rank);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_rx_count: the COUNT passes of the line-walking route, one WAVE per 4 KiB span, no workgroup barrier.
+// k_rx_scan's workgroup decides together whether its tile can be left without staging (one barrier for the four waves'
+// verdicts); measured on text without a trigger byte, that barrier is the difference between 4.3 and 6.7 TB/s -- a
+// tile takes as long as the slowest of its four waves' loads, where k_scan's waves leave one by one.  Here the wave is
+// the unit: it reads its own contiguous 4 KiB (as a k_scan wave does), tests them for the expression's few trigger
+// bytes, and if there is none it is done -- apart from the one line that starts in the span and runs on behind it,
+// decided on the 64 bytes behind the span.  A wave whose span holds a trigger stages and translates ITS span in its
+// own quarter of the workgroup's LDS (wave-local fences only), walks the lines that start there, and follows a line
+// that leaves the span through those 64 bytes and then global memory, exactly as k_rx_scan follows a line that leaves
+// the tile.  The per-tile outputs are sums over the tile's waves (atomicAdd; tile_nl is zeroed by the launcher).
+// The emit pass stays with k_rx_scan (its ranks need the tile's waves in step); both count the same thing: the
+// matches of the lines that START in the tile.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRxSpan = kRxTile / kWaves;           // 4 KiB
+constexpr uint32_t kRxSpanLds = kRxSpan + 4 * 64 + 64;    // swizzled span + the 64 raw bytes behind it
+
+template <bool LINES>
+__global__ __launch_bounds__(kBlock) void k_rx_count(const ScanArgs A, const uint32_t want_nl) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];  // the forward table
+  __shared__ __attribute__((aligned(16))) uint8_t s_span[kWaves][kRxSpanLds];
+  __shared__ uint8_t s_cls[256];
+  __shared__ unsigned long long s_trig[kBlock];
+
+  const uint64_t tile = (uint64_t)blockIdx.x + (uint64_t)blockIdx.y * gridDim.x;
+  if (tile >= A.ntiles) return;
+  if (A.tile_mask && !want_nl && A.tile_mask[tile] == 0u) return;  // the factor prefilter (see k_rx_scan)
+  const PatternDev P = A.pat;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t c = A.tile_chunk ? A.tile_chunk[tile] : 0u;
+  const ChunkDev ch = A.chunks[c];
+  const uint8_t* cbase = A.base + ch.offset;
+  const uint64_t L = ch.length;
+  const uint64_t Lr = (L + 15u) & ~(uint64_t)15u;
+  const uint64_t soff = (tile - A.chunk_tile0[c]) * (uint64_t)kRxTile + (uint64_t)wave * kRxSpan;  // this wave's span
+  if (soff >= L) return;  // (only in a chunk's last tile)
+
+  // ---- the span's bytes (bytes at or beyond L read as '\n'), the 256 bytes behind it (lane l: dword l), the byte
+  // in front of it.  A span that lies inside the chunk together with those 256 bytes -- all but a chunk's last -- needs no
+  // clamping at all (wave-uniform branch, as in k_scan).
+  uint32_t dd[4][4];
+  uint32_t la = 0x0a0a0a0au;
+  const bool inner = soff + kRxSpan + 256u <= L;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  if (inner) {
+    const uint8_t* p0 = cbase + soff + (uint64_t)lane * kUnit;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + (uint64_t)j * 1024u));
+      dd[j][0] = v.x, dd[j][1] = v.y, dd[j][2] = v.z, dd[j][3] = v.w;
+    }
+    la = *reinterpret_cast<const uint32_t*>(cbase + soff + kRxSpan + (uint64_t)lane * 4u);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t off = soff + ((uint64_t)j * 64u + lane) * kUnit;
+      dd[j][0] = dd[j][1] = dd[j][2] = dd[j][3] = 0x0a0a0a0au;
+      if (off < Lr) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(cbase + off));
+        dd[j][0] = v.x, dd[j][1] = v.y, dd[j][2] = v.z, dd[j][3] = v.w;
+        if (off + kUnit > L) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint64_t o = off + 4u * q;
+            const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+            dd[j][q] = (dd[j][q] & keep) | (0x0a0a0a0au & ~keep);
+          }
+        }
+      }
+    }
+    {
+      const uint64_t o = soff + kRxSpan + (uint64_t)lane * 4u;
+      if (o < Lr) {
+        la = *reinterpret_cast<const uint32_t*>(cbase + o);
+        const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+        la = (la & keep) | (0x0a0a0a0au & ~keep);
+      }
+    }
+  }
+  uint32_t prev_byte = '\n';
+  if (lane == 0 && soff != 0) prev_byte = cbase[soff - 1];
+
+  const bool quick = P.rx_ntrig != 0;
+  uint32_t hi = 0, any_trig = 0, any_nl = 0;
+  const uint32_t tv0 = (P.rx_trig4 & 0xffu) * 0x01010101u, tv1 = ((P.rx_trig4 >> 8) & 0xffu) * 0x01010101u;
+  const uint32_t tv2 = ((P.rx_trig4 >> 16) & 0xffu) * 0x01010101u, tv3 = (P.rx_trig4 >> 24) * 0x01010101u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi |= dd[j][0] | dd[j][1] | dd[j][2] | dd[j][3];
+    if (quick) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t x0 = dd[j][q] ^ tv0, x1 = dd[j][q] ^ tv1;
+        any_trig |= ((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1);
+        if (P.rx_ntrig > 2u) {  // (scalar)
+          const uint32_t x2 = dd[j][q] ^ tv2, x3 = dd[j][q] ^ tv3;
+          any_trig |= ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3);
+        }
+        const uint32_t y = dd[j][q] ^ 0x0a0a0a0au;
+        any_nl |= (y - 0x01010101u) & ~y;
+      }
+    }
+  }
+  if (P.ascii_only && __any((hi & 0x80808080u) != 0) && lane == 0) atomicOr(A.flags, 1u);  // the search must refuse
+  if (want_nl) {  // newlines of the span (inside the chunk only: bytes beyond L were replaced by '\n')
+    uint32_t nl_cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t off = soff + ((uint64_t)j * 64u + lane) * kUnit;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint64_t o = off + 4u * q;
+        const uint32_t keep = o >= L ? 0u : (o + 4u > L ? ((1u << (8u * (uint32_t)(L - o))) - 1u) : 0xffffffffu);
+        const uint32_t y = (dd[j][q] & keep) ^ (0x0a0a0a0au & keep) ^ ~keep;
+        nl_cnt += (uint32_t)__popc(~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu));
+      }
+    }
+    const uint32_t wn = rx_wave_sum(nl_cnt);
+    if (lane == 0 && wn) atomicAdd(A.tile_nl + tile, wn);
+  }
+
+  uint8_t* const sp = s_span[wave];
+  uint32_t* const law = reinterpret_cast<uint32_t*>(sp + kRxSpan + 4 * 64);  // the 64 raw bytes behind the span (full path)
+  const uint64_t send = soff + kRxSpan;
+  if (quick && __ballot((any_trig & 0x80808080u) != 0) == 0) {
+    // ---- no trigger in the span.  Does a line START in it and run on behind it?  Iff the span does not end the chunk, its
+    // last byte is no '\n', and it holds a line start: a '\n' somewhere, or its first byte opens the chunk / follows one.
+    const bool last_is_nl = __ballot(lane == 63u && (dd[3][3] >> 24) == 0x0au) != 0;
+    const bool has_start = __ballot((any_nl & 0x80808080u) != 0) != 0 || __ballot(lane == 0u && prev_byte == 0x0au) != 0;
+    if (send >= L || last_is_nl || !has_start) return;
+    // Inside the span the line holds no trigger: the automaton reaches the span's end in its start state.  Nearly always
+    // the line ends within the next few dozen bytes without a trigger either: every lane holds a dword of the 256 bytes
+    // behind the span; the first lane with a '\n' settles it -- no trigger in the lanes below, none below the '\n' in its
+    // own dword.  (One lane looping over such dwords in LDS, the first version, cost every wave ~1500 cycles; with 64
+    // bytes of look-ahead one wave in nine met a line that ran further and walked it through global memory: 3.2 TB/s
+    // where 7.2 are possible.)
+    const uint32_t y = la ^ 0x0a0a0a0au;
+    const uint32_t nf = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);  // 0x80 per '\n' (exact)
+    uint32_t tg = 0;
+    for (uint32_t v = 0; v < P.rx_ntrig; ++v) {
+      const uint32_t z = la ^ (((P.rx_trig4 >> (8u * v)) & 0xffu) * 0x01010101u);
+      tg |= ~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu);
+    }
+    const unsigned long long nfb = __ballot(nf != 0), tgb = __ballot(tg != 0);
+    bool walk = true;  // no '\n' within 256 bytes: a long line, walked
+    if (nfb) {
+      const int f = __builtin_ctzll(nfb);
+      const uint32_t own = (tg & ((nf & (0u - nf)) - 1u)) != 0u ? 1u : 0u;  // a trigger below the dword's first '\n'
+      walk = (tgb & ((1ull << f) - 1ull)) != 0 || __builtin_amdgcn_readlane((int)own, f) != 0;
+    }
+    if (walk && lane == 0) {  // rare: the automaton's tables straight from global memory (this wave staged nothing)
+      RxCtx X;
+      X.tilew = nullptr, X.cls = P.d_pat, X.fwd = reinterpret_cast<const uint16_t*>(P.d_pat + 256);
+      X.trig = nullptr, X.skip = P.rx_skip, X.cmask = 0x7fu;
+      X.rev = nullptr;
+      X.cbase = cbase, X.toff = soff, X.L = L;
+      X.fwd_start = P.rx_fwd_start, X.fwd_acc = P.rx_fwd_acc, X.rev_start = P.rx_rev_start, X.rev_acc = P.rx_rev_acc;
+      X.tile_bytes = kRxSpan, X.nseg = 64u;
+      uint64_t rank = 0;
+      const uint32_t n = rx_walk_line<false, LINES>(X, send, A, c, rank);
+      if (n) atomicAdd(A.tile_cnt + tile, n);
+    }
+    return;
+  }
+  if (lane < 16u) law[lane] = la;
+
+  // ---- the span holds a trigger (or the expression has many): stage and translate it, wave-locally.  The class map and
+  // the forward table are the workgroup's; every wave that needs them writes them (the same values: idempotent).
+  for (uint32_t k = lane; k < 256u / 4u; k += 64u)
+    reinterpret_cast<uint32_t*>(s_cls)[k] = reinterpret_cast<const uint32_t*>(P.d_pat)[k];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.d_pat + 256);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
+    for (uint32_t k = lane; k < (P.rx_fwd_n + 1u) / 2u; k += 64u) dst[k] = src[k];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = ((uint32_t)j * 64u + lane) * kUnit;  // span-relative
+    uint32_t* w = reinterpret_cast<uint32_t*>(sp + rx_addr(p));
+    w[0] = dd[j][0], w[1] = dd[j][1], w[2] = dd[j][2], w[3] = dd[j][3];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // this lane's 64-byte segment of the span: line starts, class codes in place, trigger word (as k_rx_scan)
+  const uint32_t seg = lane * kRxSeg;
+  unsigned long long nlm = 0, tgm = 0;
+  {
+    uint32_t* w = reinterpret_cast<uint32_t*>(sp + rx_addr(seg));
+    uint32_t d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = w[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t x = d[k] ^ 0x0a0a0a0au;
+      const uint32_t f = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu) >> 7;
+      const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
+      nlm |= (unsigned long long)nib << (4 * k);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint32_t t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = s_cls[(d[4 * g + (i >> 2)] >> (8 * (i & 3))) & 0xffu];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t cw = t[4 * j] | (t[4 * j + 1] << 8) | (t[4 * j + 2] << 16) | (t[4 * j + 3] << 24);
+        w[4 * g + j] = cw;
+        const uint32_t f = (cw >> 7) & 0x01010101u;
+        const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
+        tgm |= (unsigned long long)nib << (4 * (4 * g + j));
+      }
+    }
+  }
+  s_trig[tid] = tgm;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint64_t seg_off = soff + seg;
+  const uint32_t nvalid = seg_off >= L ? 0u : (L - seg_off >= kRxSeg ? kRxSeg : (uint32_t)(L - seg_off));
+  const unsigned long long valid = nvalid >= 64u ? ~0ull : ((1ull << nvalid) - 1ull);
+  // does the previous segment end in '\n'?  (lane 0: the byte in front of the span)
+  const uint32_t up = (uint32_t)__shfl_up((int)(uint32_t)(nlm >> 63), 1);
+  const bool prev_nl = lane == 0 ? prev_byte == 0x0au : up != 0u;
+  const unsigned long long starts = ((nlm << 1) | (prev_nl ? 1ull : 0ull)) & valid;
+
+  RxCtx X;
+  X.tilew = reinterpret_cast<const uint32_t*>(sp), X.cls = s_cls, X.fwd = reinterpret_cast<const uint16_t*>(s_dyn);
+  X.trig = s_trig + wave * 64u, X.skip = P.rx_skip, X.cmask = P.rx_skip ? 0x7fu : 0xffu;
+  X.rev = nullptr;
+  X.cbase = cbase, X.toff = soff, X.L = L;
+  X.fwd_start = P.rx_fwd_start, X.fwd_acc = P.rx_fwd_acc, X.rev_start = P.rx_rev_start, X.rev_acc = P.rx_rev_acc;
+  X.tile_bytes = kRxSpan, X.nseg = 64u;
+  X.la = reinterpret_cast<const uint8_t*>(law);
+
+  uint32_t cnt = 0;
+  uint64_t rank = 0;
+  for (unsigned long long m = starts; m; m &= m - 1ull)
+    cnt += rx_walk_line<false, LINES>(X, seg_off + (uint32_t)__builtin_ctzll(m), A, c, rank);
+  if (__any(cnt != 0)) {  // tile_cnt is zero at rest and only a wave that found something writes
+    const uint32_t wc = rx_wave_sum(cnt);
+    if (lane == 0) atomicAdd(A.tile_cnt + tile, wc);
   }
 }
 
@@ -740,6 +994,19 @@ hipError_t launch_rx_count(const ScanArgs& a, bool want_nl, bool want_lines, hip
     const uint64_t nchunks = a.nchunks;
     hipLaunchKernelGGL((k_rx_chunk<false>), dim3((unsigned)((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), rx_dyn_lds(a), s,
                        a, nchunks);
+    return hipGetLastError();
+  }
+  // the count passes: one wave per 4 KiB span (k_rx_count); XSG_RX_WAVE=0: the tile-cooperative kernel of round 2/3a
+  static const bool by_wave = [] { const char* e = getenv("XSG_RX_WAVE"); return !(e && *e == '0'); }();
+  if (by_wave) {
+    if (want_nl) {  // the waves of a tile add their newline counts
+      const hipError_t e = hipMemsetAsync(a.tile_nl, 0, 4 * a.ntiles, s);
+      if (e != hipSuccess) return e;
+    }
+    if (want_lines)
+      hipLaunchKernelGGL((k_rx_count<true>), grid, dim3(kBlock), rx_dyn_lds(a), s, a, want_nl ? 1u : 0u);
+    else
+      hipLaunchKernelGGL((k_rx_count<false>), grid, dim3(kBlock), rx_dyn_lds(a), s, a, want_nl ? 1u : 0u);
     return hipGetLastError();
   }
   if (want_lines)
