@@ -859,8 +859,10 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
       s->koff_chosen = true;
     }
   }
-  // A B A B, the better of the two rounds each: the first launches after a quiet spell run on ramping clocks
-  for (int round = 0; round < 2 && rc == XSG_OK; ++round) {
+  // A B A B A B, the best of three rounds each: the first launches after a quiet spell run on ramping clocks (measured
+  // on fresh bindings of one 50 GiB shard, scripts/probe_check.py: `Sherlock` 0.658 against 0.600 ms in seven probes
+  // of eight, 0.664 against 0.633 in the first -- two rounds and a 3 % bar picked the slower filter now and then)
+  for (int round = 0; round < 3 && rc == XSG_OK; ++round) {
     for (uint32_t hot = 0; hot < 2 && rc == XSG_OK; ++hot) {
       ScanArgs a = scan_args(s);
       a.pat.hot = hot;
@@ -877,7 +879,8 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
       ms[hot] = std::min(ms[hot], t);
     }
   }
-  s->hot = ms[1] < 0.97f * ms[0] ? 1u : 0u;  // the aligned trigger has to win clearly
+  s->hot = ms[1] < 0.98f * ms[0] ? 1u : 0u;  // the aligned trigger has to win (a wrong "window" costs the plain count 7 %, a wrong "aligned" 2 %)
+  if (getenv("XSG_PROBE_LOG")) fprintf(stderr, "[xsg] hot-filter probe: window %.4f ms, aligned %.4f ms -> %u\n", ms[0], ms[1], s->hot);
   // Long patterns also settle their wave stagger here: the default (16) is right for a scan that waits for memory and
   // costs one that waits for its slow path -- which of the two a long pattern is depends on how often its window occurs
   // in THIS text (`detective street` on the bench corpus: 5.4 TB/s with the default, 6.1 without; `Sherlock Holmes` the

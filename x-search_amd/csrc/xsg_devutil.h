@@ -29,11 +29,34 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t x, uint32_t edge, ui
 #endif
 }
 
+// Wave-wide reductions on the DPP data path: four shifts inside the rows of 16 lanes, then the two row broadcasts
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) leave the total in lane 63; v_readlane makes it
+// wave-uniform.  Seven VALU instructions and no LDS: the butterfly over __shfl_xor compiles to six DEPENDENT
+// ds_bpermute_b32 (address arithmetic + a trip through the LDS crossbar each) -- ~700 cycles of latency for the two
+// reductions in k_scan's epilogue, paid by every wave that holds a match (every wave, for a needle like `the`).
+#define XSG_DPP_STEP(OP, x, ctrl, rows) x = OP(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, false))
+__device__ __forceinline__ uint32_t dpp_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v += (uint32_t)__shfl_xor((int)v, s);
-  return v;
+  XSG_DPP_STEP(dpp_add, v, 0x111, 0xf);  // row_shr:1
+  XSG_DPP_STEP(dpp_add, v, 0x112, 0xf);  // row_shr:2
+  XSG_DPP_STEP(dpp_add, v, 0x114, 0xf);  // row_shr:4
+  XSG_DPP_STEP(dpp_add, v, 0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row's sum
+  XSG_DPP_STEP(dpp_add, v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  XSG_DPP_STEP(dpp_add, v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// maximum over the wave (unsigned; lanes without a value contribute 0)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  XSG_DPP_STEP(dpp_max, v, 0x111, 0xf);
+  XSG_DPP_STEP(dpp_max, v, 0x112, 0xf);
+  XSG_DPP_STEP(dpp_max, v, 0x114, 0xf);
+  XSG_DPP_STEP(dpp_max, v, 0x118, 0xf);
+  XSG_DPP_STEP(dpp_max, v, 0x142, 0xa);
+  XSG_DPP_STEP(dpp_max, v, 0x143, 0xc);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+#undef XSG_DPP_STEP
 // inclusive prefix sum over lanes
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
 #pragma unroll

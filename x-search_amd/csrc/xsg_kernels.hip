@@ -779,12 +779,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
       // the end of the wave's last match, relative to the tile start: it fits 16 bits, so the reduction runs on
       // 32-bit values (a 64-bit max costs three times the lane exchanges; a needle that is dense in the text pays
       // this epilogue in every wave)
-      uint32_t rel = st.last_rel;
-#pragma unroll
-      for (int sft = 32; sft >= 1; sft >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)rel, sft);
-        rel = o > rel ? o : rel;
-      }
+      const uint32_t rel = wave_max_u32(st.last_rel);
       if (lane == 0) {
         // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
         // cut dense patterns to a third)
