@@ -57,13 +57,18 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 #undef XSG_DPP_STEP
-// inclusive prefix sum over lanes
+// inclusive prefix sum over lanes: the same DPP sequence as wave_sum_u32 -- it IS a Hillis-Steele scan inside the rows,
+// and the two row broadcasts add the totals of the rows below
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
-    uint32_t o = (uint32_t)__shfl_up((int)v, s);
-    if (lane >= (uint32_t)s) v += o;
-  }
+  (void)lane;
+#define XSG_DPP_ADD(x, ctrl, rows) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, false)
+  XSG_DPP_ADD(v, 0x111, 0xf);
+  XSG_DPP_ADD(v, 0x112, 0xf);
+  XSG_DPP_ADD(v, 0x114, 0xf);
+  XSG_DPP_ADD(v, 0x118, 0xf);
+  XSG_DPP_ADD(v, 0x142, 0xa);
+  XSG_DPP_ADD(v, 0x143, 0xc);
+#undef XSG_DPP_ADD
   return v;
 }
 

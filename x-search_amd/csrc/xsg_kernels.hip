@@ -814,7 +814,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
       const uint32_t m = masks[j];
       const uint32_t pc = (uint32_t)__popc(m);
       const uint32_t incl = wave_incl_scan_u32(pc, lane);
-      const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       if (m) {
         uint64_t r = rank + (incl - pc);
         const uint64_t unit_off = wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit;
