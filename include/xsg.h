@@ -251,7 +251,8 @@ int xsg_shard_set_line_base(xsg_shard* shard, uint64_t line_base);
  * make; | XSG_WITH_NEWLINES is not served for such a pattern (XSG_ENOTSUP).
  * The first pass of a (binding, pattern) on a shard of 64 MiB or more also runs
  * the library's hot-filter probe (a few short launches and one stream sync,
- * DESIGN.md 3.1); every later call only enqueues. */
+ * DESIGN.md 3.1) -- unless another binding of the same buffer already measured
+ * this pattern on this ctx; every later call only enqueues. */
 int xsg_count_async(xsg_shard* shard, uint32_t mode, void* stream, uint64_t* d_counters);
 /* Synchronous, any pattern, XSG_COUNT_MATCHES or XSG_COUNT_LINES
  * (| XSG_WITH_NEWLINES): result in host memory. */

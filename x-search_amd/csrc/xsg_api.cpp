@@ -681,6 +681,7 @@ static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const
 
 extern "C" int xsg_shard_invalidate(xsg_shard* s) {
   if (!s) return fail(XSG_EINVAL, "shard is null");
+  if (s->ctx->memo.base == s->base) s->ctx->memo = xsg_ctx::ProbeMemo{};
   forget_derived(s);
   s->last_mode = -1;
   s->total = 0;
@@ -708,6 +709,7 @@ extern "C" int xsg_shard_create(xsg_ctx* c, const void* d_base, uint64_t capacit
 extern "C" int xsg_shard_rebind(xsg_shard* s, const void* d_base, uint64_t capacity, const xsg_chunk* chunks,
                                 uint64_t nchunks) {
   if (!s) return fail(XSG_EINVAL, "shard is null");
+  if (s->ctx->memo.base == s->base || s->ctx->memo.base == d_base) s->ctx->memo = xsg_ctx::ProbeMemo{};  // (the bytes changed)
   return bind_shard(s, d_base, capacity, chunks, nchunks);
 }
 
@@ -818,6 +820,17 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   s->koff_chosen = false;
   s->hot_serial = c->pattern_serial;
   if (s->total_bytes < c->probe_min_bytes || s->ntiles == 0) return XSG_OK;
+  if (c->memo.serial == c->pattern_serial && c->memo.base == s->base && c->memo.total_bytes == s->total_bytes) {
+    s->hot = c->memo.hot;  // measured on this buffer for this pattern by another binding
+    s->koff = c->memo.koff;
+    s->koff_chosen = c->memo.koff_chosen;
+    if (c->memo.tune_probe && (s->tune_serial != c->pattern_serial || s->tune_probe)) {
+      s->tune = c->memo.tune;
+      s->tune_serial = s->tune == kTuneAuto ? 0 : c->pattern_serial;
+      s->tune_probe = true;
+    }
+    return XSG_OK;
+  }
   XSG_TRY(ensure_tile_nl(s));
   XSG_TRY(prepare_tiles(s, false, st));
   s->cnt_clean = false;  // no finish kernel behind these launches
@@ -915,6 +928,11 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
   if (rc != XSG_OK) return rc;
   HIP_TRY(hipMemsetAsync(scan_args(s).flags, 0, 4, st));
+  c->memo.serial = c->pattern_serial;
+  c->memo.base = s->base;
+  c->memo.total_bytes = s->total_bytes;
+  c->memo.hot = s->hot, c->memo.koff = s->koff, c->memo.koff_chosen = s->koff_chosen;
+  c->memo.tune = s->tune, c->memo.tune_probe = s->tune_probe;
   return XSG_OK;
 }
 

@@ -610,12 +610,7 @@ __global__ __launch_bounds__(kBlock) void k_list_out(const ListArgs A) {
     const bool has_chunk = i < A.nchunks;
     const uint64_t c = has_chunk ? i : 0;
     const uint32_t nt = has_chunk ? A.tail_cnt[c] : 0u;
-    uint32_t nmax = nt;
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)nmax, sft);
-      nmax = o > nmax ? o : nmax;
-    }
+    const uint32_t nmax = wave_max_u32(nt);
     if (nmax) {
       uint64_t r1 = has_chunk ? A.tile_off[A.chunk_tile0[c + 1]] : 0;
       r1 = r1 < M ? r1 : M;
@@ -678,12 +673,7 @@ __global__ void k_assemble(const ListArgs A) {
   const bool has_chunk = i < A.nchunks;
   const uint64_t c = has_chunk ? i : 0;
   const uint32_t n = has_chunk ? A.tail_cnt[c] : 0u;
-  uint32_t nmax = n;
-#pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)nmax, sft);
-    nmax = o > nmax ? o : nmax;
-  }
+  const uint32_t nmax = wave_max_u32(n);
   if (nmax) {
     const uint64_t r1 = has_chunk ? A.tile_off[A.chunk_tile0[c + 1]] : 0;
     const uint64_t dst0 = has_chunk ? A.keep_pre[r1] + A.tail_pre[c] : 0;

@@ -94,6 +94,17 @@ struct xsg_ctx {
   char arch[128] = "";
   int cus = 0;
   uint64_t hbm = 0;
+  // What the probe (choose_hot_filter) measured last, kept with the buffer it was measured on: a NEW binding of the same
+  // buffer and size with the same pattern (a caller that creates a shard per search) takes it over instead of paying the
+  // probe again; xsg_shard_rebind / xsg_shard_invalidate on that buffer drop it (the bytes changed).  A choice, never a
+  // result: a stale one costs speed only.
+  struct ProbeMemo {
+    uint64_t serial = 0;
+    const uint8_t* base = nullptr;
+    uint64_t total_bytes = 0;
+    uint32_t hot = 0, koff = 0, tune = xsg::kTuneAuto;
+    bool koff_chosen = false, tune_probe = false;
+  } memo;
 };
 
 
