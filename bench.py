@@ -428,7 +428,7 @@ def configs_leg(xsg, ctx, orc, shard_t, cap, chunks, plan, blocks, ln, pattern, 
     ctx.set_pattern(b"She")
     d = timed_calls(lib, sh, 3)
     out["dense_needle"] = {"pattern": "She", "tags": {t: {"results": c, "ms": round(ms, 3)} for t, (c, ms) in d.items()},
-                           "note": "tens of millions of results: D2H of the lists (xs::lines: into pageable caller memory) dominates"}
+                           "note": "tens of millions of results: the pinned D2H of the lists dominates (xs::lines: lengths, offsets and 2 GB of line bytes through xsg_result_lines_view)"}
     tm = np.array([orc.count(b, b"She", False) for b in blocks], dtype=np.int64)
     if d["count"][0] != int(tm[pl].sum()) or d["match_byte_offsets"][0] != int(tm[pl].sum()):
         raise SystemExit("configs PARITY FAILURE: dense needle count")

@@ -281,6 +281,14 @@ int xsg_result_lines_size(xsg_shard* shard, uint64_t* n_lines, uint64_t* total_b
  * `offsets` (optional) receives the global byte offset of each line start. */
 int xsg_result_lines(xsg_shard* shard, uint64_t* lengths, char* bytes, uint64_t bytes_cap, uint64_t* offsets);
 
+/* The same without copies into caller memory: *lengths / *offsets (n_lines values each) and *bytes (total_bytes, the lines
+ * back to back) point into pinned host memory owned by the shard, valid until the next search on it.  A list that fit
+ * the one-sync route is already there; a larger one is moved in three pinned D2H copies (a needle in most lines of
+ * 10 GiB returns 3 GB: into pageable memory that is 0.3 s, pinned 0.07).  XSG_ENOMEM if the result needs more than
+ * 16 GiB of pinned memory (use xsg_result_lines). */
+int xsg_result_lines_view(xsg_shard* shard, const uint64_t** lengths, const char** bytes, const uint64_t** offsets,
+                          uint64_t* n_lines, uint64_t* total_bytes);
+
 /* newline count of the shard, available after an XSG_LINE_INDICES search (lets a
  * caller chain line-index bases from chunk to chunk without a second pass). */
 int xsg_result_newlines(xsg_shard* shard, uint64_t* newlines);

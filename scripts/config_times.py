@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Whole-call time of every xs:: tag on a device-resident shard (BASELINE configs 2 and 4), measured at the C ABI:
-xsg_count for the count tags; xsg_search + the result in host memory for the list tags (xsg_result_u64_view -- a
-pointer into the shard's pinned buffer -- for the uint64 tags; xsg_result_lines into preallocated host arrays for
-xs::lines).  No Python object is built per result.  Median of --reps calls after one warm call."""
+xsg_count for the count tags; xsg_search + the result in host memory for the list tags (xsg_result_u64_view /
+xsg_result_lines_view: pointers into the shard's pinned buffers).  No Python object is built per result.  Median of --reps calls after one warm call."""
 import argparse
 import ctypes as C
 import json
@@ -40,15 +39,11 @@ def timed_calls(lib, sh, reps, dense_ok=True):
         xsg._check(lib.xsg_result_u64_view(sh.h, C.byref(ptr), C.byref(cnt)))
         return int(cnt.value)
 
-    def lines():
+    lp, op, dp = _u64p(), _u64p(), C.c_char_p()
+
+    def lines():  # lengths, offsets and packed bytes in the shard's pinned buffers (xsg_result_lines_view)
         xsg._check(lib.xsg_search(sh.h, xsg.LINES, C.byref(n)))
-        xsg._check(lib.xsg_result_lines_size(sh.h, C.byref(nl), C.byref(nb)))
-        if "lens" not in bufs or bufs["lens"].size < nl.value or bufs["bytes"].size < nb.value:
-            bufs["lens"] = np.empty(max(nl.value, 1), dtype=np.uint64)
-            bufs["offs"] = np.empty(max(nl.value, 1), dtype=np.uint64)
-            bufs["bytes"] = np.empty(max(nb.value, 1), dtype=np.uint8)
-        xsg._check(lib.xsg_result_lines(sh.h, bufs["lens"].ctypes.data_as(_u64p), bufs["bytes"].ctypes.data, nb.value,
-                                        bufs["offs"].ctypes.data_as(_u64p)))
+        xsg._check(lib.xsg_result_lines_view(sh.h, C.byref(lp), C.cast(C.byref(dp), C.POINTER(C.c_char_p)), C.byref(op), C.byref(nl), C.byref(nb)))
         return int(nl.value)
 
     calls = [("count", lambda: count(xsg.COUNT_MATCHES)), ("count_lines", lambda: count(xsg.COUNT_LINES)),

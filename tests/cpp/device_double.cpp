@@ -115,7 +115,7 @@ extern "C" int xsg_regex_dfa_info(const void*, size_t, uint32_t, xsg_regex_dfa*,
   return fail(XSG_ENOTSUP, "no regex in the double");
 }
 
-// results of the last list search live in the shard's h_line_len / h_line_off (host vectors of xsg_objects.h) and here
+// results of the last list search live here (the product keeps them in the shard's pinned buffers, xsg_objects.h)
 struct DoubleResult {
   std::vector<uint64_t> u64;
   std::vector<uint64_t> line_begin, line_len;
@@ -266,6 +266,17 @@ extern "C" int xsg_result_lines(xsg_shard* s, uint64_t* lengths, char* bytes, ui
     if (lengths) lengths[i] = r.line_len[i];
     if (offsets) offsets[i] = r.line_begin[i];
   }
+  return XSG_OK;
+}
+extern "C" int xsg_result_lines_view(xsg_shard* s, const uint64_t** lengths, const char** bytes, const uint64_t** offsets,
+                                     uint64_t* n, uint64_t* total_bytes) {
+  if (!s || s->last_mode != XSG_LINES) return fail(XSG_ESTATE, "no lines result");
+  DoubleResult& r = *res_of(s);
+  if (lengths) *lengths = r.line_len.data();
+  if (bytes) *bytes = reinterpret_cast<const char*>(r.line_bytes.data());
+  if (offsets) *offsets = r.line_begin.data();
+  if (n) *n = r.line_len.size();
+  if (total_bytes) *total_bytes = r.line_bytes.size();
   return XSG_OK;
 }
 // no RCCL in the double: the fan-out adds on the host (and says so)

@@ -74,6 +74,12 @@ class GpuSearch:
             ls, lo = s.search_lines()
             out["lines"] = ls
             out["lines_offsets"] = lo.tolist()
+            # the zero-copy form of the same result (xsg_result_lines_view) must hold the same lines
+            vl, vb, vo = s.search_lines_view()
+            ends = np.cumsum(vl.astype(np.int64)) if vl.size else np.zeros(0, dtype=np.int64)
+            raw = vb.tobytes()
+            assert [raw[int(e) - int(n):int(e)] for e, n in zip(ends, vl)] == ls, "xsg_result_lines_view: lines differ"
+            assert vo.tolist() == out["lines_offsets"], "xsg_result_lines_view: offsets differ"
         return out
 
 

@@ -1927,17 +1927,16 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     o.line_bytes = s->d_line_bytes.as<uint8_t>();
     HIP_TRY(launch_line_gather(o, st));
     s->line_bytes = nbytes;
-    s->h_line_len.resize(total);
-    s->h_line_off.resize(total + 1);
-    if (total) HIP_TRY(hipMemcpyAsync(s->h_line_len.data(), o.line_len, 8 * total, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(s->h_line_off.data(), o.line_out_off, 8 * (total + 1), hipMemcpyDeviceToHost, st));
+    XSG_TRY(ensure_pinned(&s->hp_line_len, &s->hp_line_len_cap, (size_t)total));  // lengths: the host needs them to count
+    if (total) HIP_TRY(hipMemcpyAsync(s->hp_line_len, o.line_len, 8 * total, hipMemcpyDeviceToHost, st));  // dropped lines
+    s->fast_raw_lines = total;
   }
   HIP_TRY(hipStreamSynchronize(st));
   if (mode == XSG_LINE_INDICES) s->nl_total = s->last_newlines;
   if (mode == XSG_LINES) {
     // lines without a terminating '\n' are not reported (search_wrappers.h:199-202)
     uint64_t n = 0;
-    for (uint64_t i = 0; i < total; ++i) n += s->h_line_len[i] != UINT64_MAX;
+    for (uint64_t i = 0; i < total; ++i) n += s->hp_line_len[i] != UINT64_MAX;
     s->total = n;
   }
   s->last_mode = (int)mode;
@@ -2044,7 +2043,7 @@ extern "C" int xsg_result_lines(xsg_shard* s, uint64_t* lengths, char* bytes, ui
   }
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
-  const uint64_t raw = s->h_line_len.size();
+  const uint64_t raw = s->fast_raw_lines;
   std::vector<uint64_t> goff;
   if (offsets && raw) {
     goff.resize(raw);
@@ -2058,10 +2057,53 @@ extern "C" int xsg_result_lines(xsg_shard* s, uint64_t* lengths, char* bytes, ui
   // dropped (unterminated) lines own no bytes, so the packed bytes are already contiguous
   uint64_t k = 0;
   for (uint64_t i = 0; i < raw; ++i) {
-    if (s->h_line_len[i] == UINT64_MAX) continue;
-    if (lengths) lengths[k] = s->h_line_len[i];
+    if (s->hp_line_len[i] == UINT64_MAX) continue;
+    if (lengths) lengths[k] = s->hp_line_len[i];
     if (offsets) offsets[k] = goff[i];
     ++k;
   }
+  return XSG_OK;
+}
+
+// xs::lines without a copy into caller memory: lengths, offsets and packed bytes in the shard's pinned buffers.
+extern "C" int xsg_result_lines_view(xsg_shard* s, const uint64_t** lengths, const char** bytes, const uint64_t** offsets,
+                                     uint64_t* n_lines, uint64_t* total_bytes) {
+  if (!s) return fail(XSG_EINVAL, "shard is null");
+  if (s->last_mode != XSG_LINES) return fail(XSG_ESTATE, "no XSG_LINES result is pending on this shard");
+  xsg_ctx* c = s->ctx;
+  uint64_t raw = s->fast_raw_lines;
+  if (!s->fast_result) {  // the exact route left bytes and offsets on the device (the lengths are here): two pinned copies
+    if (8 * raw * 2 + s->line_bytes > (16ull << 30)) return fail(XSG_ENOMEM, "the result needs more than 16 GiB of pinned memory");
+    HIP_TRY(hipSetDevice(c->device));
+    XSG_TRY(ensure_pinned(&s->hp_line_bytes, &s->hp_line_bytes_cap, (size_t)s->line_bytes));
+    {
+      size_t have = s->h_result_cap / 8;
+      uint64_t* hp = static_cast<uint64_t*>(s->h_result);
+      XSG_TRY(ensure_pinned(&hp, &have, (size_t)raw));
+      s->h_result = hp;
+      s->h_result_cap = have * 8;
+    }
+    if (raw) HIP_TRY(hipMemcpyAsync(s->h_result, s->d_out_u64.p, 8 * raw, hipMemcpyDeviceToHost, c->stream));
+    if (s->line_bytes) HIP_TRY(hipMemcpyAsync(s->hp_line_bytes, s->d_line_bytes.p, s->line_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->fast_result = true;  // from here on the result lives in the pinned buffers (xsg_result_lines reads them too)
+  }
+  if (s->total != raw) {  // lines without a terminating '\n' are not reported: squeeze them out (they own no bytes)
+    uint64_t* len = s->hp_line_len;
+    uint64_t* off = static_cast<uint64_t*>(s->h_result);
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < raw; ++i) {
+      if (len[i] == UINT64_MAX) continue;
+      len[k] = len[i];
+      off[k] = off[i];
+      ++k;
+    }
+    s->fast_raw_lines = k;
+  }
+  if (lengths) *lengths = s->hp_line_len;
+  if (offsets) *offsets = static_cast<const uint64_t*>(s->h_result);
+  if (bytes) *bytes = reinterpret_cast<const char*>(s->hp_line_bytes);
+  if (n_lines) *n_lines = s->total;
+  if (total_bytes) *total_bytes = s->line_bytes;
   return XSG_OK;
 }

@@ -840,15 +840,14 @@ static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
   Partial p;
   if (mode == XSG_LINES) {
     uint64_t n = 0, nl = 0, nb = 0;
+    const uint64_t* lens = nullptr;
+    const char* bytes = nullptr;
     XSG_TRY(xsg_search(l.shard, mode, &n));
-    XSG_TRY(xsg_result_lines_size(l.shard, &nl, &nb));
-    std::vector<uint64_t> lens(nl);
-    std::vector<char> bytes(nb ? nb : 1);
-    XSG_TRY(xsg_result_lines(l.shard, lens.data(), bytes.data(), nb, nullptr));
+    XSG_TRY(xsg_result_lines_view(l.shard, &lens, &bytes, nullptr, &nl, &nb));  // the shard's pinned buffers: one copy, into the strings
     p.lines.reserve(nl);
     uint64_t at = 0;
     for (uint64_t i = 0; i < nl; ++i) {
-      p.lines.emplace_back(bytes.data() + at, lens[i]);
+      p.lines.emplace_back(bytes + at, lens[i]);
       at += lens[i];
     }
   } else {

@@ -183,7 +183,6 @@ struct xsg_shard {
   uint64_t total = 0;       // elements of the last list search
   uint64_t line_bytes = 0;  // XSG_LINES: packed bytes
   uint64_t last_newlines = 0;  // XSG_LINE_INDICES: '\n' in the shard (for chaining line bases)
-  std::vector<uint64_t> h_line_len, h_line_off;
 
   void release_all() {
     DevBuf* all[] = {&d_chunks, &d_tile_chunk, &d_chunk_tile0, &d_tile_cnt, &d_tile_nl, &d_tile_sum, &d_tile_last,

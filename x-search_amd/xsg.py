@@ -126,6 +126,7 @@ def load():
         "xsg_result_u64_view": (ci, [vp, C.POINTER(_u64p), _u64p]),
         "xsg_result_lines_size": (ci, [vp, _u64p, _u64p]),
         "xsg_result_lines": (ci, [vp, _u64p, vp, u64, _u64p]),
+        "xsg_result_lines_view": (ci, [vp, C.POINTER(_u64p), C.POINTER(C.c_char_p), C.POINTER(_u64p), _u64p, _u64p]),
         "xsg_result_newlines": (ci, [vp, _u64p]),
         "xsg_job_opts_init": (None, [C.POINTER(JobOpts)]),
         "xsg_job_start": (ci, [C.c_char_p, sz, C.c_char_p, C.c_char_p, C.POINTER(JobOpts), C.POINTER(vp)]),
@@ -181,7 +182,7 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
            "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
            "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info", "xsg_regex_dfa_info", "xsg_regex_prefix", "xsg_regex_factor",
-           "xsg_result_u64_view", "xsg_shard_invalidate"]
+           "xsg_result_u64_view", "xsg_shard_invalidate", "xsg_result_lines_view"]
 
 
 def _check(rc):
@@ -391,6 +392,21 @@ class Shard:
             out.append(raw[pos:pos + int(ln)])
             pos += int(ln)
         return out, offs
+
+    def search_lines_view(self):
+        """-> (lengths, packed bytes, global offsets of the line starts): numpy VIEWS of the shard's pinned buffers, valid
+        until the next search on it; no Python object per line"""
+        n = C.c_uint64(0)
+        _check(self._lib.xsg_search(self.h, LINES, C.byref(n)))
+        lens, offs, nl, nb = _u64p(), _u64p(), C.c_uint64(0), C.c_uint64(0)
+        data = C.c_void_p()
+        _check(self._lib.xsg_result_lines_view(self.h, C.byref(lens), C.cast(C.byref(data), C.POINTER(C.c_char_p)), C.byref(offs),
+                                               C.byref(nl), C.byref(nb)))
+        if nl.value == 0:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint64)
+        raw = (np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint8)), shape=(nb.value,)) if nb.value
+               else np.zeros(0, dtype=np.uint8))
+        return (np.ctypeslib.as_array(lens, shape=(nl.value,)), raw, np.ctypeslib.as_array(offs, shape=(nl.value,)))
 
     def scan_kernel_name(self, mode: int) -> str:
         buf = C.create_string_buffer(160)
