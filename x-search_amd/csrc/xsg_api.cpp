@@ -851,9 +851,9 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
       a.pat.hot = 0;
       a.tune = 0;
       a.ntiles = std::min<uint64_t>(a.ntiles, 65536);
-      hipError_t e = launch_scan_count(a, true, false, st);
+      hipError_t e = launch_scan_count(a, true, false, st);  // warm-up, then one timed launch
       if (e == hipSuccess) e = hipEventRecord(ev[0], st);
-      for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_scan_count(a, true, false, st);
+      if (e == hipSuccess) e = launch_scan_count(a, true, false, st);
       if (e == hipSuccess) e = hipEventRecord(ev[1], st);
       if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
       float t = 0;
@@ -881,9 +881,10 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
       a.pat.hot = hot;
       a.tune = 0;
       a.ntiles = std::min<uint64_t>(a.ntiles, 131072);
-      hipError_t e = launch_scan_count(a, true, false, st);  // warm-up (also pulls the code in)
+      // one timed launch per round (0.3 ms on the 2 GiB prefix); the first round warms up first (that pulls the code in)
+      hipError_t e = round == 0 ? launch_scan_count(a, true, false, st) : hipSuccess;
       if (e == hipSuccess) e = hipEventRecord(ev[0], st);
-      for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_scan_count(a, true, false, st);
+      if (e == hipSuccess) e = launch_scan_count(a, true, false, st);
       if (e == hipSuccess) e = hipEventRecord(ev[1], st);
       if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
       float t = 0;
@@ -893,7 +894,7 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
     }
   }
   s->hot = ms[1] < 0.98f * ms[0] ? 1u : 0u;  // the aligned trigger has to win (a wrong "window" costs the plain count 7 %, a wrong "aligned" 2 %)
-  if (getenv("XSG_PROBE_LOG")) fprintf(stderr, "[xsg] hot-filter probe: window %.4f ms, aligned %.4f ms -> %u\n", ms[0], ms[1], s->hot);
+  if (getenv("XSG_PROBE_LOG")) fprintf(stderr, "[xsg] hot-filter probe: window %.4f ms, aligned %.4f ms -> %u (koff %u)\n", ms[0], ms[1], s->hot, s->koff_chosen ? s->koff : 0u);
   // Long patterns also settle their wave stagger here: the default (16) is right for a scan that waits for memory and
   // costs one that waits for its slow path -- which of the two a long pattern is depends on how often its window occurs
   // in THIS text (`detective street` on the bench corpus: 5.4 TB/s with the default, 6.1 without; `Sherlock Holmes` the
@@ -902,15 +903,15 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   if (rc == XSG_OK && c->pat.kind == kLong && c->tune == kTuneAuto && (s->tune_serial != c->pattern_serial || s->tune_probe)) {
     float tms[2] = {1e30f, 1e30f};
     static const uint32_t cand[2] = {kDefaultStagger, 0u};
-    for (int round = 0; round < 2 && rc == XSG_OK; ++round) {
+    for (int round = 0; round < 3 && rc == XSG_OK; ++round) {
       for (int k = 0; k < 2 && rc == XSG_OK; ++k) {
         ScanArgs a = scan_args(s);
         a.pat.hot = s->hot;
         a.tune = cand[k];
         a.ntiles = std::min<uint64_t>(a.ntiles, 131072);
-        hipError_t e = launch_scan_count(a, false, false, st);
+        hipError_t e = round == 0 ? launch_scan_count(a, false, false, st) : hipSuccess;
         if (e == hipSuccess) e = hipEventRecord(ev[0], st);
-        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_scan_count(a, false, false, st);
+        if (e == hipSuccess) e = launch_scan_count(a, false, false, st);
         if (e == hipSuccess) e = hipEventRecord(ev[1], st);
         if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
         float t = 0;
