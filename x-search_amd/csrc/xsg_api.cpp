@@ -951,6 +951,7 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   // dirty until the finish kernel is in the queue behind the scan
   s->cnt_clean = false;
   if (want_lines) s->sum_clean = false;
+  a.lines_only = want_lines && !want_matches;
   HIP_TRY(launch_scan_count(a, scan_nl, want_lines || rx_lines, st));
   FinishArgs f{};
   f.base = s->base;
@@ -1257,6 +1258,7 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   XSG_TRY(choose_hot_filter(s, c->stream));  // time what a real pass of this mode would launch
   XSG_TRY(prepare_tiles(s, want_lines, c->stream));
   ScanArgs a = scan_args(s);
+  a.lines_only = want_lines;  // XSG_COUNT_LINES: what xsg_count launches for it (enqueue_count)
   s->cnt_clean = s->sum_clean = false;  // no finish kernel runs behind these launches
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));

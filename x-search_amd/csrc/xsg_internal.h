@@ -102,6 +102,9 @@ struct ScanArgs {
   uint32_t* tile_nl;                   // '\n' in the tile              (WANT_NL; every tile is written)
   uint32_t* tile_sum;                  // line summary PER WAVE (4 per tile), stored XOR kSumNl (WANT_LINES)
   uint32_t* tile_last;                 // (epoch << 16) | max (match offset + plen) in the tile, relative to the tile start
+  uint32_t lines_only;                 // count pass with line summaries, matches not asked for (xs::count_lines): a kMask1
+                                       // needle skips its match counting (and, where no end-of-chunk walk exists, tile_cnt /
+                                       // tile_last altogether)
   uint32_t* flags;                     // one word per shard, zero at rest: bit 0 = "non-ASCII byte under an ascii_only expression"
   const uint32_t* tile_mask;           // k_rx_scan: if set, only tiles with a non-zero word can hold the start of a line with a
                                        // match (the factor prefilter, xsg_api.cpp: ensure_factor_mask); null: every tile

@@ -293,6 +293,15 @@ struct WaveState {
   uint32_t lcin = 0;      // the line that is open at this point of the span already holds a match (wave-uniform 0 / 1)
   uint32_t lseen = 0;     // the span has shown a newline (wave-uniform)
   uint32_t lF = 0;        // a match start before the span's first newline (wave-uniform)
+  // kMask1: 0 = nobody asked for the number of matches (count_lines alone, ScanArgs::lines_only): `cnt` stays 0
+  uint32_t count_on = 1;  // (wave-uniform)
+  uint32_t track_last = 1;  // kMask1: last_rel is needed (the finish kernel walks the end of the chunk: plen > 1, lossy tail)
+  // kMask1, counting: where the wave's last match ends is worked out ONCE, in the epilogue, from the flags of the last
+  // wave-load that held a match (positions ascend with load, lane, byte: the highest lane of that load holds it) --
+  // per unit that is four register copies where the per-lane bookkeeping took a dozen instructions
+  uint32_t lnf[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  unsigned long long lMm = 0;  // its ballot (wave-uniform); 0 = no match in the span
+  uint32_t lrel0 = 0;          // tile-relative offset of lane 0's unit of that load (wave-uniform)
 };
 
 // ---------------------------------------------------------------------------
@@ -315,55 +324,74 @@ typedef unsigned __int128 u128;
 __device__ __forceinline__ u128 mk128(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
   return ((u128)(((uint64_t)a3 << 32) | a2) << 64) | (u128)(((uint64_t)a1 << 32) | a0);
 }
-__device__ __forceinline__ void lines_flag_step(const uint32_t (&fl)[4], const uint32_t (&src)[8], uint32_t lane, WaveState& st) {
-  const unsigned long long Mm = __ballot((fl[0] | fl[1] | fl[2] | fl[3]) != 0);  // units with a match start
-  if (Mm == 0 && st.lcin == 0 && st.lseen != 0) return;  // nothing here can change the state or the counts
-  const uint32_t n0 = nl_flags(src[0]), n1 = nl_flags(src[1]), n2 = nl_flags(src[2]), n3 = nl_flags(src[3]);
-  const unsigned long long Nm = __ballot((n0 | n1 | n2 | n3) != 0);                // units with a newline
-  if (Mm == 0) {  // no match start in the wave-load: a newline closes the open line
-    if (Nm) st.lcin = 0, st.lseen = 1;
-    return;
-  }
-  const u128 M = mk128(fl[0], fl[1], fl[2], fl[3]), N = mk128(n0, n1, n2, n3);
-  const unsigned long long Gm = __ballot(M > N);  // the unit's last event is a match start (no newline: any match start)
-  // carries of a + b + cin with generate = Gm, propagate = no newline in the unit
-  const unsigned long long a = Gm | ~Nm, b = Gm;
-  const unsigned long long s1 = a + b;
-  const uint32_t c1 = s1 < a ? 1u : 0u;
-  const unsigned long long s2 = s1 + st.lcin;
-  const uint32_t c2 = s2 < s1 ? 1u : 0u;
-  const unsigned long long C = s2 ^ a ^ b;  // bit l: the line open at the start of lane l's unit already holds a match
-  if (!st.lseen) {  // a match start before the span's first newline?  (once per span; scalar)
-    if (Nm == 0) {
-      st.lF = 1;  // (Mm != 0 here)
-    } else {
-      const int i0 = __builtin_ctzll(Nm);
-      uint32_t f = (Mm & ((1ull << i0) - 1ull)) != 0 ? 1u : 0u;
-      const uint32_t fq[4] = {(uint32_t)__builtin_amdgcn_readlane((int)fl[0], i0), (uint32_t)__builtin_amdgcn_readlane((int)fl[1], i0),
-                              (uint32_t)__builtin_amdgcn_readlane((int)fl[2], i0), (uint32_t)__builtin_amdgcn_readlane((int)fl[3], i0)};
-      const uint32_t nq[4] = {(uint32_t)__builtin_amdgcn_readlane((int)n0, i0), (uint32_t)__builtin_amdgcn_readlane((int)n1, i0),
-                              (uint32_t)__builtin_amdgcn_readlane((int)n2, i0), (uint32_t)__builtin_amdgcn_readlane((int)n3, i0)};
-      bool open = true;
+// `nf`: the matcher's flags INVERTED (all ones except bit 7 of a byte where the pattern starts), as it leaves them; the
+// newline flags are computed in the same form (the final NOT of the zero-byte test saved on both: everything below works
+// on the complements -- ~(M | N) = nM & nN;  M > N  <=>  nM < nN;  ~(E - B) = ~E + B = ~E - ~B - 1, a subtraction with
+// the borrow-in set;  firsts = M & ~(E - B) = ~nM & that).
+__device__ __forceinline__ void lines_flag_step(const uint32_t (&nf)[4], const unsigned long long Mm, const uint32_t (&src)[8],
+                                                uint32_t lane, WaveState& st) {
+  // the line state is wave-uniform and lives on the scalar unit (readfirstlane: the compiler is told so)
+  const uint32_t lcin0 = __builtin_amdgcn_readfirstlane(st.lcin), lseen0 = __builtin_amdgcn_readfirstlane(st.lseen);
+  if (Mm != 0 || lcin0 != 0 || lseen0 == 0) {  // otherwise nothing here can change the state or the counts
+    uint32_t nn[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (open) {
-          if (nq[q]) {
-            f |= (fq[q] & ((nq[q] & (0u - nq[q])) - 1u)) != 0 ? 1u : 0u;  // below the unit's first newline
-            open = false;
-          } else {
-            f |= fq[q] != 0 ? 1u : 0u;
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t y = src[q] ^ 0x0a0a0a0au;
+      nn[q] = ((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu;
+    }
+    const unsigned long long Nm = __ballot((nn[0] & nn[1] & nn[2] & nn[3]) != 0xffffffffu);  // units with a newline
+    uint32_t lcin = Nm ? 0u : lcin0;  // no match start in the wave-load: a newline closes the open line
+    if (Mm != 0) {
+      // the unit's last event is a match start (no newline: any match start): M > N as 128-bit numbers = nM < nN, spelled
+      // out as three 64-bit compares into scalar masks (the compiler's own 128-bit compare went through VGPR booleans)
+      const unsigned long long nMh = ((unsigned long long)nf[3] << 32) | nf[2], nMl = ((unsigned long long)nf[1] << 32) | nf[0];
+      const unsigned long long nNh = ((unsigned long long)nn[3] << 32) | nn[2], nNl = ((unsigned long long)nn[1] << 32) | nn[0];
+      const unsigned long long Gm = __ballot(nMh < nNh) | (__ballot(nMh == nNh) & __ballot(nMl < nNl));
+      // carries of a + b + cin with generate = Gm, propagate = no newline in the unit (carry flags, not 64-bit compares:
+      // the scalar unit has no unsigned 64-bit less-than)
+      const unsigned long long a = Gm | ~Nm, b = Gm;
+      const unsigned long long s2 = a + b + lcin0;
+      const unsigned long long C = s2 ^ a ^ b;  // bit l: the line open at the start of lane l's unit already holds a match
+      lcin = (uint32_t)(((a & b) | ((a | b) & ~s2)) >> 63);  // the carry out of bit 63 (majority of a, b, carry-in there)
+      if (lseen0 == 0) {  // a match start before the span's first newline?  (once per span; scalar)
+        uint32_t f = 1;  // no newline yet: any match start (Mm != 0 here)
+        if (Nm != 0) {
+          const int i0 = __builtin_ctzll(Nm);
+          f = (Mm & ((1ull << i0) - 1ull)) != 0 ? 1u : 0u;
+          bool open = true;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t fq = ~(uint32_t)__builtin_amdgcn_readlane((int)nf[q], i0);
+            const uint32_t nq = ~(uint32_t)__builtin_amdgcn_readlane((int)nn[q], i0);
+            const uint32_t below = nq ? (nq & (0u - nq)) - 1u : 0xffffffffu;  // below the unit's first newline
+            f |= (open && (fq & below) != 0) ? 1u : 0u;
+            open = open && nq == 0;
           }
         }
+        st.lF = __builtin_amdgcn_readfirstlane(st.lF | f);
       }
-      st.lF |= f;
-      st.lseen = 1;
+      // ~B: B = one byte above every newline, plus the unit's first byte unless it continues a line that already holds a match
+      uint32_t lowb;  // 0xff where bit `lane` of C is set (the unit's first byte starts no segment), 0x7f otherwise: one select on the scalar mask
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lowb) : "v"(0x7fu), "v"(0xffu), "s"(C));
+      const uint32_t nb0 = (nn[0] << 8) | lowb;
+      const uint32_t nb1 = __builtin_amdgcn_alignbyte(nn[1], nn[0], 3), nb2 = __builtin_amdgcn_alignbyte(nn[2], nn[1], 3);
+      const uint32_t nb3 = __builtin_amdgcn_alignbyte(nn[3], nn[2], 3);
+      const uint32_t e0 = nf[0] & nn[0], e1 = nf[1] & nn[1], e2 = nf[2] & nn[2], e3 = nf[3] & nn[3];  // ~E
+      uint32_t x0, x1, x2, x3;  // ~E - ~B - 1 = ~(E - B): four subtractions, the first with its borrow-in set
+      asm("s_mov_b64 vcc, -1\n\t"
+          "v_subb_co_u32_e32 %0, vcc, %4, %8, vcc\n\t"
+          "v_subb_co_u32_e32 %1, vcc, %5, %9, vcc\n\t"
+          "v_subb_co_u32_e32 %2, vcc, %6, %10, vcc\n\t"
+          "v_subb_co_u32_e32 %3, vcc, %7, %11, vcc"
+          : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+          : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(nb0), "v"(nb1), "v"(nb2), "v"(nb3)
+          : "vcc");
+      st.lacc += (uint32_t)__popc(~nf[0] & x0) + (uint32_t)__popc(~nf[1] & x1) + (uint32_t)__popc(~nf[2] & x2) +
+                 (uint32_t)__popc(~nf[3] & x3);
     }
+    st.lcin = __builtin_amdgcn_readfirstlane(lcin);
+    st.lseen = __builtin_amdgcn_readfirstlane(lseen0 | (Nm != 0 ? 1u : 0u));
   }
-  st.lcin = c1 | c2;
-  const uint32_t start = ((uint32_t)(C >> lane) & 1u) ^ 1u;  // 1 unless the unit's first byte continues a line that already holds a match
-  const u128 B = (N << 8) | (u128)(start << 7);
-  const u128 firsts = M & ~((M | N) - B);
-  st.lacc += (uint32_t)__popcll((unsigned long long)firsts) + (uint32_t)__popcll((unsigned long long)(firsts >> 64));
 }
 
 // One wave-load (1 KiB): `cur` is this lane's 16-byte unit, `nx` the unit that
@@ -375,7 +403,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
                                               uint32_t unit_rel, uint32_t lane, uint64_t L, uint64_t limit,
                                               const PatternDev& P,
                                               const uint8_t* cbase, const uint8_t* s_pat, uint8_t* s_view,
-                                              WaveState& st) {
+                                              WaveState& st, const bool near_limit = true) {
   // ignore_case, patterns of 4+ bytes (LAZY): the hot filter does not need the exact fold.  (x | 0x20) == (p | 0x20)
   // holds for every byte x that folds to the pattern byte p (exactly those when p is a letter, one more byte value
   // otherwise), so the candidate test runs on data OR-ed with 0x20 -- one op per dword instead of fold4's seven --
@@ -425,50 +453,75 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
     const uint32_t c0 = (P.p0 & 0xffu) * 0x01010101u;
     const uint32_t c1 = ((P.p0 >> 8) & 0xffu) * 0x01010101u;
     const uint32_t c2 = ((P.p0 >> 16) & 0xffu) * 0x01010101u;
-    uint32_t fl[4];
+    // nf: the flags INVERTED -- all ones except bit 7 of the byte where the pattern starts (the zero-byte test without its
+    // final NOT: counting and the line arithmetic work on the complement as well, lines_flag_step)
+    // One body per pattern length behind a scalar branch: written as `if (plen >= 2) z |= ...` the compiler turned the
+    // branches into selects and a one-byte needle paid the alignbyte / xor / cndmask work of a three-byte one (13
+    // instructions per dword where 4 do; the empty asm keeps the branch a branch).
+    uint32_t nf[4];
+    if (P.plen == 1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint32_t z = d[q] ^ c0;
-      if (P.plen >= 2) z |= __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) ^ c1;
-      if (P.plen >= 3) z |= __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2) ^ c2;
-      fl[q] = ~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu);
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t z = d[q] ^ c0;
+        nf[q] = ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu;
+      }
+    } else if (P.plen == 2) {
+      asm volatile("");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t z = (d[q] ^ c0) | (__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) ^ c1);
+        nf[q] = ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu;
+      }
+    } else {
+      asm volatile("");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t z = (d[q] ^ c0) | (__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) ^ c1) |
+                           (__builtin_amdgcn_alignbyte(d[q + 1], d[q], 2) ^ c2);
+        nf[q] = ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu;
+      }
     }
-    if (__ballot((fl[0] | fl[1] | fl[2] | fl[3]) != 0) != 0) {
-      if (unit_off + kUnit > limit) {  // positions at or beyond the limit belong to the tail walk
+    bool has = (nf[0] & nf[1] & nf[2] & nf[3]) != 0xffffffffu;
+    unsigned long long Mm = __ballot(has);
+    // positions at or beyond the limit belong to the tail walk.  A span that ends below the limit (wave-uniform; all
+    // but a chunk's last) does not look.
+    if (near_limit && Mm != 0) {
+      asm volatile("");  // (a branch, not a mask on the per-lane test)
+      if (unit_off + kUnit > limit) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint64_t o = unit_off + 4u * q;
-          fl[q] = o >= limit ? 0u : (o + 4u > limit ? fl[q] & ((1u << (8u * (uint32_t)(limit - o))) - 1u) : fl[q]);
+          nf[q] = o >= limit ? 0xffffffffu : (o + 4u > limit ? nf[q] | ~((1u << (8u * (uint32_t)(limit - o))) - 1u) : nf[q]);
         }
+        has = (nf[0] & nf[1] & nf[2] & nf[3]) != 0xffffffffu;
       }
-      if (EMIT) {
+      Mm = __ballot(has);
+    }
+    if (EMIT) {
+      if (Mm != 0) {
         // the emit pass needs the position bits: 0x80-per-byte flags -> one bit per position
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const uint32_t f = fl[q] >> 7;  // bits 0, 8, 16, 24
+          const uint32_t f = ~nf[q] >> 7;  // bits 0, 8, 16, 24
           m |= ((f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u)) << (4 * q);
         }
-      } else {
-        // counting needs no bit mask at all
-        const uint32_t n = (uint32_t)__popc(fl[0]) + (uint32_t)__popc(fl[1]) + (uint32_t)__popc(fl[2]) +
-                           (uint32_t)__popc(fl[3]);
-        if (n) {
-          st.cnt += n;
-          // where the last match ends: only the end-of-chunk walk asks, and a one-byte pattern has none (strchr is
-          // exact everywhere, xsg_tail.h) -- the dozen ops per unit matter for a needle that is in every unit
-          if (P.plen > 1) {
-            const uint32_t hq = fl[3] ? 3u : fl[2] ? 2u : fl[1] ? 1u : 0u;  // highest dword with a match
-            const uint32_t hf = fl[3] ? fl[3] : fl[2] ? fl[2] : fl[1] ? fl[1] : fl[0];
-            st.last_rel = unit_rel + 4u * hq + ((31u - (uint32_t)__clz(hf)) >> 3) + P.plen;
-          } else {
-            st.last_rel = unit_rel + 1u;  // unused by the finish kernel, but it must stay inside the tile (tile_last's tag)
-          }
-        }
-        if (WANT_LINES) lines_flag_step(fl, nlsrc, lane, st);
-        return 0;
       }
-    } else if (!EMIT) {
-      if (WANT_LINES) lines_flag_step(fl, nlsrc, lane, st);  // (fl is all zero)
+    } else {
+      if (Mm != 0) {
+        // counting needs no bit mask at all: popcount(nf) = 32 - matches of the dword, chained through v_bcnt's accumulator
+        if (st.count_on) {
+          const uint32_t n = 128u - ((uint32_t)__popc(nf[0]) + (uint32_t)__popc(nf[1]) + (uint32_t)__popc(nf[2]) + (uint32_t)__popc(nf[3]));
+          st.cnt += n;
+        }
+        // where the last match ends: only the end-of-chunk walk asks, and a one-byte pattern has none (strchr is
+        // exact everywhere, xsg_tail.h); see WaveState::lnf
+        if (st.track_last) {
+          st.lnf[0] = nf[0], st.lnf[1] = nf[1], st.lnf[2] = nf[2], st.lnf[3] = nf[3];
+          st.lMm = Mm;
+          st.lrel0 = __builtin_amdgcn_readfirstlane(unit_rel - lane * kUnit);
+        }
+      }
+      if (WANT_LINES) lines_flag_step(nf, Mm, nlsrc, lane, st);
       return 0;
     }
   } else {
@@ -726,6 +779,11 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   // (The emit pass has only the careful body: it visits few tiles, and what it costs there is the FETCH of its code --
   // 23 KB with both bodies -- by every compute unit that gets a workgroup, not the end-of-chunk checks.)
   WaveState st;
+  if (KIND == kMask1) {
+    st.track_last = (!P.exact_tail && P.plen > 1) ? 1u : 0u;
+    st.count_on = (WANT_LINES && !EMIT && A.lines_only) ? 0u : 1u;
+  }
+  const bool near_limit = wbase + kWaveSpan > limit;  // wave-uniform: only a chunk's last spans reach the tail walk's zone
   if (EMIT && !wave_on) {
     // nothing to decide
   } else if (!EMIT && wbase + kWaveSpan <= L) {
@@ -734,7 +792,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
       st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, false, ALIGNED>(
           v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit,
-          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st);
+          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st, near_limit);
     }
   } else {
 #pragma unroll
@@ -742,7 +800,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
       const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
       st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, true, ALIGNED>(
           v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit,
-          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st);
+          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st, near_limit);
     }
   }
   const uint32_t cnt = st.cnt, nlc = st.nlc;
@@ -774,12 +832,28 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
     // found" at rest (tile_cnt = 0, tile_sum = 0 = "has a newline, no match";
     // k_count_finish puts that back as it consumes them) and only waves that
     // found something else write: no LDS, no barrier, no store on the common path.
-    if (__any(cnt != 0)) {
+    bool wave_has;
+    if (KIND == kMask1) wave_has = st.count_on ? __any(cnt != 0) : st.lMm != 0;  // (lines only, no end-of-chunk walk: nothing to report)
+    else wave_has = __any(cnt != 0);
+    if (wave_has) {
       const uint32_t wc = wave_sum_u32(cnt);
       // the end of the wave's last match, relative to the tile start: it fits 16 bits, so the reduction runs on
       // 32-bit values (a 64-bit max costs three times the lane exchanges; a needle that is dense in the text pays
       // this epilogue in every wave)
-      const uint32_t rel = wave_max_u32(st.last_rel);
+      uint32_t rel;
+      if (KIND == kMask1) {
+        rel = 1u;  // no end-of-chunk walk reads it (it must stay inside the tile: tile_last's tag)
+        if (st.lMm != 0) {  // scalar: the highest lane of the last wave-load with a match
+          const int l = 63 - __builtin_clzll(st.lMm);
+          const uint32_t f3 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[3], l), f2 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[2], l);
+          const uint32_t f1 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[1], l), f0 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[0], l);
+          const uint32_t hq = f3 ? 3u : f2 ? 2u : f1 ? 1u : 0u;
+          const uint32_t hf = f3 ? f3 : f2 ? f2 : f1 ? f1 : f0;
+          rel = st.lrel0 + (uint32_t)l * kUnit + 4u * hq + ((31u - (uint32_t)__builtin_clz(hf)) >> 3) + P.plen;
+        }
+      } else {
+        rel = wave_max_u32(st.last_rel);
+      }
       if (lane == 0) {
         // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
         // cut dense patterns to a third)
