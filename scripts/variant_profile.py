@@ -87,8 +87,10 @@ def main():
         flags = {0: 0, "icase": xsg.FLAG_IGNORE_CASE, "regex": xsg.FLAG_REGEX}[fl]
         ctx.set_pattern(pat.encode(), flags)
         st = sh.tune(modes[mode]) if a.tune else None
-        ms = sh.time_scan_kernel(modes[mode], a.iters)
+        # the count first: the timed launches are then what every call after the first one launches (a needle the first
+        # count found dense runs with a smaller wave stagger, x-search_amd/csrc/xsg_api.cpp: density_serial)
         cm = int(sh.count(modes[mode])[xsg.CTR_LINES if mode == "count_lines" else xsg.CTR_MATCHES])
+        ms = sh.time_scan_kernel(modes[mode], a.iters)
         print(json.dumps({"case": name, "pattern": pat, "flags": fl, "mode": mode, "gib": a.gib, "bytes": nbytes, "lexicon": a.lexicon,
                           "result": cm, "bytes_per_result": round(nbytes / max(cm, 1), 1),
                           "kernel": sh.scan_kernel_name(modes[mode]), "tuned_stagger": st, "ms": round(ms, 4),

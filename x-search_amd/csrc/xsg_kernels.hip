@@ -984,7 +984,9 @@ static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, b
   // memory-bound (7.0 -> 7.36 TB/s with the stagger); the other kinds measured 2-3 % slower with it
   const bool light = (a.pat.kind == kOne || a.pat.kind == kTwo || a.pat.kind == kLong) &&
                      (!a.pat.icase || a.pat.kind == kTwo) && !want_nl && !emit;
-  return !light ? 0u : kDefaultStagger;  // count_lines too: 7.1 TB/s at 4 against 7.46-7.49 at 16 on the 50 GiB shard
+  // count_lines too: 7.1 TB/s at 4 against 7.46-7.49 at 16 on the 50 GiB shard.  A needle an earlier count found dense in
+  // this data (ScanArgs::dense_hint) keeps the slow path busy: 4 (`that`, 191 M matches in 50 GiB: 8.25 ms at 16, 7.66 at 4)
+  return !light ? 0u : a.dense_hint ? 4u : kDefaultStagger;
 }
 
 void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap) {

@@ -120,6 +120,8 @@ struct xsg_shard {
   uint64_t shard_line_base = 0;
   uint32_t tune = xsg::kTuneAuto;  // wave stagger chosen by xsg_shard_tune (kTuneAuto: per variant / ctx override)
   uint64_t tune_serial = 0;        // ... for this ctx->pattern_serial (0: not bound to a pattern)
+  uint64_t density_serial = 0;     // ctx->pattern_serial for which `dense` was observed (a synchronous count's result)
+  bool dense = false;              // ... more than one result per 2 KiB of this data
   bool tune_probe = false;         // `tune` came from choose_hot_filter's two-way probe (re-measured after a re-bind), not from xsg_shard_tune
   // hot filter of the window kinds for (this binding, the ctx's current pattern): measured once, see choose_hot_filter
   uint32_t hot = 0;
