@@ -28,6 +28,7 @@ CASES = {
     "lines_She": ("She", 0, "count_lines"),
     "icase_lines_the": ("the", "icase", "count_lines"),
     "one_that": ("that", 0, "count"),
+    "mask2_Holmes": ("Holmes", 0, "count"),
     "mask2_Sherl": ("Sherl", 0, "count"),
     "long_Sherlock_Holmes": ("Sherlock Holmes", 0, "count"),
     "long_detective_street": ("detective street", 0, "count"),

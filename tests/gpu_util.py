@@ -80,6 +80,12 @@ class GpuSearch:
             raw = vb.tobytes()
             assert [raw[int(e) - int(n):int(e)] for e, n in zip(ends, vl)] == ls, "xsg_result_lines_view: lines differ"
             assert vo.tolist() == out["lines_offsets"], "xsg_result_lines_view: offsets differ"
+        # once more: what a SECOND count launches may differ from the first (a needle the first count found dense runs
+        # with another stagger, a 4..8-byte one byte-parallel: x-search_amd/csrc/xsg_kernels.hip, dense_bytes_route)
+        c2 = s.count(xsg.COUNT_MATCHES | xsg.WITH_NEWLINES)
+        assert [int(x) for x in c2] == [int(x) for x in c], "the second count differs from the first"
+        if "count_lines" in out:
+            assert int(s.count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == out["count_lines"], "the second count_lines differs"
         return out
 
 

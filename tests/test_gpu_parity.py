@@ -157,6 +157,26 @@ def test_text_blocks_all_pattern_kinds(gs, oracle):
             assert_same(got, want, f"exact={exact} pat={p[:20]!r}")
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_dense_needles_of_4_to_8_bytes_take_the_byte_parallel_route(gs, oracle, exact):
+    """A 4..8-byte needle that a first count finds dense (more than one result per 2 KiB) is decided byte-parallel from
+    then on (k_scan<0,...>, 'dense: byte-parallel' in the kernel name): every tag, both tail modes, against the oracle."""
+    blocks = [corpus.text_block(77, i, n, needle=b"Sherlock", needle_rate=0.03) for i, n in enumerate((70001, 16384, 33, 250000))]
+    blocks.append(corpus.small_alphabet(5, 40000, b"abc \n", terminate=True))
+    gs.bind(blocks)
+    for pat in (b"that", b"which", b"Holmes", b"locked ", b"Sherlock", b"abca", b"bcabc", b"aaaa", b"abababab", b"was "):
+        flags = xsg.FLAG_EXACT_TAIL if exact else 0
+        got = gs.all_modes(pat, flags)
+        want = oracle_all_modes(oracle, blocks, pat, exact=exact)
+        assert_same(got, want, f"exact={exact} pat={pat!r}")
+        if got["count_matches"] * 2048 > sum(b.size for b in blocks):
+            assert "byte-parallel" in gs.shard.scan_kernel_name(xsg.COUNT_MATCHES), pat
+    # ignore_case keeps its own route
+    got = gs.all_modes(b"that", xsg.FLAG_IGNORE_CASE)
+    assert_same(got, oracle_all_modes(oracle, blocks, b"that", ignore_case=True), "ignore_case")
+    assert "byte-parallel" not in gs.shard.scan_kernel_name(xsg.COUNT_MATCHES)
+
+
 def test_global_offsets_and_explicit_line_bases(gs, oracle):
     blocks = [corpus.text_block(5, i, 70_000, needle_rate=1e-3) for i in range(3)]
     goffs = [1_000_000, 5_000_000_000, 5_000_070_000]

@@ -472,7 +472,7 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
         const uint32_t z = (d[q] ^ c0) | (__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) ^ c1);
         nf[q] = ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu;
       }
-    } else {
+    } else if (P.plen == 3) {
       asm volatile("");
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -480,6 +480,50 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
                            (__builtin_amdgcn_alignbyte(d[q + 1], d[q], 2) ^ c2);
         nf[q] = ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu;
       }
+    } else {
+      // 4..8 bytes: a needle of the window kinds that an earlier count found DENSE in this data (launch_scan re-routes
+      // it here).  Its hot filter would send every wave-load into the slow path; decided byte-parallel, every position
+      // costs the same whether it matches or not: (plen + 6) instructions per dword -- three shifted views shared by
+      // all pattern bytes, one (view ^ byte) | z per pattern byte, the zero-byte test -- and the scan stays bound by memory.
+      asm volatile("");
+      const uint32_t c3 = (P.p0 >> 24) * 0x01010101u;
+      uint32_t a1[5], a2[5], a3[5], z[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a1[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+        a2[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+        a3[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+        z[q] = (d[q] ^ c0) | (a1[q] ^ c1) | (a2[q] ^ c2) | (a3[q] ^ c3);
+      }
+      if (P.plen > 4) {
+        asm volatile("");
+        const uint32_t c4 = (P.p1 & 0xffu) * 0x01010101u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] |= d[q + 1] ^ c4;
+        if (P.plen > 5) {
+          asm volatile("");
+          const uint32_t c5 = ((P.p1 >> 8) & 0xffu) * 0x01010101u;
+          a1[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z[q] |= a1[q + 1] ^ c5;
+          if (P.plen > 6) {
+            asm volatile("");
+            const uint32_t c6 = ((P.p1 >> 16) & 0xffu) * 0x01010101u;
+            a2[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] |= a2[q + 1] ^ c6;
+            if (P.plen > 7) {
+              asm volatile("");
+              const uint32_t c7 = (P.p1 >> 24) * 0x01010101u;
+              a3[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 3);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) z[q] |= a3[q + 1] ^ c7;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nf[q] = ((z[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z[q] | 0x7f7f7f7fu;
     }
     bool has = (nf[0] & nf[1] & nf[2] & nf[3]) != 0xffffffffu;
     unsigned long long Mm = __ballot(has);
@@ -973,6 +1017,14 @@ static dim3 tile_grid(uint64_t ntiles) {
   return dim3((unsigned)maxx, (unsigned)((ntiles + maxx - 1) / maxx), 1);
 }
 
+// A needle of 4..8 bytes that an earlier count found dense in this data is decided byte-parallel, like the 1..3-byte
+// needles (scan_load, kMask1): no hot filter, no slow path -- every wave-load would take it.  (Not ignore_case: folding
+// every byte up front costs more than the slow path does; XSG_DENSE_BYTES=0 switches the re-routing off.)
+static bool dense_bytes_route(const ScanArgs& a) {
+  static const bool on = [] { const char* e = getenv("XSG_DENSE_BYTES"); return !(e && *e == '0'); }();
+  return on && a.dense_hint && !a.pat.icase && (a.pat.kind == kOne || a.pat.kind == kMask2 || a.pat.kind == kTwo);
+}
+
 static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, bool emit) {
   if (a.tune != kTuneAuto) return a.tune & 0xffu;
   // The stagger only pays where the kernel is memory-bound: it takes issue slots
@@ -1004,17 +1056,20 @@ void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, 
              a.tile_mask ? " (tiles marked by the factor prefilter only)" : "");
     return;
   }
-  const bool window = a.pat.kind == kTwo || a.pat.kind == kLong || a.pat.kind == kClass;
-  const int kind = (a.pat.kind == kClass && a.pat.cls_fast && !a.pat.hot) ? (int)kClassFast : (int)a.pat.kind;
-  snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s, %s> stagger=%u", kind, b[emit ? 0 : want_nl],
-           b[emit ? 0 : want_lines], b[emit], b[a.pat.icase ? 1 : 0], b[window && a.pat.hot ? 1 : 0],
-           pick_stagger(a, want_nl, want_lines, emit));
+  ScanArgs r = a;
+  if (dense_bytes_route(a)) r.pat.kind = kMask1;
+  const bool window = r.pat.kind == kTwo || r.pat.kind == kLong || r.pat.kind == kClass;
+  const int kind = (r.pat.kind == kClass && r.pat.cls_fast && !r.pat.hot) ? (int)kClassFast : (int)r.pat.kind;
+  snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s, %s> stagger=%u%s", kind, b[emit ? 0 : want_nl],
+           b[emit ? 0 : want_lines], b[emit], b[r.pat.icase ? 1 : 0], b[window && r.pat.hot ? 1 : 0],
+           pick_stagger(r, want_nl, want_lines, emit), r.pat.kind != a.pat.kind ? " (dense: byte-parallel)" : "");
 }
 
 static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_lines, bool emit, hipStream_t s) {
   if (a_in.ntiles == 0) return hipSuccess;
   ScanArgs a = a_in;
-  a.tune = pick_stagger(a_in, want_nl, want_lines, emit);
+  if (dense_bytes_route(a)) a.pat.kind = kMask1;
+  a.tune = pick_stagger(a, want_nl, want_lines, emit);
   static const uint64_t emit_grid = [] { const char* e = getenv("XSG_EMIT_GRID"); return e && atoll(e) > 0 ? (uint64_t)atoll(e) : 16384ull; }();
   const dim3 grid = (emit && a.hit_tiles) ? dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(a.hit_cap, 1), emit_grid), 1, 1)
                                          : tile_grid(a.ntiles);
