@@ -394,10 +394,17 @@ def configs_leg(xsg, ctx, orc, shard_t, cap, chunks, plan, blocks, ln, pattern, 
     t0 = time.perf_counter()
     first_idx = sh.search_u64_view(xsg.LINE_INDICES).copy()
     out["line_indices_first_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
-    r = timed_calls(lib, sh, 7)
+    # 21 calls per tag, the median: the first handful of count_lines calls of this leg run up to 25 % slower than the rest
+    # (GPU timestamps: 1.52, 1.92, 1.93, 1.81, 1.74, 1.66, 1.57, 1.57 ms ... for one kernel on the same data, only inside
+    # this process, after seconds of full-rate scanning; scripts/lines_transient.py does not reproduce it on a fresh
+    # process) -- min and max are in the record
+    spread = {}
+    r = timed_calls(lib, sh, 21, spread=spread)
+    out["kernels"] = {"count": sh.scan_kernel_name(xsg.COUNT_MATCHES), "count_lines": sh.scan_kernel_name(xsg.COUNT_LINES)}
     base = r["count"][1]
     for tag, (cnt, ms) in r.items():
-        out["tags"][tag] = {"results": cnt, "ms": round(ms, 4), "gbs": round(nbytes / ms / 1e6, 1),
+        out["tags"][tag] = {"results": cnt, "ms": round(ms, 4), "ms_min": round(spread[tag][0], 4), "ms_max": round(spread[tag][1], 4),
+                            "gbs": round(nbytes / ms / 1e6, 1),
                             "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "vs_count": round(ms / base, 3)}
     # ---- element-wise check
     goffs = sub["global_offset"]

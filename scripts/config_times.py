@@ -21,8 +21,8 @@ import xsg  # noqa: E402
 _u64p = C.POINTER(C.c_uint64)
 
 
-def timed_calls(lib, sh, reps, dense_ok=True):
-    """-> {tag: (results, median ms)} for the shard's current pattern"""
+def timed_calls(lib, sh, reps, dense_ok=True, spread=None):
+    """-> {tag: (results, median ms)} for the shard's current pattern; spread (a dict) receives {tag: (min ms, max ms)}"""
     out = {}
     ctr = np.zeros(xsg.NUM_COUNTERS, dtype=np.uint64)
     n = C.c_uint64(0)
@@ -57,6 +57,8 @@ def timed_calls(lib, sh, reps, dense_ok=True):
             res = fn()
             ts.append(time.perf_counter() - t0)
         out[name] = (res, float(np.median(ts)) * 1e3)
+        if spread is not None:
+            spread[name] = (min(ts) * 1e3, max(ts) * 1e3)
     return out
 
 
