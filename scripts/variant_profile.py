@@ -27,6 +27,8 @@ CASES = {
     "lines_the": ("the", 0, "count_lines"),
     "lines_She": ("She", 0, "count_lines"),
     "icase_lines_the": ("the", "icase", "count_lines"),
+    "icase_the": ("the", "icase", "count"),
+    "icase_Holmes": ("holmes", "icase", "count"),
     "one_that": ("that", 0, "count"),
     "mask2_Holmes": ("Holmes", 0, "count"),
     "mask2_Sherl": ("Sherl", 0, "count"),

@@ -171,10 +171,14 @@ def test_dense_needles_of_4_to_8_bytes_take_the_byte_parallel_route(gs, oracle, 
         assert_same(got, want, f"exact={exact} pat={pat!r}")
         if got["count_matches"] * 2048 > sum(b.size for b in blocks):
             assert "byte-parallel" in gs.shard.scan_kernel_name(xsg.COUNT_MATCHES), pat
-    # ignore_case keeps its own route
-    got = gs.all_modes(b"that", xsg.FLAG_IGNORE_CASE)
-    assert_same(got, oracle_all_modes(oracle, blocks, b"that", ignore_case=True), "ignore_case")
-    assert "byte-parallel" not in gs.shard.scan_kernel_name(xsg.COUNT_MATCHES)
+    # ignore_case: a needle of letters needs no fold ((x | 0x20) == p is exact) and takes the route as well; one with
+    # another byte in it keeps the hot filter and its properly folded slow path
+    for pat, routed in ((b"That", True), (b"HOLMES", True), (b"sHeRlOcK", True), (b"was ", False), (b"E", None), (b"tH", None), (b"She", None), (b"a\n"[:1] + b" ", None)):
+        flags = xsg.FLAG_IGNORE_CASE | (xsg.FLAG_EXACT_TAIL if exact else 0)
+        got = gs.all_modes(pat, flags)
+        assert_same(got, oracle_all_modes(oracle, blocks, pat, exact=exact, ignore_case=True), f"ignore_case exact={exact} pat={pat!r}")
+        if routed is not None and got["count_matches"] * 2048 > sum(b.size for b in blocks):
+            assert ("byte-parallel" in gs.shard.scan_kernel_name(xsg.COUNT_MATCHES)) == routed, pat
 
 
 def test_global_offsets_and_explicit_line_bases(gs, oracle):

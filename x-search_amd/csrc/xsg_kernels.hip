@@ -414,9 +414,22 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
   constexpr bool LAZY = ICASE && KIND != kMask1;
   constexpr uint32_t k20 = 0x20202020u;
   uint32_t r[8] = {cur.x, cur.y, cur.z, cur.w, 0u, 0u, 0u, 0u};
-  uint32_t d[8] = {LAZY ? (cur.x | k20) : ICASE ? fold4(cur.x) : cur.x, LAZY ? (cur.y | k20) : ICASE ? fold4(cur.y) : cur.y,
-                   LAZY ? (cur.z | k20) : ICASE ? fold4(cur.z) : cur.z, LAZY ? (cur.w | k20) : ICASE ? fold4(cur.w) : cur.w,
+  uint32_t d[8] = {LAZY ? (cur.x | k20) : cur.x, LAZY ? (cur.y | k20) : cur.y, LAZY ? (cur.z | k20) : cur.z, LAZY ? (cur.w | k20) : cur.w,
                    0u, 0u, 0u, 0u};
+  // The byte-parallel path under ignore_case: a needle of letters only (PatternDev::lazy_exact; the usual case) needs no
+  // fold either -- (x | 0x20) == p decides it exactly, one instruction per dword where fold4 takes seven.
+  constexpr bool FOLD1 = ICASE && KIND == kMask1;
+  const bool orfold = FOLD1 && P.lazy_exact;  // (wave-uniform)
+  if (FOLD1) {
+    if (orfold) {
+      asm volatile("");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] |= k20;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] = fold4(d[q]);
+    }
+  }
   const uint32_t own0 = d[0], own1 = d[1];  // what the left neighbour reads (never cleared)
   if (CAREFUL) {
     // bytes at or beyond L are not part of the chunk: clear them once
@@ -433,11 +446,11 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
   // the neighbour's first 8 bytes: lane+1's unit, lane 63 takes lane 0 of the next load / the edge
   const uint32_t e0r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.x) : nx.x;
   const uint32_t e1r = nx_is_vgpr ? __builtin_amdgcn_readfirstlane(nx.y) : nx.y;
-  const uint32_t e0 = LAZY ? (e0r | k20) : ICASE ? fold4(e0r) : e0r;
-  const uint32_t e1 = LAZY ? (e1r | k20) : ICASE ? fold4(e1r) : e1r;
+  const uint32_t e0 = (LAZY || orfold) ? (e0r | k20) : ICASE ? fold4(e0r) : e0r;
+  const uint32_t e1 = (LAZY || orfold) ? (e1r | k20) : ICASE ? fold4(e1r) : e1r;
   d[4] = from_next_lane(own0, e0, lane);
   d[5] = from_next_lane(own1, e1, lane);
-  const uint32_t(&nlsrc)[8] = LAZY ? r : d;  // own bytes as the newline tests must see them
+  const uint32_t(&nlsrc)[8] = ICASE ? r : d;  // own bytes as the newline tests must see them (fold4 leaves '\n' alone, OR-ing does not)
   if (is_cls(KIND)) {
     if (P.ascii_only) st.hi |= r[0] | r[1] | r[2] | r[3];  // own bytes (beyond the chunk end: cleared); folding keeps bit 7
   }
@@ -1018,11 +1031,12 @@ static dim3 tile_grid(uint64_t ntiles) {
 }
 
 // A needle of 4..8 bytes that an earlier count found dense in this data is decided byte-parallel, like the 1..3-byte
-// needles (scan_load, kMask1): no hot filter, no slow path -- every wave-load would take it.  (Not ignore_case: folding
-// every byte up front costs more than the slow path does; XSG_DENSE_BYTES=0 switches the re-routing off.)
+// needles (scan_load, kMask1): no hot filter, no slow path -- every wave-load would take it.  (ignore_case only for
+// needles of letters, which need no fold: folding every byte up front costs more than the slow path does;
+// XSG_DENSE_BYTES=0 switches the re-routing off.)
 static bool dense_bytes_route(const ScanArgs& a) {
   static const bool on = [] { const char* e = getenv("XSG_DENSE_BYTES"); return !(e && *e == '0'); }();
-  return on && a.dense_hint && !a.pat.icase && (a.pat.kind == kOne || a.pat.kind == kMask2 || a.pat.kind == kTwo);
+  return on && a.dense_hint && (!a.pat.icase || a.pat.lazy_exact) && (a.pat.kind == kOne || a.pat.kind == kMask2 || a.pat.kind == kTwo);
 }
 
 static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, bool emit) {
