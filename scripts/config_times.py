@@ -51,6 +51,8 @@ def timed_calls(lib, sh, reps, dense_ok=True, spread=None):
              ("line_indices", lambda: u64(xsg.LINE_INDICES)), ("lines", lines)]
     for name, fn in calls:
         res = fn()  # warm (buffers, probes, the cached newline counts)
+        for _ in range(3):  # ... and the clocks: the first launches after a quiet spell run up to 30 % slower (GPU timestamps)
+            fn()
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
@@ -65,7 +67,7 @@ def timed_calls(lib, sh, reps, dense_ok=True, spread=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", type=float, default=10.0)
-    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--patterns", type=str, default="Sherlock,She,the")
     a = ap.parse_args()
     from test_gpu_fullsize import build_shard

@@ -181,6 +181,36 @@ def test_dense_needles_of_4_to_8_bytes_take_the_byte_parallel_route(gs, oracle, 
             assert ("byte-parallel" in gs.shard.scan_kernel_name(xsg.COUNT_MATCHES)) == routed, pat
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_bordered_patterns_whose_occurrences_do_not_overlap_in_the_data(gs, oracle, exact):
+    """`that` has a border (t...t) and could overlap itself ("thathat") -- in text it does not, and the library finds that
+    out once per binding (one count pass per border for the word two overlapping occurrences would spell) and then
+    counts and lists it like a pattern without a border.  Both outcomes, several borders, overlaps only in one chunk,
+    only across the end-of-chunk zone, under ignore_case; every tag against the oracle, and the async entry point."""
+    import torch
+    text = [corpus.text_block(31, i, n, needle_rate=0.01) for i, n in enumerate((90000, 16384 * 3 + 5, 40000))]
+    glued = np.frombuffer(b"so thathat is that and thathathat too\n" * 3, dtype=np.uint8)
+    tail_pair = np.concatenate([text[2][:-1], np.frombuffer(b" thathat", dtype=np.uint8)])  # unterminated, overlap at the very end
+    cases = {
+        "no overlap": text,
+        "overlaps in one chunk": [text[0], np.concatenate([text[1][:30000], glued, text[1][30000:]]), text[2]],
+        "overlap in the end zone": [text[0], tail_pair],
+    }
+    flags = xsg.FLAG_EXACT_TAIL if exact else 0
+    dc = torch.zeros(xsg.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+    for name, blocks in cases.items():
+        gs.bind(blocks)
+        for pat in (b"that", b"else", b"stats", b"abcab", b"aXa", b"was w", b"tt", b"hath", b"e the"):
+            got = gs.all_modes(pat, flags)
+            want = oracle_all_modes(oracle, blocks, pat, exact=exact)
+            assert_same(got, want, f"{name} exact={exact} pat={pat!r}")
+            gs.shard.count_async(xsg.COUNT_MATCHES, 0, dc.data_ptr())  # uses what the synchronous calls established
+            torch.cuda.synchronize()
+            assert int(dc[xsg.CTR_MATCHES]) == want["count_matches"], (name, pat)
+        got = gs.all_modes(b"ThAt", flags | xsg.FLAG_IGNORE_CASE)
+        assert_same(got, oracle_all_modes(oracle, blocks, b"ThAt", exact=exact, ignore_case=True), f"{name} ignore_case")
+
+
 def test_global_offsets_and_explicit_line_bases(gs, oracle):
     blocks = [corpus.text_block(5, i, 70_000, needle_rate=1e-3) for i in range(3)]
     goffs = [1_000_000, 5_000_000_000, 5_000_070_000]

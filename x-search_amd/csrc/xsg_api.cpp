@@ -117,6 +117,7 @@ extern "C" void xsg_ctx_destroy(xsg_ctx* c) {
   c->d_pat.release();
   c->d_pre.release();
   c->d_fac.release();
+  c->d_aux_pat.release();
   delete c;
 }
 
@@ -307,6 +308,7 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   ++c->pattern_serial;
   c->koff_cands.clear();
   c->bordered = false;  // the kernel walks every line as the reference does: what it reports is already non-overlapping
+  c->overlap_words.clear();
   const size_t rev_off = rx_rev_offset((uint32_t)dfa.fwd.size());
   const size_t anc_off = (rev_off + 2 * dfa.rev.size() + 15) & ~(size_t)15;
   const size_t bytes = anc_off + 2 * dfa.anc.size() + 16;
@@ -426,6 +428,7 @@ static int set_class_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t f
   ++c->pattern_serial;
   c->koff_cands.clear();
   c->bordered = xsg::sequence_can_overlap(seq);
+  c->overlap_words.clear();
   std::vector<uint8_t> blob;
   PatternDev P;
   class_fields(ex, icase, &P, &blob);
@@ -560,6 +563,16 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
     pi[i] = (uint32_t)k;
   }
   c->bordered = pi[plen - 1] > 0;
+  c->overlap_words.clear();
+  for (uint32_t b = pi[plen - 1]; b > 0; b = pi[b - 1]) {
+    std::vector<uint8_t> w(p, p + (plen - b));
+    w.insert(w.end(), p, p + plen);
+    if (c->overlap_words.size() == 3 || w.size() > XSG_MAX_PATTERN) {  // `aaaa`: such a needle overlaps itself wherever it is dense
+      c->overlap_words.clear();
+      break;
+    }
+    c->overlap_words.push_back(std::move(w));
+  }
 
   // padded device copy (the long-pattern verify and the tail walk read it)
   XSG_TRY(c->d_pat.ensure(XSG_MAX_PATTERN + 16));
@@ -595,6 +608,7 @@ static void forget_derived(xsg_shard* s) {
   s->fast_dense_serial = 0;                  // a pattern whose lists did not fit the one-sync route
   s->fast_result = false;
   s->density_serial = 0;                     // a pattern found dense in this data (scan_args: stagger)
+  s->overlap_serial = 0;                     // a bordered pattern whose occurrences do not overlap in this data
 }
 
 static int bind_shard(xsg_shard* s, const void* d_base, uint64_t capacity, const xsg_chunk* chunks, uint64_t nchunks) {
@@ -940,9 +954,9 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
 }
 
 static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool want_nl, hipStream_t st,
-                         uint64_t* d_counters, uint64_t* host_counters) {
+                         uint64_t* d_counters, uint64_t* host_counters, const PatternDev* other_pattern = nullptr) {
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
-  XSG_TRY(choose_hot_filter(s, st));
+  if (!other_pattern) XSG_TRY(choose_hot_filter(s, st));
   const uint64_t nchunks = s->chunks.size();
   // kDfa: k_rx_scan counts matching lines directly into tile_cnt (a line is one lane's work): no line summaries
   const bool rx_lines = want_lines && s->ctx->pat.kind == kDfa;
@@ -950,6 +964,11 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   XSG_TRY(prepare_tiles(s, want_lines, st));
   const bool scan_nl = want_nl && !s->nl_cached;  // the per-tile newline counts of this binding may already exist
   ScanArgs a = scan_args(s);
+  if (other_pattern) {  // (ensure_overlap_check: a word derived from the ctx's pattern, nothing measured or remembered for it)
+    a.pat = *other_pattern;
+    a.dense_hint = 0;
+    if (s->tune_serial != 0) a.tune = kTuneAuto;
+  }
   // dirty until the finish kernel is in the queue behind the scan
   s->cnt_clean = false;
   if (want_lines) s->sum_clean = false;
@@ -982,6 +1001,45 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   s->cnt_clean = true;
   if (want_lines) s->sum_clean = true;
   if (scan_nl) s->nl_cached = true;
+  return XSG_OK;
+}
+
+// A literal pattern with a border CAN overlap itself; whether it DOES in the bound data is a property of that data, and in
+// text it nearly never does (`that`: "thathat" would have to occur).  Two occurrences plen - b apart spell the word
+// P[0 .. plen - b) + P, one word per border b: a count pass for each (exact to the end of the chunk, so pairs reaching into
+// the end-of-chunk zone are seen too) settles it once per (binding, pattern).  No such word -> every occurrence is kept by
+// the reference's walk, and the pattern is counted and listed like one without a border: one pass and no list where
+// xs::count took the whole list route (`that` on 10 GiB: 5.3 ms -> one pass).
+static bool overlap_free_known(const xsg_shard* s) {
+  return s->overlap_serial == s->ctx->pattern_serial && s->overlap_free;
+}
+static int ensure_overlap_check(xsg_shard* s) {
+  xsg_ctx* c = s->ctx;
+  if (s->overlap_serial == c->pattern_serial) return XSG_OK;
+  s->overlap_serial = c->pattern_serial;
+  s->overlap_free = false;
+  if (!c->bordered || c->overlap_words.empty() || s->ntiles == 0) return XSG_OK;
+  hipStream_t st = c->stream;
+  XSG_TRY(c->d_aux_pat.ensure(XSG_MAX_PATTERN + 16));
+  for (const std::vector<uint8_t>& w : c->overlap_words) {
+    std::vector<uint8_t> padded(XSG_MAX_PATTERN + 16, 0);
+    memcpy(padded.data(), w.data(), w.size());
+    HIP_TRY(hipMemcpyAsync(c->d_aux_pat.p, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (`padded` leaves scope)
+    PatternDev P{};
+    P.plen = (uint32_t)w.size();
+    window_fields(w.data(), w.size(), pick_filter_window(w.data(), w.size()), &P);
+    P.kind = w.size() < 4 ? kMask1 : w.size() == 4 ? kOne : w.size() < 8 ? kMask2 : w.size() == 8 ? kTwo : kLong;
+    P.d_pat = c->d_aux_pat.as<uint8_t>();
+    P.exact_tail = 1u;
+    P.has_newline = c->pat.has_newline;
+    P.icase = c->pat.icase;
+    XSG_TRY(enqueue_count(s, true, false, false, st, s->d_counters.as<uint64_t>(), s->h_counters, &P));
+    HIP_TRY(hipStreamSynchronize(st));
+    s->table_pending = false;
+    if (s->h_counters[XSG_CTR_MATCHES] != 0) return XSG_OK;  // they do overlap here: the list route decides which are kept
+  }
+  s->overlap_free = true;
   return XSG_OK;
 }
 
@@ -1063,7 +1121,7 @@ extern "C" int xsg_count_async(xsg_shard* s, uint32_t mode, void* stream, uint64
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
   if (m == XSG_COUNT_MATCHES) {
-    if (c->bordered) {
+    if (c->bordered && !overlap_free_known(s)) {  // (known from an earlier synchronous call: this entry point may not wait)
       if (want_nl)
         return fail(XSG_ENOTSUP, "pattern can overlap itself: XSG_WITH_NEWLINES next to its match count needs xsg_count()");
       return enqueue_count_bordered(s, st, d_counters);
@@ -1190,7 +1248,8 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
     }
     // too many candidates for the list route to pay: the count passes below walk every line (k_rx_scan)
   }
-  if (m == XSG_COUNT_MATCHES && c->bordered) {
+  if (m == XSG_COUNT_MATCHES && c->bordered) XSG_TRY(ensure_overlap_check(s));
+  if (m == XSG_COUNT_MATCHES && c->bordered && !overlap_free_known(s)) {
     // greedy non-overlap needs the ordered occurrence list
     XSG_TRY(run_list(s, XSG_MATCH_BYTE_OFFSETS, false));
     note_density(s, s->total);
@@ -1231,7 +1290,8 @@ extern "C" int xsg_count_begin(xsg_shard* s, uint32_t mode) {
   if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
   s->begin_sync_result = false;
   XSG_TRY(ensure_factor_mask(s));
-  if ((m == XSG_COUNT_MATCHES && c->bordered) || (use_prefilter(s) && s->pre_dense_serial != c->pattern_serial)) {  // needs the ordered list: done synchronously, handed out by _end
+  if (m == XSG_COUNT_MATCHES && c->bordered) XSG_TRY(ensure_overlap_check(s));
+  if ((m == XSG_COUNT_MATCHES && c->bordered && !overlap_free_known(s)) || (use_prefilter(s) && s->pre_dense_serial != c->pattern_serial)) {  // needs the ordered list: done synchronously, handed out by _end
     XSG_TRY(xsg_count(s, mode, s->begin_counters));
     s->begin_sync_result = true;
     return XSG_OK;
@@ -1391,7 +1451,7 @@ static bool fast_route_serves(const xsg_shard* s, uint32_t mode, bool outputs) {
   const char* e = getenv("XSG_LIST_FAST");  // 0: every list search takes the exact route (tests, A/B)
   if ((e && *e == '0') || !outputs || s->ntiles == 0 || s->want_nl_total) return false;
   if (c->pat.kind == kDfa) return false;                                // k_rx_scan / the prefilter route: exact route
-  if (mode == XSG_MATCH_BYTE_OFFSETS && c->bordered) return false;      // greedy keep: exact route
+  if (mode == XSG_MATCH_BYTE_OFFSETS && c->bordered && !overlap_free_known(s)) return false;  // greedy keep: exact route
   if (s->chunks.size() > (1u << 20)) return false;                      // the tail prefix is one workgroup's work
   if (s->ntiles >= (1ull << 32)) return false;                          // hit list: uint32 tile numbers
   return s->fast_dense_serial != c->pattern_serial;
@@ -1670,6 +1730,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   s->fast_result = false;
   XSG_TRY(ensure_factor_mask(s));
 
+  if (mode == XSG_MATCH_BYTE_OFFSETS && c->bordered) XSG_TRY(ensure_overlap_check(s));
   // 0. a result that fits the one-sync route's capacities is done there (one stream sync, a third of the launches)
   bool counts_ready = false;
   if (fast_route_serves(s, mode, outputs)) {
@@ -1820,7 +1881,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
 
   if (line_mode) {
     HIP_TRY(launch_line_starts_keep(l, st));
-  } else if (c->bordered) {
+  } else if (c->bordered && !overlap_free_known(s)) {
     // chain heads walk their chains (a few entries at text densities); a chain over the budget -- a long run of one
     // byte searched for `aa` is ONE chain per chunk -- raises a flag and is finished by pointer jumping, log2(length)
     // parallel rounds (xsg_list_kernels.hip: k_greedy_links / k_greedy_jump)

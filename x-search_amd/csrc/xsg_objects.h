@@ -73,6 +73,11 @@ struct xsg_ctx {
   std::vector<uint8_t> pattern;
   uint32_t flags = 0;
   bool bordered = false;  // the pattern can overlap itself
+  // ... a literal one, in these ways: for every border b the word P[0 .. plen - b) + P, the text of two occurrences
+  // plen - b apart.  No such word in the data <=> no two occurrences overlap <=> the greedy walk keeps every occurrence
+  // (xsg_api.cpp: ensure_overlap_check).  Empty: not checkable (a regex, more than three borders, words too long).
+  std::vector<std::vector<uint8_t>> overlap_words;
+  DevBuf d_aux_pat;  // device copy of the word being looked for
   xsg::PatternDev pat{};
   DevBuf d_pat;
   // kDfa with a selective start (xsg_regex.h: RegexDfa::prefix): the class-sequence pattern that finds the candidates
@@ -120,6 +125,8 @@ struct xsg_shard {
   uint64_t shard_line_base = 0;
   uint32_t tune = xsg::kTuneAuto;  // wave stagger chosen by xsg_shard_tune (kTuneAuto: per variant / ctx override)
   uint64_t tune_serial = 0;        // ... for this ctx->pattern_serial (0: not bound to a pattern)
+  uint64_t overlap_serial = 0;     // ctx->pattern_serial for which `overlap_free` was established on this binding
+  bool overlap_free = false;       // ... no two occurrences of the (bordered) pattern overlap anywhere in these chunks
   uint64_t density_serial = 0;     // ctx->pattern_serial for which `dense` was observed (a synchronous count's result)
   bool dense = false;              // ... more than one result per 2 KiB of this data
   bool tune_probe = false;         // `tune` came from choose_hot_filter's two-way probe (re-measured after a re-bind), not from xsg_shard_tune
