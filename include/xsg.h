@@ -249,13 +249,20 @@ int xsg_shard_set_line_base(xsg_shard* shard, uint64_t line_base);
  * least 2^20): if there are more, all four counters read UINT64_MAX and
  * xsg_count (synchronous, sizes exactly, remembers the size) is the call to
  * make; | XSG_WITH_NEWLINES is not served for such a pattern (XSG_ENOTSUP).
+ * For a LITERAL with a border the exception lapses once a synchronous call
+ * (xsg_count, xsg_search) on this binding has established that its occurrences
+ * do not overlap in the bound data -- the usual case in text; see xsg_count.
  * The first pass of a (binding, pattern) on a shard of 64 MiB or more also runs
  * the library's hot-filter probe (a few short launches and one stream sync,
  * DESIGN.md 3.1) -- unless another binding of the same buffer already measured
  * this pattern on this ctx; every later call only enqueues. */
 int xsg_count_async(xsg_shard* shard, uint32_t mode, void* stream, uint64_t* d_counters);
 /* Synchronous, any pattern, XSG_COUNT_MATCHES or XSG_COUNT_LINES
- * (| XSG_WITH_NEWLINES): result in host memory. */
+ * (| XSG_WITH_NEWLINES): result in host memory.  The first XSG_COUNT_MATCHES
+ * (or match-offset search) of a literal with a border on a binding also runs
+ * one count pass per border (at most three) for the word two overlapping
+ * occurrences would spell: if the data holds none, every occurrence is a
+ * match and the pattern is served like one without a border from then on. */
 int xsg_count(xsg_shard* shard, uint32_t mode, uint64_t counters[XSG_NUM_COUNTERS]);
 
 /* Split-phase form of xsg_count for host pipelines: _begin enqueues the pass on the ctx's stream and returns,
