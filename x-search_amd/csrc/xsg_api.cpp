@@ -607,6 +607,7 @@ static void forget_derived(xsg_shard* s) {
   s->mask_serial = s->mask_dense_serial = 0; // regex factor prefilter: tile marks
   s->fast_dense_serial = 0;                  // a pattern whose lists did not fit the one-sync route
   s->fast_result = false;
+  s->line_len_on_device = false;
   s->density_serial = 0;                     // a pattern found dense in this data (scan_args: stagger)
   s->overlap_serial = 0;                     // a bordered pattern whose occurrences do not overlap in this data
 }
@@ -1728,6 +1729,7 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   s->total = 0;
   s->line_bytes = 0;
   s->fast_result = false;
+  s->line_len_on_device = false;
   XSG_TRY(ensure_factor_mask(s));
 
   if (mode == XSG_MATCH_BYTE_OFFSETS && c->bordered) XSG_TRY(ensure_overlap_check(s));
@@ -1995,26 +1997,30 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     XSG_TRY(s->d_line_off.ensure(8 * (total + 1)));
     XSG_TRY(s->d_scan_tmp.ensure(8 * scan_tmp_elems(total + 1)));
     o.line_len = s->d_line_len.as<uint64_t>();
+    XSG_TRY(s->d_dropped.ensure(16));
+    o.dropped = s->d_dropped.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(o.dropped, 0, 4, st));
     HIP_TRY(launch_line_lengths(o, st));
     HIP_TRY(launch_exclusive_scan_u64(o.line_len, s->d_line_off.as<uint64_t>(), total, s->d_scan_tmp.as<uint64_t>(), st));
     uint64_t nbytes = 0;
+    HIP_TRY(hipMemcpyAsync(&s->h_dropped, o.dropped, 4, hipMemcpyDeviceToHost, st));  // (rides on the sync below)
     XSG_TRY(d2h_u64(c, s->d_line_off.as<uint64_t>() + total, &nbytes));
     XSG_TRY(s->d_line_bytes.ensure(std::max<uint64_t>(nbytes, 1)));
     o.line_out_off = s->d_line_off.as<uint64_t>();
     o.line_bytes = s->d_line_bytes.as<uint8_t>();
     HIP_TRY(launch_line_gather(o, st));
     s->line_bytes = nbytes;
-    XSG_TRY(ensure_pinned(&s->hp_line_len, &s->hp_line_len_cap, (size_t)total));  // lengths: the host needs them to count
-    if (total) HIP_TRY(hipMemcpyAsync(s->hp_line_len, o.line_len, 8 * total, hipMemcpyDeviceToHost, st));  // dropped lines
+    // the lengths stay on the device until a result accessor asks (fetch_line_lengths): how many lines lack their
+    // newline -- all the search itself needs to know -- was counted by the kernel (a host loop over 66 M pinned
+    // entries took a third of the call)
+    s->line_len_on_device = true;
     s->fast_raw_lines = total;
   }
   HIP_TRY(hipStreamSynchronize(st));
   if (mode == XSG_LINE_INDICES) s->nl_total = s->last_newlines;
   if (mode == XSG_LINES) {
     // lines without a terminating '\n' are not reported (search_wrappers.h:199-202)
-    uint64_t n = 0;
-    for (uint64_t i = 0; i < total; ++i) n += s->hp_line_len[i] != UINT64_MAX;
-    s->total = n;
+    s->total = total - s->h_dropped;
   }
   s->last_mode = (int)mode;
   return XSG_OK;
@@ -2091,6 +2097,19 @@ extern "C" int xsg_result_newlines(xsg_shard* s, uint64_t* newlines) {
   return XSG_OK;
 }
 
+// xs::lines, exact route: the line lengths into the shard's pinned buffer (once per result)
+static int fetch_line_lengths(xsg_shard* s) {
+  if (!s->line_len_on_device) return XSG_OK;
+  xsg_ctx* c = s->ctx;
+  const uint64_t raw = s->fast_raw_lines;
+  HIP_TRY(hipSetDevice(c->device));
+  XSG_TRY(ensure_pinned(&s->hp_line_len, &s->hp_line_len_cap, (size_t)raw));
+  if (raw) HIP_TRY(hipMemcpyAsync(s->hp_line_len, s->d_line_len.p, 8 * raw, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  s->line_len_on_device = false;
+  return XSG_OK;
+}
+
 extern "C" int xsg_result_lines_size(xsg_shard* s, uint64_t* n_lines, uint64_t* total_bytes) {
   if (!s) return fail(XSG_EINVAL, "shard is null");
   if (s->last_mode != XSG_LINES) return fail(XSG_ESTATE, "no XSG_LINES result is pending on this shard");
@@ -2120,6 +2139,7 @@ extern "C" int xsg_result_lines(xsg_shard* s, uint64_t* lengths, char* bytes, ui
   }
   xsg_ctx* c = s->ctx;
   HIP_TRY(hipSetDevice(c->device));
+  XSG_TRY(fetch_line_lengths(s));
   const uint64_t raw = s->fast_raw_lines;
   std::vector<uint64_t> goff;
   if (offsets && raw) {
@@ -2149,7 +2169,8 @@ extern "C" int xsg_result_lines_view(xsg_shard* s, const uint64_t** lengths, con
   if (s->last_mode != XSG_LINES) return fail(XSG_ESTATE, "no XSG_LINES result is pending on this shard");
   xsg_ctx* c = s->ctx;
   uint64_t raw = s->fast_raw_lines;
-  if (!s->fast_result) {  // the exact route left bytes and offsets on the device (the lengths are here): two pinned copies
+  XSG_TRY(fetch_line_lengths(s));
+  if (!s->fast_result) {  // the exact route left bytes and offsets on the device as well: two more pinned copies
     if (8 * raw * 2 + s->line_bytes > (16ull << 30)) return fail(XSG_ENOMEM, "the result needs more than 16 GiB of pinned memory");
     HIP_TRY(hipSetDevice(c->device));
     XSG_TRY(ensure_pinned(&s->hp_line_bytes, &s->hp_line_bytes_cap, (size_t)s->line_bytes));

@@ -923,6 +923,7 @@ __global__ __launch_bounds__(kBlock) void k_line_lengths(const LineOutArgs A) {
     A.out_u64[i] = g;
     if (A.line_len_host) A.line_len_host[i] = len;
     if (A.out_host) A.out_host[i] = g;
+    if (e < 0 && A.dropped) atomicAdd(A.dropped, 1u);  // (at most one per chunk: its last line)
   }
 }
 

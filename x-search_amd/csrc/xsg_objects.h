@@ -142,7 +142,7 @@ struct xsg_shard {
   DevBuf d_tile_off, d_tile_nl_off, d_scan_tmp;
   DevBuf d_m_pos, d_m_chunk, d_m_ls, d_keep, d_keep_pre;
   DevBuf d_chunk_shift0, d_tail_cnt, d_tail_pos, d_tail_pre;
-  DevBuf d_f_pos, d_f_match, d_f_chunk, d_out_u64, d_line_len, d_line_off, d_line_bytes;
+  DevBuf d_f_pos, d_f_match, d_f_chunk, d_out_u64, d_line_len, d_line_off, d_line_bytes, d_dropped;
   DevBuf d_c_pos, d_c_chunk, d_c_len, d_c_keep, d_c_pre;  // prefilter route of kDfa: the candidates
   DevBuf d_tile_mask;             // factor prefilter of kDfa: tiles in which a line with a factor occurrence starts
   uint64_t mask_serial = 0;       // ... valid for this ctx->pattern_serial on this binding (0: not built)
@@ -181,6 +181,8 @@ struct xsg_shard {
   size_t hp_line_bytes_cap = 0;
   uint64_t fast_dense_serial = 0;  // ctx->pattern_serial whose result did not fit the route's capacity on this binding (0: none)
   bool fast_result = false;        // the pending result lives in the pinned mirrors (h_result, hp_line_*)
+  bool line_len_on_device = false; // xs::lines on the exact route: the lengths have not been copied to hp_line_len yet (fetch_line_lengths)
+  uint32_t h_dropped = 0;          // ... lines without a terminating newline among them (counted by k_line_lengths)
   uint64_t fast_raw_lines = 0;     // xs::lines on that route: entries of hp_line_len (dropped lines included)
   uint64_t nl_total = 0;           // '\n' in the shard, valid while nl_off_cached
 
@@ -197,7 +199,7 @@ struct xsg_shard {
     DevBuf* all[] = {&d_chunks, &d_tile_chunk, &d_chunk_tile0, &d_tile_cnt, &d_tile_nl, &d_tile_sum, &d_tile_last,
                      &d_counters, &d_finish, &d_tile_off, &d_tile_nl_off, &d_scan_tmp, &d_m_pos, &d_m_chunk, &d_m_ls,
                      &d_keep, &d_keep_pre, &d_chunk_shift0, &d_tail_cnt, &d_tail_pos, &d_tail_pre, &d_f_pos, &d_f_match,
-                     &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes, &d_c_pos, &d_c_chunk, &d_c_len, &d_c_keep,
+                     &d_f_chunk, &d_out_u64, &d_line_len, &d_line_off, &d_line_bytes, &d_dropped, &d_c_pos, &d_c_chunk, &d_c_len, &d_c_keep,
                      &d_c_pre, &d_tile_mask, &d_tot, &d_hit, &d_scan2, &d_wmask};
     for (DevBuf* b : all) b->release();
     if (h_stage) (void)hipHostFree(h_stage);
