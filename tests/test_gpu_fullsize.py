@@ -100,6 +100,25 @@ def test_dense_pattern_10gib_count_properties(shard10, oracle):
         assert int(c[xsg.CTR_NEWLINES]) == int(nl_t[s["plan"]].sum())
 
 
+def test_dense_needles_of_4_to_8_bytes_10gib(shard10, oracle):
+    """`that` (a border: the overlap check of its first count; dense: byte-parallel from the second call on) and `Holmes`
+    at full size: the first and the later calls launch different kernels and must agree with the oracle-derived counts."""
+    s = shard10
+    for pat in (b"that", b"Holmes"):
+        s["ctx"].set_pattern(pat)
+        tm = np.array([oracle.count(b, pat, False) for b in s["blocks"]], dtype=np.int64)
+        tlc = np.array([oracle.count(b, pat, True) for b in s["blocks"]], dtype=np.int64)
+        want_m, want_l = int(tm[s["plan"]].sum()), int(tlc[s["plan"]].sum())
+        names = []
+        for _ in range(3):
+            assert int(s["shard"].count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == want_m
+            assert int(s["shard"].count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == want_l
+            names.append(s["shard"].scan_kernel_name(xsg.COUNT_MATCHES))
+        assert "byte-parallel" in names[-1], names
+        got = s["shard"].search_u64_view(xsg.MATCH_BYTE_OFFSETS)
+        assert got.size == want_m and np.all(np.diff(got.astype(np.int64)) >= len(pat))  # sorted, no two overlap
+
+
 def test_config3_shape_50gib_count(oracle):
     """One rank's share of config 3 is covered by bench.py (it checks every timed
     step); here the 50 GiB shard is checked once more through count_lines."""
