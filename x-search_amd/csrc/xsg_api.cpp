@@ -103,6 +103,16 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
     delete c;
     return fail(XSG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
+  // the code objects of the three kernel files, loaded now rather than inside the first search
+  e = warm_scan_kernels(c->stream);
+  if (e == hipSuccess) e = warm_list_kernels(c->stream);
+  if (e == hipSuccess) e = warm_rx_kernels(c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return fail(XSG_EHIP, "loading the kernels failed: %s", hipGetErrorString(e));
+  }
   *out = c;
   return XSG_OK;
 }

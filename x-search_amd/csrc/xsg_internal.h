@@ -325,6 +325,10 @@ hipError_t launch_line_nl_delta(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_indices(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_lengths(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s);
+// one empty launch per kernel file (code object): see xsg_kernels.hip
+hipError_t warm_scan_kernels(hipStream_t s);
+hipError_t warm_list_kernels(hipStream_t s);
+hipError_t warm_rx_kernels(hipStream_t s);
 // one-sync route: the line index of every entry by one wave per entry (sparse lists: no prefix pass over the entries)
 hipError_t launch_line_index_waves(const LineOutArgs& a, hipStream_t s);
 

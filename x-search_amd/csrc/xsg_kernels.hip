@@ -1294,4 +1294,14 @@ hipError_t launch_count_finish(const FinishArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+
+// Loading a code object costs milliseconds the first time one of its kernels is launched: xsg_ctx_create launches this
+// empty kernel of every kernel file, so that the first search of a process does not pay for it (5.5 ms of the first
+// xsg_count, scripts/first_call.py).
+__global__ void k_warm_scan() {}
+hipError_t warm_scan_kernels(hipStream_t s) {
+  hipLaunchKernelGGL(k_warm_scan, dim3(1), dim3(1), 0, s);
+  return hipGetLastError();
+}
+
 }  // namespace xsg
