@@ -317,13 +317,9 @@ struct WaveState {
 //     match, the unit's first byte is NOT a segment start.  "The open line holds a match" is a carry through the 64
 //     units of the wave-load -- generate: the unit's last event is a match (M > N as numbers); propagate: no newline in
 //     the unit -- and the carries of a 64-bit add ARE that recurrence: two ballots, one s_add, one mask back to the lanes.
-// ~50 VALU instructions per unit on top of the matcher's; the wave's summary (F, L, C of xsg_linesum.h) falls out at the
-// end of the span: T = all counted segments, F = a match before the span's first newline, L = the final carry.
+// ~45 VALU instructions per unit on top of the matcher's (DESIGN.md 3.1 has the steps that got it there); the wave's
+// summary (F, L, C of xsg_linesum.h) falls out at the end of the span: T = all counted segments, F = a match before the span's first newline, L = the final carry.
 // ---------------------------------------------------------------------------
-typedef unsigned __int128 u128;
-__device__ __forceinline__ u128 mk128(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
-  return ((u128)(((uint64_t)a3 << 32) | a2) << 64) | (u128)(((uint64_t)a1 << 32) | a0);
-}
 // `nf`: the matcher's flags INVERTED (all ones except bit 7 of a byte where the pattern starts), as it leaves them; the
 // newline flags are computed in the same form (the final NOT of the zero-byte test saved on both: everything below works
 // on the complements -- ~(M | N) = nM & nN;  M > N  <=>  nM < nN;  ~(E - B) = ~E + B = ~E - ~B - 1, a subtraction with
@@ -459,8 +455,8 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
 
   uint32_t m = 0;
   if (KIND == kMask1) {
-    // plen 1..3 -- usually dense in text, so there is no cheap "nothing here" case to
-    // filter for: decide all 16 positions byte-parallel instead.  z has a zero byte at
+    // plen 1..3 (and 4..8-byte needles found dense, launch_scan: dense_bytes_route) -- usually dense in text, so there
+    // is no cheap "nothing here" case to filter for: decide all 16 positions byte-parallel instead.  z has a zero byte at
     // byte i of dword q iff the pattern starts at position 4q+i; fl[q] flags exactly
     // those bytes with 0x80 (5 to 11 ops per dword instead of ~24 for windows + masks).
     const uint32_t c0 = (P.p0 & 0xffu) * 0x01010101u;
