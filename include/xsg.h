@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define XSG_ABI_VERSION 2
+/* 3: xsg_shard_invalidate and xsg_result_lines_view joined (round 3); nothing was removed or changed in meaning */
+#define XSG_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 #define XSG_OK 0
