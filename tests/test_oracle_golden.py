@@ -116,6 +116,30 @@ def test_wrappers_over_reference_primitives_equal_restated(oracle, reference):
         assert got == want
 
 
+def test_restatement_equals_reference_build_on_text_with_dense_and_bordered_needles(oracle, reference):
+    """The inputs on which round 3's device routes act -- needles that are in most lines (`e`, `the`), dense 4..8-byte
+    ones (`that`, `Holmes`), bordered ones with and without overlapping occurrences in the data -- pinned on the CPU
+    side: the restatement against the reference's own compiled primitives, and the wrappers over both."""
+    import corpus
+    texts = [corpus.text_block(91, i, n, needle_rate=0.02) for i, n in enumerate((20011, 4096, 333, 65536))]
+    glued = np.frombuffer(b"so thathat is that and thathathat too\nelselse stats statstats\n" * 4, dtype=np.uint8)
+    texts.append(np.concatenate([texts[1][:1000], glued, texts[1][1000:]]))
+    texts.append(texts[0][:-1].copy())  # unterminated
+    for data in texts:
+        for p in (b"e", b"th", b"the", b"that", b"else", b"stats", b"Holmes", b"Sherlock", b"was w", b"tt", b"e the", b"aXa"):
+            assert oracle.count_matches(p, data) == reference.count_matches(p, data), p
+            assert oracle.count_matching_lines(p, data) == reference.count_matching_lines(p, data), p
+            got = (oracle.byte_offsets_match(data, p).tolist(), oracle.byte_offsets_line(data, p).tolist(),
+                   oracle.count(data, p, True), oracle.count(data, p, False), [x.tolist() for x in oracle.lines_spans(data, p)])
+            oracle.use_reference_primitives(reference)
+            try:
+                want = (oracle.byte_offsets_match(data, p).tolist(), oracle.byte_offsets_line(data, p).tolist(),
+                        oracle.count(data, p, True), oracle.count(data, p, False), [x.tolist() for x in oracle.lines_spans(data, p)])
+            finally:
+                oracle.use_reference_primitives(None)
+            assert got == want, p
+
+
 def test_chunk_driver_matches_single_thread(oracle):
     import corpus
     blocks = [corpus.text_block(3, i, 200_000 + 1000 * i, needle_rate=1e-3) for i in range(7)]
