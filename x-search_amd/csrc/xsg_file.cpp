@@ -1471,8 +1471,11 @@ extern "C" int xsg_host_lines(xsg_host_searcher* hs, const void* data, uint64_t 
   XSG_TRY(host_slot_acquire(hs, &l.s));
   XSG_TRY(host_stage(l.s, data, len));
   uint64_t cnt = 0, nl = 0, nb = 0;
+  const uint64_t* vlens = nullptr;
+  const char* vbytes = nullptr;
   XSG_TRY(xsg_search(l.s->shard, XSG_LINES, &cnt));
-  XSG_TRY(xsg_result_lines_size(l.s->shard, &nl, &nb));
+  // out of the shard's pinned buffers (a large result arrives there by pinned copies, not by a pageable D2H)
+  XSG_TRY(xsg_result_lines_view(l.s->shard, &vlens, &vbytes, nullptr, &nl, &nb));
   uint64_t* lens = static_cast<uint64_t*>(malloc(8 * std::max<uint64_t>(nl, 1)));
   char* buf = static_cast<char*>(malloc(std::max<uint64_t>(nb, 1)));
   if (!lens || !buf) {
@@ -1480,12 +1483,8 @@ extern "C" int xsg_host_lines(xsg_host_searcher* hs, const void* data, uint64_t 
     free(buf);
     return fail(XSG_ENOMEM, "host allocation failed");
   }
-  const int r = xsg_result_lines(l.s->shard, lens, buf, nb, nullptr);
-  if (r != XSG_OK) {
-    free(lens);
-    free(buf);
-    return r;
-  }
+  if (nl) memcpy(lens, vlens, 8 * nl);
+  if (nb) memcpy(buf, vbytes, nb);
   *lengths = lens;
   *bytes = buf;
   *n = nl;
