@@ -44,6 +44,8 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 const char* last_error_message() { return g_err; }
+bool trace_on() { return false; }
+void trace(const char*, ...) {}
 }  // namespace xsg
 using xsg::fail;
 extern "C" const char* xsg_last_error(void) { return g_err; }

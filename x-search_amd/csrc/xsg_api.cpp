@@ -4,6 +4,7 @@
 // compute entry point needs a HIP device and fails with XSG_ENODEV/XSG_EHIP
 // otherwise.
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -34,6 +35,21 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 const char* last_error_message() { return g_err; }
+
+static const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
+bool trace_on() {
+  static const bool on = [] { const char* e = getenv("XSG_TRACE"); return e && *e && *e != '0'; }();
+  return on;
+}
+void trace(const char* fmt, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_loaded).count();
+  fprintf(stderr, "[xsg +%10.3f ms] %s\n", ms, buf);
+}
 }  // namespace xsg
 
 extern "C" int xsg_abi_version(void) { return XSG_ABI_VERSION; }
@@ -56,7 +72,9 @@ extern "C" const char* xsg_last_error(void) { return g_err; }
 extern "C" int xsg_device_count(int* count) {
   if (!count) return fail(XSG_EINVAL, "count is null");
   int n = 0;
+  XSG_TRACE("hipGetDeviceCount ...");
   hipError_t e = hipGetDeviceCount(&n);
+  XSG_TRACE("hipGetDeviceCount -> %d", n);
   if (e != hipSuccess) {
     *count = 0;
     return fail(XSG_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
@@ -73,11 +91,13 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
   if (n <= 0) return fail(XSG_ENODEV, "no HIP device visible");
   if (device < 0 || device >= n) return fail(XSG_ENODEV, "device %d out of range (0..%d)", device, n - 1);
   HIP_TRY(hipSetDevice(device));
+  XSG_TRACE("ctx_create: hipSetDevice(%d) done", device);
   xsg_ctx* c = new (std::nothrow) xsg_ctx();
   if (!c) return fail(XSG_ENOMEM, "host allocation failed");
   c->device = device;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
+  XSG_TRACE("ctx_create: device properties");
   if (e != hipSuccess) {
     delete c;
     return fail(XSG_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
@@ -103,11 +123,16 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
     delete c;
     return fail(XSG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
+  XSG_TRACE("ctx_create: stream");
   // the code objects of the three kernel files, loaded now rather than inside the first search
   e = warm_scan_kernels(c->stream);
+  XSG_TRACE("ctx_create: scan kernels launched");
   if (e == hipSuccess) e = warm_list_kernels(c->stream);
+  XSG_TRACE("ctx_create: list kernels launched");
   if (e == hipSuccess) e = warm_rx_kernels(c->stream);
+  XSG_TRACE("ctx_create: rx kernels launched");
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  XSG_TRACE("ctx_create: warm-up synchronised");
   if (e != hipSuccess) {
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -613,14 +613,17 @@ static int slot_prepare(xsg_job* j, Slot** out) {
     if (!l.ctx) {
       XSG_TRY(xsg_ctx_create(j->opts.device, &l.ctx));
       XSG_TRY(xsg_shard_create(l.ctx, nullptr, 0, nullptr, 0, &l.shard));
+      XSG_TRACE("slot: lane %d ctx + shard created", k);
     }
     XSG_TRY(xsg_set_pattern(l.ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
+    XSG_TRACE("slot: lane %d pattern set", k);
     if (need > l.cap) {
       if (l.dev) (void)hipFree(l.dev);
       l.dev = nullptr;
       l.cap = 0;
       HIP_TRY(hipMalloc(&l.dev, need));
       l.cap = need;
+      XSG_TRACE("slot: lane %d device buffer %llu bytes", k, (unsigned long long)need);
     }
   }
   *out = own.release();
@@ -646,6 +649,7 @@ static int buf_prepare(xsg_job* j, HostBuf** out) {
     HIP_TRY(hipSetDevice(j->opts.device));
     HIP_TRY(hipHostMalloc(&own->pinned, need, hipHostMallocDefault));
     own->cap = need;
+    XSG_TRACE("pinned buffer %llu bytes", (unsigned long long)need);
   }
   if (j->compression != XSG_COMPRESSION_NONE && own->staging.size() < j->max_actual) {
     try {
@@ -986,6 +990,7 @@ static void worker_main(xsg_job* j) {
   j->stats.chunks += chunks;
   j->stats.seconds_device += t_dev;
   if (--j->active == 0) {  // the last worker closes the result (Searcher.h:116-119)
+    XSG_TRACE("job: last worker done (%llu chunks)", (unsigned long long)j->stats.chunks);
     j->finished = true;
     j->stats.seconds_total = seconds_since(j->t_start);
     j->cv.notify_all();
@@ -1019,6 +1024,7 @@ extern "C" int xsg_job_start(const void* pattern, size_t plen, const char* file_
 
 static int job_start_impl(const void* pattern, size_t plen, const char* file_path, const char* meta_file_path,
                           const xsg_job_opts* opts, xsg_job** out) {
+  XSG_TRACE("job: start");
   if (!out) return fail(XSG_EINVAL, "out is null");
   *out = nullptr;
   if (!opts || opts->struct_size != sizeof(xsg_job_opts)) return fail(XSG_EINVAL, "bad xsg_job_opts (struct_size)");
@@ -1084,6 +1090,7 @@ static int job_start_impl(const void* pattern, size_t plen, const char* file_pat
     return r;
   }
   j->stats.plan_chunks = j->plan.size();
+  XSG_TRACE("job: plan of %zu chunks, device count %d", j->plan.size(), ndev);
   if (opts->chunk_begin || opts->chunk_end) {
     if (opts->chunk_begin > opts->chunk_end || opts->chunk_end > j->plan.size()) {
       close(j->fd);
@@ -1118,6 +1125,7 @@ static int job_start_impl(const void* pattern, size_t plen, const char* file_pat
   }
   j->active = nworkers;
   j->readers_running = nreaders;
+  XSG_TRACE("job: %d pinned buffers ready, starting %d readers + %d workers", nbufs, nreaders, nworkers);
   xsg_job* raw = j.release();
   for (int t = 0; t < nreaders; ++t) raw->threads.emplace_back(reader_main, raw);
   for (int t = 0; t < nworkers; ++t) raw->threads.emplace_back(worker_main, raw);

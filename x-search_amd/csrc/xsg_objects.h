@@ -13,7 +13,15 @@
 namespace xsg {
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 const char* last_error_message();
+// XSG_TRACE=1: timestamped marks on stderr ("[xsg +12.345 ms] label"), milliseconds since the library was loaded --
+// where the time of a process's first search goes (HIP start-up, code objects, pinned ring, device buffers, first chunk).
+bool trace_on();
+void trace(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 }  // namespace xsg
+#define XSG_TRACE(...)                      \
+  do {                                      \
+    if (xsg::trace_on()) xsg::trace(__VA_ARGS__); \
+  } while (0)
 
 #define HIP_TRY(expr)                                                                                        \
   do {                                                                                                       \
