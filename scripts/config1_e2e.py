@@ -38,7 +38,7 @@ for _ in range(5):
 print(json.dumps({"what": "CPU reference, 1 thread, 6 chunks in RAM", "ms": round(min(ts) * 1e3, 2),
                   "gib_s": round(data.size / min(ts) / 2**30, 2), "count": got}), flush=True)
 try:
-    for th, rd, chunk in ((1, 1, 16 << 20), (2, 2, 16 << 20), (2, 4, 16 << 20), (2, 6, 16 << 20), (2, 6, 4 << 20), (3, 8, 4 << 20),
+    for th, rd, chunk in ((1, 1, 16 << 20), (1, 2, 16 << 20), (2, 2, 16 << 20), (2, 4, 16 << 20), (2, 6, 16 << 20), (2, 6, 4 << 20), (3, 8, 4 << 20),
                           (4, 8, 2 << 20)):
         ms = []
         for rep in range(8):

@@ -47,8 +47,12 @@ void trace(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_loaded).count();
-  fprintf(stderr, "[xsg +%10.3f ms] %s\n", ms, buf);
+  const auto now = std::chrono::steady_clock::now();
+  const double ms = std::chrono::duration<double, std::milli>(now - g_loaded).count();
+  // (the second figure is CLOCK_MONOTONIC in seconds: a launcher that prints the same clock before it starts the
+  // process and after it has exited -- scripts/cli_trace.py -- shows what lies before the library is loaded and behind
+  // the last mark: the process's start and its teardown)
+  fprintf(stderr, "[xsg +%10.3f ms | %.6f] %s\n", ms, std::chrono::duration<double>(now.time_since_epoch()).count(), buf);
 }
 }  // namespace xsg
 
@@ -124,13 +128,17 @@ extern "C" int xsg_ctx_create(int device, xsg_ctx** out) {
     return fail(XSG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
   XSG_TRACE("ctx_create: stream");
-  // the code objects of the three kernel files, loaded now rather than inside the first search
+  // The code object of the scan kernels (3.5 MB, ~5 ms the first time in a process) is loaded now rather than inside
+  // the first search -- every search launches one of them.  The list kernels' (1.1 ms) and the automaton route's
+  // (0.5 ms) are loaded by the first search that needs them: a count of a literal needs neither
+  // (profiles/r04_cli_start.txt; XSG_WARM_ALL=1 loads all three here, as round 3 did).
   e = warm_scan_kernels(c->stream);
   XSG_TRACE("ctx_create: scan kernels launched");
-  if (e == hipSuccess) e = warm_list_kernels(c->stream);
-  XSG_TRACE("ctx_create: list kernels launched");
-  if (e == hipSuccess) e = warm_rx_kernels(c->stream);
-  XSG_TRACE("ctx_create: rx kernels launched");
+  static const bool warm_all = [] { const char* w = getenv("XSG_WARM_ALL"); return w && *w == '1'; }();
+  if (warm_all) {
+    if (e == hipSuccess) e = warm_list_kernels(c->stream);
+    if (e == hipSuccess) e = warm_rx_kernels(c->stream);
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   XSG_TRACE("ctx_create: warm-up synchronised");
   if (e != hipSuccess) {
@@ -781,7 +789,10 @@ extern "C" int xsg_shard_set_line_base(xsg_shard* s, uint64_t line_base) {
 // ---------------------------------------------------------------------------
 // counting
 // ---------------------------------------------------------------------------
-static ScanArgs scan_args(xsg_shard* s) {
+static uint32_t scan_variant(bool want_nl, bool want_lines) { return (want_nl ? 1u : 0u) | (want_lines ? 2u : 0u); }
+
+// `variant`: which k_scan instantiation the arguments are for (scan_variant): it selects the measured hot filter
+static ScanArgs scan_args(xsg_shard* s, uint32_t variant = 0) {
   ScanArgs a{};
   a.base = s->base;
   a.chunks = s->d_chunks.as<ChunkDev>();
@@ -797,7 +808,8 @@ static ScanArgs scan_args(xsg_shard* s) {
   a.epoch = s->epoch;
   a.dense_hint = (s->density_serial == s->ctx->pattern_serial && s->dense) ? 1u : 0u;
   a.pat = s->ctx->pat;
-  a.pat.hot = s->ctx->hot_env >= 0 ? (uint32_t)s->ctx->hot_env : (s->hot_serial == s->ctx->pattern_serial ? s->hot : 0u);
+  a.pat.hot = s->ctx->hot_env >= 0 ? (uint32_t)s->ctx->hot_env
+              : (s->hot_serial == s->ctx->pattern_serial && ((s->hot_known >> variant) & 1u)) ? s->hot_v[variant] : 0u;
   if (a.pat.kind == kLong && s->hot_serial == s->ctx->pattern_serial && s->koff_chosen)
     window_fields(s->ctx->pattern.data(), s->ctx->pattern.size(), s->koff, &a.pat);  // the window measured best on this shard
   a.tile_cnt = s->d_tile_cnt.as<uint32_t>();
@@ -859,21 +871,44 @@ static bool is_window_kind(uint32_t k) { return k == kTwo || k == kLong || k == 
 // The window kinds have two hot filters (k_scan<..., ALIGNED>): the aligned-dword trigger does half the VALU work
 // but looks at 4 bytes of the window where the window filter looks at 8, so text in which the window's 4-byte
 // pieces are common (a window made of words of the text) sends it into the slow path all the time.  Which one is
-// faster is a property of (pattern, data): measured once per binding and pattern on a prefix of the shard (up to
-// 2 GiB, a few launches of a fraction of a millisecond and one sync), remembered until the shard is re-bound or the
-// pattern changes.  The probe runs the newline-counting variant whatever the caller's mode: it is the
-// VALU-heaviest, so it shows a difference that the plain count -- HBM-bound with either filter -- hides, and a
-// filter with less ALU work is the right one for the light variants too.  Shards under 64 MiB keep the window
-// filter (their scans take microseconds either way); XSG_HOT pins the choice.
-static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
+// faster is a property of (pattern, data, kernel variant): measured once per binding, pattern and VARIANT on a prefix
+// of the shard (up to 2 GiB, a few launches of a fraction of a millisecond and one sync), remembered until the shard
+// is re-bound or the pattern changes.  The probe times the variant the caller's pass is about to launch (round 3
+// timed the newline-counting variant for every mode: the VALU-heaviest shows the largest difference -- but the answer
+// differs: on the bench corpus the aligned trigger wins the count + newlines pass by 12 % and loses the plain count,
+// which waits for memory with either filter, by 1.7 %).  Shards under 64 MiB keep the window filter (their scans
+// take microseconds either way); XSG_HOT pins the choice.
+static int choose_hot_filter(xsg_shard* s, hipStream_t st, bool want_nl = false, bool want_lines = false) {
   xsg_ctx* c = s->ctx;
-  if (!is_window_kind(c->pat.kind) || c->hot_env >= 0 || s->hot_serial == c->pattern_serial) return XSG_OK;
-  s->hot = 0;
-  s->koff_chosen = false;
-  s->hot_serial = c->pattern_serial;
-  if (s->total_bytes < c->probe_min_bytes || s->ntiles == 0) return XSG_OK;
-  if (c->memo.serial == c->pattern_serial && c->memo.base == s->base && c->memo.total_bytes == s->total_bytes) {
-    s->hot = c->memo.hot;  // measured on this buffer for this pattern by another binding
+  if (!is_window_kind(c->pat.kind) || c->hot_env >= 0) return XSG_OK;
+  const uint32_t v = scan_variant(want_nl, want_lines);
+  const bool first = s->hot_serial != c->pattern_serial;  // nothing measured for this pattern on this binding yet
+  if (first) {
+    s->hot_known = 0;
+    memset(s->hot_v, 0, sizeof s->hot_v);
+    s->koff_chosen = false;
+    s->hot_serial = c->pattern_serial;
+  }
+  if ((s->hot_known >> v) & 1u) return XSG_OK;
+  if (s->total_bytes < c->probe_min_bytes || s->ntiles == 0) {
+    s->hot_known = 0xfu;  // too small to measure: the window filter for every variant
+    return XSG_OK;
+  }
+  // Another binding of this buffer may have measured this pattern already (a caller that creates a shard per search).
+  // The memo is keyed by address, size, chunk count and a content tag -- the first and last 16 bytes of the text: an
+  // allocator that hands a freed address out again for OTHER data of the same size does not inherit the choice.
+  bool memo_hit = c->memo.serial == c->pattern_serial && c->memo.base == s->base && c->memo.total_bytes == s->total_bytes &&
+                  c->memo.nchunks == s->chunks.size();
+  uint64_t tag[4] = {0, 0, 0, 0};
+  {
+    const xsg_chunk& c0 = s->chunks.front();
+    const xsg_chunk& c1 = s->chunks.back();
+    HIP_TRY(hipMemcpyAsync(tag, s->base + c0.offset, std::min<uint64_t>(16, c0.length), hipMemcpyDeviceToHost, st));
+    if (c1.length >= 16) HIP_TRY(hipMemcpyAsync(tag + 2, s->base + c1.offset + c1.length - 16, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memo_hit = memo_hit && memcmp(tag, c->memo.tag, sizeof tag) == 0;
+  }
+  if (memo_hit && first) {  // measured on this buffer for this pattern by another binding
     s->koff = c->memo.koff;
     s->koff_chosen = c->memo.koff_chosen;
     if (c->memo.tune_probe && (s->tune_serial != c->pattern_serial || s->tune_probe)) {
@@ -881,11 +916,17 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
       s->tune_serial = s->tune == kTuneAuto ? 0 : c->pattern_serial;
       s->tune_probe = true;
     }
+  }
+  if (memo_hit && ((c->memo.hot_known >> v) & 1u)) {
+    s->hot_v[v] = c->memo.hot_v[v];
+    s->hot_known |= (uint8_t)(1u << v);
     return XSG_OK;
   }
-  XSG_TRY(ensure_tile_nl(s));
-  XSG_TRY(prepare_tiles(s, false, st));
+  const bool settle_window = first && !memo_hit;  // the filter window and the stagger of a long pattern: once per pattern
+  if (want_nl) XSG_TRY(ensure_tile_nl(s));
+  XSG_TRY(prepare_tiles(s, want_lines, st));
   s->cnt_clean = false;  // no finish kernel behind these launches
+  if (want_lines) s->sum_clean = false;
   hipEvent_t ev[2];
   for (hipEvent_t& e : ev) HIP_TRY(hipEventCreate(&e));
   float ms[2] = {1e30f, 1e30f};
@@ -893,8 +934,7 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   // Long patterns first settle WHICH 8 bytes the hot loop looks for: how often a window occurs in this text decides
   // how often the slow path runs (`detective street` on the bench corpus: "ective s" every 4 KiB, "ve stree" every
   // 11 KiB), and no static letter table knows the text.  Each candidate: the window filter on a 1 GiB prefix.
-  s->koff_chosen = false;
-  if (c->pat.kind == kLong && c->koff_cands.size() > 1) {
+  if (settle_window && c->pat.kind == kLong && c->koff_cands.size() > 1) {
     float best = 1e30f;
     uint32_t best_koff = c->koff_cands[0];
     for (uint32_t koff : c->koff_cands) {
@@ -934,9 +974,9 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
       a.tune = 0;
       a.ntiles = std::min<uint64_t>(a.ntiles, 131072);
       // one timed launch per round (0.3 ms on the 2 GiB prefix); the first round warms up first (that pulls the code in)
-      hipError_t e = round == 0 ? launch_scan_count(a, true, false, st) : hipSuccess;
+      hipError_t e = round == 0 ? launch_scan_count(a, want_nl, want_lines, st) : hipSuccess;
       if (e == hipSuccess) e = hipEventRecord(ev[0], st);
-      if (e == hipSuccess) e = launch_scan_count(a, true, false, st);
+      if (e == hipSuccess) e = launch_scan_count(a, want_nl, want_lines, st);
       if (e == hipSuccess) e = hipEventRecord(ev[1], st);
       if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
       float t = 0;
@@ -945,20 +985,26 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
       ms[hot] = std::min(ms[hot], t);
     }
   }
-  s->hot = ms[1] < 0.98f * ms[0] ? 1u : 0u;  // the aligned trigger has to win (a wrong "window" costs the plain count 7 %, a wrong "aligned" 2 %)
-  if (getenv("XSG_PROBE_LOG")) fprintf(stderr, "[xsg] hot-filter probe: window %.4f ms, aligned %.4f ms -> %u (koff %u)\n", ms[0], ms[1], s->hot, s->koff_chosen ? s->koff : 0u);
+  // the aligned trigger has to win: by 2 % where the variant is VALU-bound and the stakes are 12 %; by any margin the
+  // probe can see where the kernel waits for memory (the plain count: 1.7 % either way, measured with the stagger off)
+  s->hot_v[v] = ms[1] < (v == 0 ? 0.995f : 0.98f) * ms[0] ? 1u : 0u;
+  s->hot_known |= (uint8_t)(1u << v);
+  static const bool probe_log = getenv("XSG_PROBE_LOG") != nullptr;
+  if (probe_log)
+    fprintf(stderr, "[xsg] hot-filter probe (variant nl=%d lines=%d): window %.4f ms, aligned %.4f ms -> %u (koff %u)\n", (int)want_nl,
+            (int)want_lines, ms[0], ms[1], (unsigned)s->hot_v[v], s->koff_chosen ? s->koff : 0u);
   // Long patterns also settle their wave stagger here: the default (16) is right for a scan that waits for memory and
   // costs one that waits for its slow path -- which of the two a long pattern is depends on how often its window occurs
   // in THIS text (`detective street` on the bench corpus: 5.4 TB/s with the default, 6.1 without; `Sherlock Holmes` the
   // other way round).  The plain count with the window and filter just chosen, stagger 0 against the default, on the
   // same prefix; a tie keeps the default.  xsg_shard_tune (all staggers, full size) overrides it.
-  if (rc == XSG_OK && c->pat.kind == kLong && c->tune == kTuneAuto && (s->tune_serial != c->pattern_serial || s->tune_probe)) {
+  if (rc == XSG_OK && settle_window && c->pat.kind == kLong && c->tune == kTuneAuto && (s->tune_serial != c->pattern_serial || s->tune_probe)) {
     float tms[2] = {1e30f, 1e30f};
     static const uint32_t cand[2] = {kDefaultStagger, 0u};
     for (int round = 0; round < 3 && rc == XSG_OK; ++round) {
       for (int k = 0; k < 2 && rc == XSG_OK; ++k) {
         ScanArgs a = scan_args(s);
-        a.pat.hot = s->hot;
+        a.pat.hot = s->hot_v[v];
         a.tune = cand[k];
         a.ntiles = std::min<uint64_t>(a.ntiles, 131072);
         hipError_t e = round == 0 ? launch_scan_count(a, false, false, st) : hipSuccess;
@@ -981,10 +1027,17 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
   for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
   if (rc != XSG_OK) return rc;
   HIP_TRY(hipMemsetAsync(scan_args(s).flags, 0, 4, st));
-  c->memo.serial = c->pattern_serial;
-  c->memo.base = s->base;
-  c->memo.total_bytes = s->total_bytes;
-  c->memo.hot = s->hot, c->memo.koff = s->koff, c->memo.koff_chosen = s->koff_chosen;
+  if (!memo_hit) {
+    c->memo = xsg_ctx::ProbeMemo{};
+    c->memo.serial = c->pattern_serial;
+    c->memo.base = s->base;
+    c->memo.total_bytes = s->total_bytes;
+    c->memo.nchunks = s->chunks.size();
+    memcpy(c->memo.tag, tag, sizeof tag);
+  }
+  c->memo.hot_v[v] = s->hot_v[v];
+  c->memo.hot_known |= (uint8_t)(1u << v);
+  c->memo.koff = s->koff, c->memo.koff_chosen = s->koff_chosen;
   c->memo.tune = s->tune, c->memo.tune_probe = s->tune_probe;
   return XSG_OK;
 }
@@ -992,14 +1045,14 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st) {
 static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool want_nl, hipStream_t st,
                          uint64_t* d_counters, uint64_t* host_counters, const PatternDev* other_pattern = nullptr) {
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
-  if (!other_pattern) XSG_TRY(choose_hot_filter(s, st));
   const uint64_t nchunks = s->chunks.size();
   // kDfa: k_rx_scan counts matching lines directly into tile_cnt (a line is one lane's work): no line summaries
   const bool rx_lines = want_lines && s->ctx->pat.kind == kDfa;
   if (rx_lines) want_lines = false;
-  XSG_TRY(prepare_tiles(s, want_lines, st));
   const bool scan_nl = want_nl && !s->nl_cached;  // the per-tile newline counts of this binding may already exist
-  ScanArgs a = scan_args(s);
+  if (!other_pattern) XSG_TRY(choose_hot_filter(s, st, scan_nl, want_lines));  // measured for the variant this pass launches
+  XSG_TRY(prepare_tiles(s, want_lines, st));
+  ScanArgs a = scan_args(s, scan_variant(scan_nl, want_lines));
   if (other_pattern) {  // (ensure_overlap_check: a word derived from the ctx's pattern, nothing measured or remembered for it)
     a.pat = *other_pattern;
     a.dense_hint = 0;
@@ -1364,9 +1417,9 @@ extern "C" int xsg_time_scan_kernel(xsg_shard* s, uint32_t mode, int iters, floa
   const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
   const bool want_lines = m == XSG_COUNT_LINES;
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
-  XSG_TRY(choose_hot_filter(s, c->stream));  // time what a real pass of this mode would launch
+  XSG_TRY(choose_hot_filter(s, c->stream, want_nl, want_lines));  // time what a real pass of this mode would launch
   XSG_TRY(prepare_tiles(s, want_lines, c->stream));
-  ScanArgs a = scan_args(s);
+  ScanArgs a = scan_args(s, scan_variant(want_nl, want_lines));
   a.lines_only = want_lines;  // XSG_COUNT_LINES: what xsg_count launches for it (enqueue_count)
   s->cnt_clean = s->sum_clean = false;  // no finish kernel runs behind these launches
   hipEvent_t e0, e1;
@@ -1393,7 +1446,7 @@ extern "C" int xsg_scan_kernel_name(xsg_shard* s, uint32_t mode, char* out, size
   const bool list = m >= XSG_MATCH_BYTE_OFFSETS;
   // what the FIRST pass of this mode launches on this shard right now (newline counts already cached -> plain kernel)
   const bool want_nl = ((mode & XSG_WITH_NEWLINES) != 0 || m == XSG_LINE_INDICES) && !s->nl_cached;
-  ScanArgs a = scan_args(s);
+  ScanArgs a = scan_args(s, scan_variant(want_nl, !list && m == XSG_COUNT_LINES));
   if (use_prefilter(s)) {  // what xsg_count / xsg_search launch: the candidate scan, then the automaton at candidates
     a.pat = s->ctx->pre_pat;
     a.pat.hot = 0;
@@ -1425,11 +1478,16 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   const uint32_t nhot = (is_window_kind(c->pat.kind) && c->hot_env < 0) ? 2u : 1u;
   // the probe first (it also settles a long pattern's filter window, which the loop below keeps), then both hot
   // filters against every stagger at full size
+  const bool tune_nl = (mode & XSG_WITH_NEWLINES) != 0, tune_lines = (mode & 0xffu) == XSG_COUNT_LINES;
+  const uint32_t v = scan_variant(tune_nl, tune_lines);
   s->hot_serial = 0;
-  XSG_TRY(choose_hot_filter(s, c->stream));
+  XSG_TRY(choose_hot_filter(s, c->stream, tune_nl, tune_lines));
+  if (nhot == 2) best_hot = s->hot_v[v];
   for (uint32_t hot = 0; hot < nhot; ++hot) {
-    s->hot = hot;
-    s->hot_serial = c->pattern_serial;
+    if (nhot == 2) {
+      s->hot_v[v] = (uint8_t)hot;
+      s->hot_known |= (uint8_t)(1u << v);
+    }
     for (uint32_t t : cand) {
       s->tune = t;
       float ms = 0;
@@ -1446,7 +1504,7 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   s->tune = best;
   s->tune_serial = c->pattern_serial;
   s->tune_probe = false;
-  s->hot = best_hot;
+  if (nhot == 2) s->hot_v[v] = (uint8_t)best_hot;
   if (chosen) *chosen = best;
   return XSG_OK;
 }
@@ -1570,12 +1628,12 @@ static int run_list_fast(xsg_shard* s, uint32_t mode) {
   memset(s->h_tot, 0, 8 * (kTotWords + 1));  // nothing of this shard is in flight: every search ends in a sync
 
   // ---- 1. bulk count per tile (+ newlines per tile, once per binding)
-  XSG_TRY(choose_hot_filter(s, st));
+  const bool scan_nl = want_nl && !s->nl_cached;
+  XSG_TRY(choose_hot_filter(s, st, scan_nl, false));
   XSG_TRY(prepare_tiles(s, false, st));
-  ScanArgs a = scan_args(s);
+  ScanArgs a = scan_args(s, scan_variant(scan_nl, false));
   a.tile_wmask = s->d_wmask.as<uint32_t>();  // the count pass marks the waves that found something, the emit pass reads only those
   s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them
-  const bool scan_nl = want_nl && !s->nl_cached;
   HIP_TRY(launch_scan_count(a, scan_nl, false, st));
   if (scan_nl) s->nl_cached = true;
 
@@ -1780,18 +1838,18 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
 
   // 1. bulk count per tile
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
+  const bool scan_nl = want_nl && !s->nl_cached;  // newline counts per tile: once per binding, whatever the pattern
   if (!counts_ready) {
-    XSG_TRY(choose_hot_filter(s, st));
+    XSG_TRY(choose_hot_filter(s, st, scan_nl, false));
     XSG_TRY(prepare_tiles(s, false, st));
   }
-  ScanArgs a = scan_args(s);
+  ScanArgs a = scan_args(s, scan_variant(scan_nl, false));
   const bool pre = use_prefilter(s);  // candidates by the class-sequence matcher, then the automaton
   if (pre) {
     a.pat = c->pre_pat;
     a.pat.hot = 0;
   }
   s->cnt_clean = false;  // the tile counts stay in place for the emit pass: the next pass re-zeroes them
-  const bool scan_nl = want_nl && !s->nl_cached;  // newline counts per tile: once per binding, whatever the pattern
   if (!counts_ready) HIP_TRY(launch_scan_count(a, scan_nl, false, st));
   if (scan_nl) s->nl_cached = true;
 

@@ -449,7 +449,10 @@ struct Partial {
   std::vector<std::string> lines;
 };
 
+static std::atomic<uint64_t> g_job_serial{0};
+
 struct xsg_job {
+  const uint64_t serial = ++g_job_serial;
   xsg_job_opts opts{};
   std::vector<uint8_t> pattern;
   int fd = -1;
@@ -462,7 +465,6 @@ struct xsg_job {
   // the filled buffers, hipMemcpyAsync them on their own stream and run the scan.  The
   // pinned buffers circulate: free -> (reader) -> ready -> (worker) -> free.
   std::vector<std::thread> threads;
-  std::atomic<uint64_t> next_chunk{0};
   std::atomic<bool> stop{false};
   std::atomic<int> active{0};   // device workers still running
   int readers_running = 0;      // guarded by q_mu
@@ -470,6 +472,15 @@ struct xsg_job {
   std::condition_variable q_cv_free, q_cv_ready;
   std::vector<struct HostBuf*> all_bufs, free_bufs;
   std::deque<struct HostBuf*> ready_bufs;
+  // Reading is decoupled from the chunk plan: the readers fill ONE chunk at a time together, piece by piece (a plain
+  // file's chunk of 16 MiB is read as pieces of 4 MiB by whichever readers are free), so that a file of six chunks keeps
+  // eight readers busy and its first chunk is on its way to the device after a quarter of a chunk's read time.  A
+  // compressed chunk is one piece (its decoder needs all of it).  All guarded by q_mu.
+  uint64_t next_chunk = 0;            // next chunk of the plan to open
+  struct HostBuf* open_buf = nullptr; // the chunk being filled
+  uint64_t open_next_piece = 0, open_npieces = 0;
+  uint64_t piece_bytes = 4u << 20;
+  int bufs_max = 0, bufs_created = 0; // the pinned ring grows on demand (readers allocate their buffers in parallel)
 
   // ordered result store
   std::mutex mu;
@@ -532,19 +543,22 @@ struct HostBuf {
   uint64_t cap = 0;
   std::vector<uint8_t> staging;  // compressed bytes before decode
   uint64_t index = 0;            // chunk it currently holds
+  std::atomic<uint64_t> pieces_left{0};  // pieces of that chunk still being read
   ~HostBuf() {
     if (pinned) (void)hipHostFree(pinned);
   }
 };
 
-// Device side of a worker: two lanes of ctx (= stream) + shard scratch + device buffer.  Count tags alternate
+// Device side of a worker: two lanes of ctx (= stream) + shard scratch + device buffer.  Every tag alternates
 // between them so that the copy of chunk i+1 is already in the queue (and moving) while chunk i is scanned and
-// its result waited for; list tags use lane 0 only.
+// its result waited for: count tags enqueue copy + scan and collect the counters one chunk later; list tags enqueue
+// the copy and run their search (which ends in a stream sync of ITS lane) one chunk later.
 struct Lane {
   xsg_ctx* ctx = nullptr;
   xsg_shard* shard = nullptr;
   void* dev = nullptr;
   uint64_t cap = 0;
+  uint64_t job_serial = 0;  // the job this lane carries the pattern of (lane_prepare)
 };
 struct Slot {
   Lane lane[2];
@@ -599,33 +613,40 @@ static void slot_give_back(Slot* s) {
 
 static bool is_count_mode(uint32_t mode) { return mode == XSG_COUNT_MATCHES || mode == XSG_COUNT_LINES; }
 
+// One lane of a slot, ready for this job: its context and shard (created on first use), the job's pattern, a device
+// buffer that holds the job's largest chunk.  `serial` = the job the lane was last prepared for.
+static int lane_prepare(xsg_job* j, Slot& s, int k) {
+  Lane& l = s.lane[k];
+  if (l.job_serial == j->serial) return XSG_OK;
+  HIP_TRY(hipSetDevice(j->opts.device));
+  const uint64_t need = ((j->max_orig + 15u) & ~(uint64_t)15u) + 256u;
+  if (!l.ctx) {
+    XSG_TRY(xsg_ctx_create(j->opts.device, &l.ctx));
+    XSG_TRY(xsg_shard_create(l.ctx, nullptr, 0, nullptr, 0, &l.shard));
+    XSG_TRACE("slot: lane %d ctx + shard created", k);
+  }
+  XSG_TRY(xsg_set_pattern(l.ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
+  if (need > l.cap) {
+    if (l.dev) (void)hipFree(l.dev);
+    l.dev = nullptr;
+    l.cap = 0;
+    HIP_TRY(hipMalloc(&l.dev, need));
+    l.cap = need;
+    XSG_TRACE("slot: lane %d device buffer %llu bytes", k, (unsigned long long)need);
+  }
+  l.job_serial = j->serial;
+  return XSG_OK;
+}
+
+// A worker's slot: taken from the pool or new; lane 0 is made ready here, lane 1 when a second chunk arrives while the
+// first is in flight (a stream costs 10-20 ms to create in a fresh process, a device buffer up to 5: a file of one
+// chunk never pays for the second lane).
 static int slot_prepare(xsg_job* j, Slot** out) {
   Slot* s = slot_take(j->opts.device);
   std::unique_ptr<Slot> own(s ? s : new (std::nothrow) Slot());
   if (!own) return fail(XSG_ENOMEM, "host allocation failed");
-  s = own.get();
-  s->device = j->opts.device;
-  HIP_TRY(hipSetDevice(j->opts.device));
-  const int nlanes = is_count_mode(j->opts.mode) ? 2 : 1;
-  const uint64_t need = ((j->max_orig + 15u) & ~(uint64_t)15u) + 256u;
-  for (int k = 0; k < nlanes; ++k) {
-    Lane& l = s->lane[k];
-    if (!l.ctx) {
-      XSG_TRY(xsg_ctx_create(j->opts.device, &l.ctx));
-      XSG_TRY(xsg_shard_create(l.ctx, nullptr, 0, nullptr, 0, &l.shard));
-      XSG_TRACE("slot: lane %d ctx + shard created", k);
-    }
-    XSG_TRY(xsg_set_pattern(l.ctx, j->pattern.data(), j->pattern.size(), j->opts.pattern_flags));
-    XSG_TRACE("slot: lane %d pattern set", k);
-    if (need > l.cap) {
-      if (l.dev) (void)hipFree(l.dev);
-      l.dev = nullptr;
-      l.cap = 0;
-      HIP_TRY(hipMalloc(&l.dev, need));
-      l.cap = need;
-      XSG_TRACE("slot: lane %d device buffer %llu bytes", k, (unsigned long long)need);
-    }
-  }
+  own->device = j->opts.device;
+  XSG_TRY(lane_prepare(j, *own, 0));
   *out = own.release();
   return XSG_OK;
 }
@@ -750,29 +771,113 @@ extern "C" int xsg_device_numa(int device, int* node, char* cpulist, size_t cap)
   return XSG_OK;
 }
 
+// CPUs this process may use: its affinity mask, capped by the cgroup's CPU quota (cpu.max)
+static int cpu_budget() {
+  int n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = "";
+    long long period = 0;
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long long quota = atoll(q);
+      if (quota > 0) n = (int)std::min<long long>(n, std::max<long long>(1, quota / period));
+    }
+    fclose(f);
+  }
+  return n;
+}
+static uint64_t env_u64(const char* name, uint64_t dflt) {
+  const char* v = getenv(name);
+  return v && *v ? strtoull(v, nullptr, 0) : dflt;
+}
+// reader threads the pipeline runs whatever the caller asked for (see job_start_impl)
+static int auto_readers() {
+  static const int n = [] {
+    const uint64_t e = env_u64("XSG_MIN_READERS", 0);
+    if (e) return (int)std::min<uint64_t>(e, 64);
+    return std::min(8, std::max(2, cpu_budget() / 2));
+  }();
+  return n;
+}
+
 // ---- stage 1: read (+ decompress) into a pinned buffer ------------------------
-static void reader_loop(xsg_job* j, double& t_read, double& t_dec, uint64_t& rbytes) {
-  while (!j->stop.load()) {
-    const uint64_t i = j->next_chunk.fetch_add(1);
-    if (i >= j->plan.size()) break;
-    HostBuf* b = nullptr;
-    {
-      std::unique_lock<std::mutex> lk(j->q_mu);
-      j->q_cv_free.wait(lk, [&] { return !j->free_bufs.empty() || j->stop.load(); });
-      if (j->stop.load()) break;
-      b = j->free_bufs.back();
+static uint64_t pieces_of(const xsg_job* j, const xsg_file_chunk& fc) {
+  if (j->compression != XSG_COMPRESSION_NONE) return 1;  // a decoder needs the whole chunk
+  return std::max<uint64_t>(1, fc.actual_size / j->piece_bytes);  // the last piece takes the remainder
+}
+
+// A reader's next piece of work: (buffer, piece) of the chunk that is open, opening the next chunk of the plan -- in a
+// free buffer of the ring, or in one this reader allocates (the ring grows on demand, up to bufs_max: a fresh process
+// pays 3-5 ms per 16 MiB of hipHostMalloc, and several readers pay it side by side while the first chunk is already
+// being read).  false: nothing left to read, or the job stopped.
+static bool next_piece(xsg_job* j, HostBuf** buf, uint64_t* piece) {
+  std::unique_lock<std::mutex> lk(j->q_mu);
+  HostBuf* mine = nullptr;  // a buffer this reader holds but has not placed yet
+  for (;;) {
+    if (j->stop.load()) break;
+    if (j->open_buf && j->open_next_piece < j->open_npieces) {
+      *buf = j->open_buf;
+      *piece = j->open_next_piece++;
+      if (mine) {
+        j->free_bufs.push_back(mine);
+        j->q_cv_free.notify_one();
+      }
+      return true;
+    }
+    if (j->next_chunk >= j->plan.size()) break;
+    if (!mine && !j->free_bufs.empty()) {
+      mine = j->free_bufs.back();
       j->free_bufs.pop_back();
     }
-    const xsg_file_chunk& fc = j->plan[i];
+    if (!mine && j->bufs_created < j->bufs_max) {
+      ++j->bufs_created;
+      lk.unlock();
+      HostBuf* b = nullptr;
+      const int r = buf_prepare(j, &b);
+      lk.lock();
+      if (r != XSG_OK) {
+        lk.unlock();
+        job_fail(j, r);
+        return false;
+      }
+      j->all_bufs.push_back(b);
+      mine = b;
+      continue;  // the state may have moved while the lock was released
+    }
+    if (!mine) {
+      j->q_cv_free.wait(lk);
+      continue;
+    }
+    j->open_buf = mine;
+    mine = nullptr;
+    j->open_buf->index = j->next_chunk++;
+    j->open_npieces = pieces_of(j, j->plan[j->open_buf->index]);
+    j->open_buf->pieces_left.store(j->open_npieces);
+    j->open_next_piece = 0;
+    j->q_cv_free.notify_all();  // readers waiting for a buffer: there are pieces to take now
+  }
+  if (mine) j->free_bufs.push_back(mine);
+  return false;
+}
+
+static void reader_loop(xsg_job* j, double& t_read, double& t_dec, uint64_t& rbytes) {
+  HostBuf* b = nullptr;
+  uint64_t piece = 0;
+  while (next_piece(j, &b, &piece)) {
+    const xsg_file_chunk& fc = j->plan[b->index];
+    const uint64_t np = pieces_of(j, fc);
+    const uint64_t lo = piece * j->piece_bytes;
+    const uint64_t n = piece + 1 == np ? fc.actual_size - lo : j->piece_bytes;
     auto t0 = Clock::now();
     int r = XSG_OK;
     // the plan was validated at start; the buffers were sized from it -- checked again where the bytes land
     if (fc.original_size > b->cap || (j->compression != XSG_COMPRESSION_NONE && fc.actual_size > b->staging.size()) ||
         (j->compression == XSG_COMPRESSION_NONE && fc.actual_size > b->cap))
-      r = fail(XSG_EIO, "chunk %llu does not fit its buffers", (unsigned long long)i);
-    if (r == XSG_OK && fc.actual_size) {
-      void* dst = j->compression == XSG_COMPRESSION_NONE ? b->pinned : (void*)b->staging.data();
-      r = pread_full(j->fd, dst, fc.actual_size, fc.actual_offset);
+      r = fail(XSG_EIO, "chunk %llu does not fit its buffers", (unsigned long long)b->index);
+    if (r == XSG_OK && n) {
+      uint8_t* dst = j->compression == XSG_COMPRESSION_NONE ? static_cast<uint8_t*>(b->pinned) : b->staging.data();
+      r = pread_full(j->fd, dst + lo, n, fc.actual_offset + lo);
     }
     t_read += seconds_since(t0);
     if (r == XSG_OK && j->compression != XSG_COMPRESSION_NONE && fc.original_size) {
@@ -782,18 +887,17 @@ static void reader_loop(xsg_job* j, double& t_read, double& t_dec, uint64_t& rby
       t_dec += seconds_since(t0);
     }
     if (r != XSG_OK) {
-      job_fail(j, r);
-      std::lock_guard<std::mutex> lk(j->q_mu);
-      j->free_bufs.push_back(b);
+      job_fail(j, r);  // (the buffer stays with the job: other readers may still be writing their pieces of it)
       break;
     }
-    rbytes += fc.actual_size;
-    b->index = i;
-    {
-      std::lock_guard<std::mutex> lk(j->q_mu);
-      j->ready_bufs.push_back(b);
+    rbytes += n;
+    if (b->pieces_left.fetch_sub(1) == 1) {  // the chunk is complete
+      {
+        std::lock_guard<std::mutex> lk(j->q_mu);
+        j->ready_bufs.push_back(b);
+      }
+      j->q_cv_ready.notify_one();
     }
-    j->q_cv_ready.notify_one();
   }
 }
 
@@ -835,12 +939,10 @@ static int bind_chunk(xsg_job* j, Lane& l, const HostBuf& hb) {
   return xsg_shard_rebind(l.shard, l.dev, l.cap, &ch, 1);
 }
 
-// list tags: one chunk at a time (the list search synchronises the stream several times anyway)
-static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
+// list tags, second half: the search on the lane whose copy was queued one chunk earlier, then publish
+static int list_collect(xsg_job* j, Lane& l, const HostBuf& hb) {
   const xsg_file_chunk& fc = j->plan[hb.index];
   const uint32_t mode = j->opts.mode;
-  Lane& l = s.lane[0];
-  XSG_TRY(bind_chunk(j, l, hb));
   Partial p;
   if (mode == XSG_LINES) {
     uint64_t n = 0, nl = 0, nb = 0;
@@ -867,7 +969,7 @@ static int process_chunk(xsg_job* j, Slot& s, const HostBuf& hb) {
       XSG_TRY(xsg_result_newlines(l.shard, &p.newlines));
     }
   }
-  // the searches above synchronise the stream: the pinned buffer is free again
+  // the search synchronised the lane's stream: its pinned buffer is free again
   publish(j, hb.index, std::move(p));
   return XSG_OK;
 }
@@ -902,15 +1004,20 @@ static void worker_body(xsg_job* j, double& t_dev, uint64_t& bytes, uint64_t& ch
     job_fail(j, r);
     return;
   }
-  const bool pipelined = is_count_mode(j->opts.mode);
-  HostBuf* inflight = nullptr;  // count tags: the chunk whose pass is in lane (k ^ 1)'s queue
+  const bool counting = is_count_mode(j->opts.mode);
+  HostBuf* inflight = nullptr;  // the chunk whose copy (count tags: and pass) is in lane (k ^ 1)'s queue
   int k = 0;
+  // The second lane costs a fresh process 10-20 ms (a stream, a device buffer: profiles/r04_cli_start.txt) and buys
+  // the ~50 us a chunk that one lane loses between two chunks: made when the job is long enough to pay that back --
+  // or used when the slot already has it (a pooled slot of an earlier, larger job).
+  const uint64_t per_worker = (j->plan.size() + (uint64_t)j->opts.num_threads - 1) / (uint64_t)std::max(j->opts.num_threads, 1);
+  const bool two_lanes = sp->lane[1].ctx != nullptr || per_worker >= env_u64("XSG_LANE2_MIN_CHUNKS", 32);
   for (;;) {
     HostBuf* b = nullptr;
     bool done = false;
     {
       std::unique_lock<std::mutex> lk(j->q_mu);
-      // with a pass in flight, do not sleep on the queue: collect that result first (its pinned buffer goes
+      // with a chunk in flight, do not sleep on the queue: collect that result first (its pinned buffer goes
       // back to the readers, who may be waiting for exactly that one)
       if (!inflight)
         j->q_cv_ready.wait(lk, [&] { return !j->ready_bufs.empty() || j->readers_running == 0 || j->stop.load(); });
@@ -925,29 +1032,34 @@ static void worker_body(xsg_job* j, double& t_dev, uint64_t& bytes, uint64_t& ch
     }
     if (done) break;
     const auto t0 = Clock::now();
-    if (!pipelined) {
-      r = process_chunk(j, *sp, *b);
-      bytes += j->plan[b->index].original_size;
+    if (b) r = lane_prepare(j, *sp, k);
+    if (b && r == XSG_OK) r = counting ? count_enqueue(j, *sp, k, *b) : bind_chunk(j, sp->lane[k], *b);
+    if (inflight) {
+      const int r2 = counting ? count_collect(j, *sp, k ^ 1, inflight->index) : list_collect(j, sp->lane[k ^ 1], *inflight);
+      bytes += j->plan[inflight->index].original_size;
       ++chunks;
-      give_back(j, b);
-    } else {
-      if (b) r = count_enqueue(j, *sp, k, *b);
-      if (inflight) {
-        const int r2 = count_collect(j, *sp, k ^ 1, inflight->index);
-        bytes += j->plan[inflight->index].original_size;
-        ++chunks;
-        give_back(j, inflight);
-        inflight = nullptr;
-        if (r == XSG_OK) r = r2;
-      }
-      if (b) {
-        if (r == XSG_OK) {
-          inflight = b;
+      if (r2 != XSG_OK) (void)hipDeviceSynchronize();  // the failed lane may still read the pinned buffer
+      give_back(j, inflight);
+      inflight = nullptr;
+      if (r == XSG_OK) r = r2;
+    }
+    if (b) {
+      if (r == XSG_OK) {
+        inflight = b;
+        if (two_lanes) {
           k ^= 1;
-        } else {
-          (void)hipDeviceSynchronize();  // the failed lane may still read the pinned buffer
-          give_back(j, b);
+        } else {  // one lane: this chunk's result is collected before the next chunk is looked at
+          const int r2 = counting ? count_collect(j, *sp, k, inflight->index) : list_collect(j, sp->lane[k], *inflight);
+          bytes += j->plan[inflight->index].original_size;
+          ++chunks;
+          if (r2 != XSG_OK) (void)hipDeviceSynchronize();
+          give_back(j, inflight);
+          inflight = nullptr;
+          r = r2;
         }
+      } else {
+        (void)hipDeviceSynchronize();  // the failed lane may still read the pinned buffer
+        give_back(j, b);
       }
     }
     t_dev += seconds_since(t0);
@@ -956,9 +1068,8 @@ static void worker_body(xsg_job* j, double& t_dev, uint64_t& bytes, uint64_t& ch
       break;
     }
   }
-  if (inflight) {  // stopped with a pass in flight: let it drain before the buffer is handed back
-    uint64_t ctr[XSG_NUM_COUNTERS];
-    (void)xsg_count_end(sp->lane[k ^ 1].shard, ctr);
+  if (inflight) {  // stopped with a chunk in flight: let its lane drain before the buffer is handed back
+    (void)hipStreamSynchronize(sp->lane[k ^ 1].ctx->stream);
     give_back(j, inflight);
   }
   if (r == XSG_OK)
@@ -1107,25 +1218,21 @@ static int job_start_impl(const void* pattern, size_t plen, const char* file_pat
   j->t_start = Clock::now();
   const uint64_t nch = std::max<uint64_t>(j->plan.size(), 1);
   const int nworkers = (int)std::min<uint64_t>((uint64_t)opts->num_threads, nch);
-  const int nreaders = (int)std::min<uint64_t>((uint64_t)opts->num_max_readers, nch);
-  // one buffer being filled per reader, one being consumed per worker (two for count tags: a worker keeps the
-  // next chunk's copy queued behind the current scan), one in between
-  const int per_worker = is_count_mode(opts->mode) ? 2 : 1;
-  const int nbufs = (int)std::min<uint64_t>((uint64_t)(per_worker * nworkers + nreaders + 1), nch + 1);
-  for (int i = 0; i < nbufs; ++i) {
-    HostBuf* b = nullptr;
-    r = buf_prepare(j.get(), &b);
-    if (r != XSG_OK) {
-      bufs_release(j.get());
-      close(j->fd);
-      return r;
-    }
-    j->all_bufs.push_back(b);
-    j->free_bufs.push_back(b);
-  }
+  // How many threads READ is the pipeline's business, not the caller's: num_threads = 1, num_max_readers = 1 is what the
+  // reference's one-call API defaults to (README.md:37), and one thread copying page-cache bytes into pinned memory
+  // moves 6-10 GiB/s where the link to the device takes 50.  The caller's number is a floor; the pipeline adds readers
+  // up to half the CPUs the process may use (2..8; XSG_MIN_READERS overrides), and they share the chunks piece by piece.
+  j->piece_bytes = std::max<uint64_t>(env_u64("XSG_READ_PIECE", 4u << 20), 1u << 16);
+  uint64_t pieces = 0;
+  for (const xsg_file_chunk& c : j->plan) pieces += pieces_of(j.get(), c);
+  const int nreaders = (int)std::min<uint64_t>((uint64_t)std::max(opts->num_max_readers, auto_readers()), std::max<uint64_t>(pieces, 1));
+  // the ring: two chunks per worker (one being scanned, one whose copy is queued behind it), the one the readers are
+  // filling, and two complete ones in between -- never more buffers than chunks.  Allocated on demand by the readers.
+  j->bufs_max = (int)std::min<uint64_t>((uint64_t)(2 * nworkers + 3), nch);
   j->active = nworkers;
   j->readers_running = nreaders;
-  XSG_TRACE("job: %d pinned buffers ready, starting %d readers + %d workers", nbufs, nreaders, nworkers);
+  XSG_TRACE("job: starting %d readers + %d workers, ring of up to %d pinned buffers, %llu pieces", nreaders, nworkers,
+            j->bufs_max, (unsigned long long)pieces);
   xsg_job* raw = j.release();
   for (int t = 0; t < nreaders; ++t) raw->threads.emplace_back(reader_main, raw);
   for (int t = 0; t < nworkers; ++t) raw->threads.emplace_back(worker_main, raw);

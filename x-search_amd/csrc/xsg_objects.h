@@ -109,13 +109,16 @@ struct xsg_ctx {
   uint64_t hbm = 0;
   // What the probe (choose_hot_filter) measured last, kept with the buffer it was measured on: a NEW binding of the same
   // buffer and size with the same pattern (a caller that creates a shard per search) takes it over instead of paying the
-  // probe again; xsg_shard_rebind / xsg_shard_invalidate on that buffer drop it (the bytes changed).  A choice, never a
-  // result: a stale one costs speed only.
+  // probe again; xsg_shard_rebind / xsg_shard_invalidate on that buffer drop it (the bytes changed), and so does a
+  // binding of the same address and size whose first or last 16 bytes differ (a freed buffer handed out again for other
+  // data).  A choice, never a result: a stale one costs speed only.
   struct ProbeMemo {
     uint64_t serial = 0;
     const uint8_t* base = nullptr;
-    uint64_t total_bytes = 0;
-    uint32_t hot = 0, koff = 0, tune = xsg::kTuneAuto;
+    uint64_t total_bytes = 0, nchunks = 0;
+    uint64_t tag[4] = {0, 0, 0, 0};  // the first and the last 16 bytes of the text that was measured
+    uint8_t hot_v[4] = {0, 0, 0, 0}, hot_known = 0;  // as xsg_shard::hot_v / hot_known
+    uint32_t koff = 0, tune = xsg::kTuneAuto;
     bool koff_chosen = false, tune_probe = false;
   } memo;
 };
@@ -138,8 +141,12 @@ struct xsg_shard {
   uint64_t density_serial = 0;     // ctx->pattern_serial for which `dense` was observed (a synchronous count's result)
   bool dense = false;              // ... more than one result per 2 KiB of this data
   bool tune_probe = false;         // `tune` came from choose_hot_filter's two-way probe (re-measured after a re-bind), not from xsg_shard_tune
-  // hot filter of the window kinds for (this binding, the ctx's current pattern): measured once, see choose_hot_filter
-  uint32_t hot = 0;
+  // hot filter of the window kinds for (this binding, the ctx's current pattern): measured once PER KERNEL VARIANT the
+  // caller's mode launches (bit 0 of the index: the pass also counts newlines; bit 1: it builds line summaries) -- the
+  // aligned trigger wins by 12 % where the kernel is VALU-bound (count + newlines) and loses 2 % where it waits for
+  // memory (the plain count); see choose_hot_filter
+  uint8_t hot_v[4] = {0, 0, 0, 0};
+  uint8_t hot_known = 0;  // bit v: hot_v[v] was measured (or settled without measuring) for hot_serial's pattern
   uint32_t koff = 0;  // long patterns: the filter window measured best here
   bool koff_chosen = false;
   uint64_t hot_serial = 0;  // the ctx->pattern_serial `hot` was measured for (0: never)
