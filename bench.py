@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=10)
     ap.add_argument("--e2e-gib", type=float, default=4.0,
                     help="size of the tmpfs file of the end-to-end (file -> result) leg; 0 = skip")
+    ap.add_argument("--cli-gib", type=float, default=10.0,
+                    help="N=1: size of the large tmpfs file of the `cli` block (fresh-process wall times of xsgrep, the README's "
+                         "my_grep, GNU grep and the reference CPU path; BASELINE config 1's 100 MB file is always timed); 0 = skip")
     ap.add_argument("--no-tune", action="store_true", help="keep the per-variant default stagger")
     ap.add_argument("--no-regex", action="store_true", help="skip the regex leg (N=1: a few expressions on the resident shard)")
     ap.add_argument("--configs-gib", type=float, default=10.0,
@@ -207,7 +210,10 @@ def cpu_baseline(args, blocks, pattern: bytes):
         "by_threads": {str(t): round(rates[t][0], 3) for t in ts},
         "physical_cores": pc, "hw_threads": hw, "sockets": topo["sockets"], "numa_nodes": topo["numa_nodes"],
         "cgroup_cpu_quota": topo["cgroup_cpu_quota"],
-        "expected_count_checked": expect_all >= 0,
+        # every pass of every thread count returned exactly the count the oracle's per-template counts add up to (a
+        # difference is a SystemExit above); the whole sample holds `expected_matches_in_sample` occurrences
+        "every_pass_count_equals_expected": True,
+        "expected_matches_in_sample": expect_all,
         "note": note,
         "sample": f"{want_chunks} chunks x {args.chunk_mib} MiB = {want_chunks * chunk_bytes / 2**30:.1f} GiB of the same corpus in RAM "
                   f"(first-touched by the workers), persistent thread pool, chunk work-stealing, xs::count; "
@@ -264,32 +270,55 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         nthreads = int(os.environ.get("XSG_E2E_WORKERS", str(max(1, min(4, budget // 3)))))
         nreaders = int(os.environ.get("XSG_E2E_READERS", str(max(1, min(8, budget - max(1, min(4, budget // 3)))))))
 
-        def run(mode, meta=None, data=None):
+        def run(mode, meta=None, data=None, nrd=None):
             if dist is not None:
                 dist.barrier()
             t0 = time.perf_counter()
             j = xsg.Job(pattern, data or path, mode, meta_path=meta, device=dev_index, num_threads=nthreads,
-                        num_max_readers=nreaders, chunk_range=(lo, hi) if world > 1 else None)
+                        num_max_readers=nrd or nreaders, chunk_range=(lo, hi) if world > 1 else None)
             r = j.result()
             dt = time.perf_counter() - t0
+            st = j.stats()
             j.close()
             if dist is not None:  # wall time of the slowest rank (this leg is not a device measurement)
                 dt = _allreduce_max_host(dist, dt)
-            return r, dt
+            return r, dt, st
+
+        # what every tag must return for this rank's chunk range, from the oracle's results on the template chunks
+        from xs_oracle import Oracle
+        orc = Oracle()
+        sizes = np.array([blocks[int(c)].size for c in plan], dtype=np.uint64)
+        goff = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+        nl_t = np.array([orc.count_newlines(b) for b in blocks], dtype=np.uint64)
+        nl_before = np.concatenate([[0], np.cumsum(nl_t[plan])[:-1]]).astype(np.uint64)
+        m_t = [orc.byte_offsets_match(b, pattern) for b in blocks]
+        li_t = [orc.line_indices(b, pattern, 0) for b in blocks]
+        lines_t = [orc.lines(b, pattern) for b in blocks]
+        rng_ = range(lo, hi)
+        want_m = np.concatenate([m_t[int(plan[i])] + goff[i] for i in rng_]) if hi > lo else np.zeros(0, dtype=np.uint64)
+        # (a job over a chunk range numbers its lines from the range's first line: xsg_file.cpp, publish)
+        want_li = np.concatenate([li_t[int(plan[i])] + (nl_before[i] - nl_before[lo]) for i in rng_]) if hi > lo else np.zeros(0, dtype=np.uint64)
+        want_lines = [l for i in rng_ for l in lines_t[int(plan[i])]]
 
         run(xsg.COUNT_MATCHES)  # warm: thread/buffer pools, page cache
-        r, dt = run(xsg.COUNT_MATCHES)
+        r, dt, st = run(xsg.COUNT_MATCHES)
         if r != want_local:
             raise SystemExit(f"e2e PARITY FAILURE: count {r} != {want_local}")
         out["count_gib_s"] = round(size / dt / 2**30, 2)
-        r, dt = run(xsg.MATCH_BYTE_OFFSETS)
-        if len(r) != want_local:
-            raise SystemExit(f"e2e PARITY FAILURE: {len(r)} offsets != {want_local}")
+        r, dt, st = run(xsg.MATCH_BYTE_OFFSETS)
+        if not np.array_equal(np.asarray(r, dtype=np.uint64), want_m):
+            raise SystemExit(f"e2e PARITY FAILURE: match_byte_offsets differ from the oracle's ({len(r)} against {want_m.size})")
         out["match_byte_offsets_gib_s"] = round(size / dt / 2**30, 2)
-        r, dt = run(xsg.LINE_INDICES)
+        r, dt, st = run(xsg.LINE_INDICES)
+        if not np.array_equal(np.asarray(r, dtype=np.uint64), want_li):
+            raise SystemExit(f"e2e PARITY FAILURE: line_indices differ from the oracle's ({len(r)} against {want_li.size})")
         out["line_indices_gib_s"] = round(size / dt / 2**30, 2)
-        r, dt = run(xsg.LINES)
+        r, dt, st = run(xsg.LINES)
+        if list(r) != want_lines:
+            raise SystemExit(f"e2e PARITY FAILURE: lines differ from the oracle's ({len(r)} against {len(want_lines)})")
         out["lines_gib_s"] = round(size / dt / 2**30, 2)
+        out["parity"] = (f"count == expected; {want_m.size} match offsets, {want_li.size} line indices and {len(want_lines)} lines "
+                         f"== the oracle's, element by element")
         # config 5: LZ4 blocks + metafile, host decode overlapped with H2D + scan
         mp, dp = path + ".lz4.meta", path + ".lz4"
         if rank == 0:
@@ -306,17 +335,29 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         nsmall = min(max(world, n // 4), 128)
         lo, hi = (nsmall * rank) // world, (nsmall * (rank + 1)) // world
         want_l = int(sum(tcount[int(c)] for c in plan[lo:hi]))
-        nreaders = int(os.environ.get("XSG_E2E_DECODERS", str(max(1, min(12, budget - nthreads)))))
-        run(xsg.COUNT_MATCHES, mp, dp)
-        r, dt = run(xsg.COUNT_MATCHES, mp, dp)
+        ndecoders = int(os.environ.get("XSG_E2E_DECODERS", str(max(1, min(12, budget - nthreads)))))
+        run(xsg.COUNT_MATCHES, mp, dp, ndecoders)
+        r, dt, st = run(xsg.COUNT_MATCHES, mp, dp, ndecoders)
         if r != want_l:
             raise SystemExit(f"e2e PARITY FAILURE (lz4): count {r} != {want_l}")
         small_bytes = int(sum(blocks[int(c)].size for c in plan[:nsmall]))
         out["lz4_metafile_count_gib_s"] = round(small_bytes / dt / 2**30, 2)
         out["lz4_compressed_fraction"] = round(os.path.getsize(dp) / small_bytes, 3) if rank == 0 else None
+        # config 5's accounting (this rank's job): which decoder ran, what one decoder thread moves, where the wall time went
+        dec_s, rd_s, dev_s = st["seconds_decompress"], st["seconds_read"], st["seconds_device"]
+        out["lz4"] = {
+            "decoder": xsg.codec_name(xsg.COMPRESSION_LZ4),
+            "reader_decoder_threads": ndecoders, "device_workers": nthreads,
+            "decode_gib_s_per_thread": round(st["bytes_scanned"] / max(dec_s, 1e-9) / 2**30, 2),
+            "decode_thread_seconds": round(dec_s, 4), "read_thread_seconds": round(rd_s, 4),
+            "device_worker_seconds": round(dev_s, 4), "wall_seconds": round(dt, 4),
+            "decode_share_of_reader_time": round(dec_s / max(dec_s + rd_s, 1e-9), 3),
+            "bound": "host LZ4 decode: wall time ~ decode thread-seconds / threads; the H2D copies and scans of the same bytes "
+                     "take device_worker_seconds in all and overlap with it",
+        }
         out["file_gib"] = round(size / 2**30, 2)
-        out["threads"] = (f"{nthreads} device workers + {max(1, min(8, budget - nthreads)) if 'XSG_E2E_READERS' not in os.environ else os.environ['XSG_E2E_READERS']} readers per GPU "
-                          f"({nreaders} reader/decoder threads for LZ4); CPU budget per rank {budget}")
+        out["threads"] = (f"{nthreads} device workers + {nreaders} readers per GPU ({ndecoders} reader/decoder threads for LZ4); "
+                          f"CPU budget per rank {budget}")
         out["what"] = ("wall time from xsg_job_start to join on a tmpfs file (page-cache read -> pinned buffers -> "
                        "hipMemcpyAsync -> scan -> ordered result); bounded by PCIe Gen5 x16 and the host read path, "
                        "not by HBM")
@@ -448,6 +489,23 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+
+    # ---- N = 1, first (before this process touches the GPU): the reference's one published measurement on this box --
+    # `time grep Sherlock FILE` against `time my_grep Sherlock FILE` (README.md:44-62): fresh processes, wall time, outputs
+    # compared byte for byte.  Never `value`.
+    cli = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and os.environ.get("XSG_BENCH_CLI", "1") != "0":
+        sys.path.insert(0, str(ROOT / "scripts"))
+        try:
+            from cli_clock import cli_block
+            sizes = [("config1_100MB", 100_000_000, 5)]
+            if args.cli_gib > 0:
+                sizes.append((f"{args.cli_gib:g}GiB", int(args.cli_gib * 2**30), 3))
+            cli = cli_block(tuple(sizes), pattern=args.pattern.encode("latin-1"))
+        except SystemExit:
+            raise
+        except Exception as ex:  # a missing tool, no room in /dev/shm: reported, not fatal
+            cli = {"error": f"{type(ex).__name__}: {ex}"}
 
     import torch
     import xsg
@@ -757,6 +815,8 @@ def main():
                 "algorithmic_bytes_per_launch": shard_bytes,
             },
         }
+        if cli is not None:
+            line["cli"] = cli
         if untuned is not None:
             line["untuned"] = untuned
         if configs is not None:

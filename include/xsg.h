@@ -36,8 +36,9 @@
 extern "C" {
 #endif
 
-/* 3: xsg_shard_invalidate and xsg_result_lines_view joined (round 3); nothing was removed or changed in meaning */
-#define XSG_ABI_VERSION 3
+/* 3: xsg_shard_invalidate and xsg_result_lines_view joined (round 3); 4: xsg_count_async_status joined, XSG_MAX_PATTERN
+ * grew and the line tags accept a literal that contains '\n' (round 4); nothing was removed or changed in meaning */
+#define XSG_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 #define XSG_OK 0
@@ -120,7 +121,12 @@ enum xsg_mode {
  * closed under case instead, the same thing). */
 #define XSG_FLAG_REGEX 0x4u
 
-#define XSG_MAX_PATTERN 1024u
+/* A literal may be up to 32 KiB long (the reference's walk takes any std::string; what bounds it here is one 16-bit
+ * field: the end of a tile's last match, relative to the tile, must stay below 2^16).  The scan kernel keeps the first
+ * KiB of a long pattern in LDS and verifies the rest of a candidate from the device copy of the pattern.  A regular
+ * expression (XSG_FLAG_REGEX) is at most XSG_MAX_REGEX bytes of text. */
+#define XSG_MAX_PATTERN 32768u
+#define XSG_MAX_REGEX 1024u
 
 /* ---- counters written by the count entry points --------------------------- */
 #define XSG_CTR_MATCHES 0  /* XSG_COUNT_MATCHES result */
@@ -159,9 +165,14 @@ int xsg_device_count(int* count);
 int xsg_ctx_create(int device, xsg_ctx** out);
 void xsg_ctx_destroy(xsg_ctx* ctx);
 /* Literal pattern, 1..XSG_MAX_PATTERN bytes, any byte values (or, with
- * XSG_FLAG_REGEX, a regular expression of the families above).  Patterns that can match a
- * '\n' are accepted for XSG_COUNT_MATCHES / XSG_MATCH_BYTE_OFFSETS only (the
- * line modes return XSG_ENOTSUP for them). */
+ * XSG_FLAG_REGEX, a regular expression of the families above, at most XSG_MAX_REGEX bytes).  A LITERAL that contains
+ * '\n' is served by every tag: the reference's line walk (search_wrappers.h:29-50,163-207: after a match, on to the
+ * first '\n' at or behind its end) is then a chain from occurrence to occurrence, resolved on the device; the line
+ * it reports for a match begins behind the last '\n' before the match (at the byte after the match's first byte if
+ * that byte is a '\n' itself: previous_new_line_offset_relative_to_match, :111-123) and ends at the first '\n' at or
+ * behind the match's end -- so xs::lines hands out strings that contain newlines.  xsg_count_async does not serve
+ * XSG_COUNT_LINES for such a pattern (XSG_ENOTSUP: use xsg_count).  A regular EXPRESSION that can match '\n' keeps
+ * to XSG_COUNT_MATCHES / XSG_MATCH_BYTE_OFFSETS (the line modes return XSG_ENOTSUP for it). */
 int xsg_set_pattern(xsg_ctx* ctx, const void* pattern, size_t plen, uint32_t flags);
 /* Would XSG_FLAG_REGEX accept this expression?  XSG_OK, or XSG_ENOTSUP with the
  * reason in xsg_last_error().  Needs no device (callers route on it the way the
@@ -258,6 +269,15 @@ int xsg_shard_set_line_base(xsg_shard* shard, uint64_t line_base);
  * DESIGN.md 3.1) -- unless another binding of the same buffer already measured
  * this pattern on this ctx; every later call only enqueues. */
 int xsg_count_async(xsg_shard* shard, uint32_t mode, void* stream, uint64_t* d_counters);
+/* The same pass with an error channel: *d_status (device memory, one uint64, overwritten by the call) receives 0 or a
+ * combination of the XSG_STATUS_* bits below, and when it is not 0 all four counters read ZERO -- so a caller that adds
+ * up or all-reduces counters (and the status word with them: the bits of different ranks add up to something non-zero)
+ * can never mistake a refusal for a number.  xsg_count_async itself keeps its older convention (UINT64_MAX in all four
+ * counters); new callers should use this form. */
+#define XSG_STATUS_OK 0u
+#define XSG_STATUS_OVERFLOW 1u  /* a self-overlapping pattern's bounded device-side list ran out of capacity: call xsg_count */
+#define XSG_STATUS_NONASCII 2u  /* an expression that is exact on ASCII data only met a byte >= 0x80 (see XSG_FLAG_REGEX) */
+int xsg_count_async_status(xsg_shard* shard, uint32_t mode, void* stream, uint64_t* d_counters, uint64_t* d_status);
 /* Synchronous, any pattern, XSG_COUNT_MATCHES or XSG_COUNT_LINES
  * (| XSG_WITH_NEWLINES): result in host memory.  The first XSG_COUNT_MATCHES
  * (or match-offset search) of a literal with a border on a binding also runs
@@ -423,6 +443,10 @@ int xsg_meta_read(const char* meta_path, int32_t* compression, xsg_file_chunk** 
 int xsg_meta_write(const char* file_path, const char* meta_out_path, const char* data_out_path, int32_t compression,
                    uint64_t chunk_bytes, uint64_t mapping_gap, int hc);
 void xsg_free(void* p);
+/* Which decoder serves a compression type on this host (loads it if need be): "liblz4" / "libzstd" (the system's
+ * shared library, what the reference links: Dockerfile:8), "built-in LZ4 block codec" (csrc/xsg_lz4.h, when the host
+ * has no liblz4 or XSG_NO_LIBLZ4=1), "none" for XSG_COMPRESSION_NONE, "" if the type cannot be served here. */
+const char* xsg_codec_name(int32_t compression);
 
 /* ======================================================================== */
 /* Multi-GPU: the one exchange step, RCCL over xGMI                           */

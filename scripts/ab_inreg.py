@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the in-register class verification (XSG_CLS_INREG=0|1, read when the pattern is set) on whole xsg_count calls:
 class sequences proper and the prefilter route of the automaton family (whose candidate scan is a class sequence)."""
+import os
+os.environ.setdefault("XSG_TEST_HOOKS", "1")  # this script switches XSG_* toggles between searches (read once per process otherwise)
 import argparse, json, os, sys, time
 from pathlib import Path
 import numpy as np

@@ -4,6 +4,8 @@ tests/test_gpu_fuzz.py and, every third seed each, the class-sequence and the va
 tests/test_gpu_regex.py; many more seeds).  Runs for --minutes, prints a progress line
 every few seeds, stops at the first difference (the assertion message reproduces it).
 Result summary -> gpurun_out/fuzz_campaign.json."""
+import os
+os.environ.setdefault("XSG_TEST_HOOKS", "1")  # this campaign switches the list routes between seeds
 import argparse
 import json
 import sys

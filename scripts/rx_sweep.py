@@ -2,6 +2,8 @@
 """k_rx_scan (the automaton route of XSG_FLAG_REGEX) on a device-resident shard of the bench corpus: kernel time per
 expression and mode, next to the literal and class-sequence kernels on the same shard.
 Writes JSON lines to gpurun_out/rx_sweep.jsonl."""
+import os
+os.environ.setdefault("XSG_TEST_HOOKS", "1")  # this script switches XSG_* toggles between searches (read once per process otherwise)
 import argparse
 import json
 import sys

@@ -2,6 +2,8 @@
 """One k_scan variant on a device-resident shard, a few launches: the unit that scripts/gpu_variants.sh runs under
 rocprofv3 (kernel trace / SQ counters / FETCH_SIZE), once per variant, so that every variant -- not only the plain
 count the bench times -- has tracked evidence under profiles/.  Prints one JSON line (HIP-event timing)."""
+import os
+os.environ.setdefault("XSG_TEST_HOOKS", "1")  # this script switches XSG_* toggles between searches (read once per process otherwise)
 import argparse
 import json
 import sys
@@ -51,7 +53,7 @@ CASES = {
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", default="count_Sherlock")
+    ap.add_argument("--case", default="count_Sherlock", help="one case, a comma-separated list (one shard, one process), or 'all'")
     ap.add_argument("--gib", type=float, default=20.0)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--tune", action="store_true")
@@ -79,7 +81,7 @@ def main():
     del dts
     ctx = xsg.Context(0)
     sh = xsg.Shard(ctx, shard_t.data_ptr(), cap, xsg.make_chunks(off, ln))
-    names = [a.case] if a.case != "all" else list(CASES)
+    names = list(CASES) if a.case == "all" else a.case.split(",")
     modes = {"count": xsg.COUNT_MATCHES, "count_lines": xsg.COUNT_LINES, "count+nl": xsg.COUNT_MATCHES | xsg.WITH_NEWLINES}
     import os
     for name in names:

@@ -1,5 +1,9 @@
+import os
 import sys
 from pathlib import Path
+
+# the library reads its XSG_* toggles once per process; the route tests switch them between searches (x-search_amd/csrc/xsg_objects.h)
+os.environ.setdefault("XSG_TEST_HOOKS", "1")
 
 import pytest
 

@@ -67,7 +67,7 @@ class GpuSearch:
         out["newlines"] = int(c[xsg.CTR_NEWLINES])
         out["bytes"] = int(c[xsg.CTR_BYTES])
         out["match_byte_offsets"] = s.search_u64(xsg.MATCH_BYTE_OFFSETS).tolist()
-        if lines and (b"\n" not in pattern or (flags & xsg.FLAG_REGEX)):
+        if lines:  # (a LITERAL that contains '\n' is served by the line tags too: its walk is a chain of occurrences)
             out["count_lines"] = int(s.count(xsg.COUNT_LINES)[xsg.CTR_LINES])
             out["line_byte_offsets"] = s.search_u64(xsg.LINE_BYTE_OFFSETS).tolist()
             out["line_indices"] = s.search_u64(xsg.LINE_INDICES).tolist()
@@ -107,7 +107,7 @@ def oracle_all_modes(oracle, blocks, pattern: bytes, exact=False, global_offsets
             lb = nl_before if line_bases is None else int(line_bases[i])
             out["count_matches"] += oracle.count(b, pattern, False)
             out["match_byte_offsets"] += [int(x) + g for x in oracle.byte_offsets_match(b, pattern)]
-            if b"\n" not in pattern:
+            if True:  # (patterns that contain '\n' included: the reference's walk is defined for any string)
                 out["count_lines"] += oracle.count(b, pattern, True)
                 out["line_byte_offsets"] += [int(x) + g for x in oracle.byte_offsets_line(b, pattern)]
                 out["line_indices"] += [int(x) for x in oracle.line_indices(b, pattern, lb)]
@@ -119,9 +119,6 @@ def oracle_all_modes(oracle, blocks, pattern: bytes, exact=False, global_offsets
             out["bytes"] += int(b.size)
             goff += int(b.size)
             nl_before += nl
-        if b"\n" in pattern:
-            for k in ("count_lines", "line_byte_offsets", "line_indices", "lines", "lines_offsets"):
-                out.pop(k)
         return out
     finally:
         oracle.set_exact(False)

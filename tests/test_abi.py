@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/xsg.h but not exported by libxsg.so"
     assert sorted(xsg.EXPORTS) == names, "x-search_amd/xsg.py binds a different set than include/xsg.h declares"
-    assert lib.xsg_abi_version() == 3  # round 2: diagnostics left, RCCL and split-phase counts joined; round 3: two entry points more
+    assert lib.xsg_abi_version() == 4  # round 2: diagnostics left, RCCL and split-phase counts joined; round 3: two entry points more; round 4: xsg_count_async_status
 
 
 def test_chunk_struct_layout_matches_header():

@@ -243,11 +243,17 @@ def test_argument_errors(gs):
     assert e.value.code == xsg.EINVAL
     with pytest.raises(xsg.XsgError):
         gs.ctx.set_pattern(b"x" * (xsg.MAX_PATTERN + 1))
+    # (round 3 refused the line tags for a literal that contains '\n' and patterns over 1 KiB; both are answered now:
+    # test_line_tags_of_literals_that_contain_a_newline, test_patterns_up_to_32_kib)
     gs.bind([np.frombuffer(b"a\nb\n", dtype=np.uint8)])
     gs.ctx.set_pattern(b"a\n")
+    assert gs.shard.search_u64(xsg.LINE_BYTE_OFFSETS).tolist() == [0]
+    gs.ctx.set_pattern(b"a[^x]b", xsg.FLAG_REGEX)  # an EXPRESSION that can match '\n' keeps to the match tags
     with pytest.raises(xsg.XsgError) as e:
         gs.shard.search_u64(xsg.LINE_BYTE_OFFSETS)
     assert e.value.code == xsg.ENOTSUP
+    with pytest.raises(xsg.XsgError):
+        gs.ctx.set_pattern(b"x" * (xsg.MAX_REGEX + 1), xsg.FLAG_REGEX)
     # misaligned chunk offset
     import torch
     t = torch.zeros(4096, dtype=torch.uint8, device="cuda:0")
@@ -530,3 +536,93 @@ def test_one_long_chain_of_overlapping_occurrences(gs, oracle):
         assert_same(got, oracle_all_modes(oracle, blocks, pat), f"run of a, {pat!r}")
         assert got["count_matches"] >= (1 << 20) // len(pat)
         assert dt < 5.0, dt
+
+
+def test_line_tags_of_literals_that_contain_a_newline(gs, oracle):
+    """search_wrappers.h:29-50,163-207 for a pattern with '\\n' in it: the line walk is a chain from occurrence to
+    occurrence (after a match, on to the first newline at or behind its END), lines span several text lines, a pattern
+    that begins with '\\n' has its line start behind the match's first byte (:111-123).  All tags, both tail modes,
+    ignore_case, chunks with and without a final newline, long chains (every line of a chunk)."""
+    rng = np.random.default_rng(99)
+    blocks = []
+    for i in range(5):
+        n = int(rng.choice([0, 1, 50, 4095, 4096, 16384, 40000, 70001]))
+        b = np.frombuffer(b"ab\n", dtype=np.uint8)[rng.integers(0, 3, size=n)].copy()
+        if n and i % 2:
+            b[-1] = 10
+        blocks.append(b)
+    blocks.append(corpus.text_block(5, 0, 300_000, needle_rate=3e-4))
+    blocks.append(np.frombuffer(b"Sherlock\n" * 20000, dtype=np.uint8).copy())  # one chain through 20000 lines
+    for exact in (False, True):
+        gs.bind(blocks)
+        for pat in (b"a\n", b"\na", b"\n", b"\n\n", b"b\nb", b"ab\nab", b"\nab\n", b"k\nS", b"\nSherlock", b"Sherlock\nSherlock", b"e\nthe"):
+            got = gs.all_modes(pat, xsg.FLAG_EXACT_TAIL if exact else 0)
+            assert_same(got, oracle_all_modes(oracle, blocks, pat, exact), f"{pat!r} exact={exact}")
+    gs.bind(blocks)
+    for pat in (b"K\ns", b"\nSHERLOCK"):
+        assert_same(gs.all_modes(pat, xsg.FLAG_IGNORE_CASE), oracle_all_modes(oracle, blocks, pat, ignore_case=True), f"{pat!r} icase")
+    # the split-phase count (what the file pipeline calls) serves count_lines of such a pattern synchronously
+    gs.ctx.set_pattern(b"k\nS")
+    gs.shard.count_begin(xsg.COUNT_LINES)
+    assert int(gs.shard.count_end()[xsg.CTR_LINES]) == oracle_all_modes(oracle, blocks, b"k\nS")["count_lines"]
+    import torch
+    ctr = torch.zeros(xsg.NUM_COUNTERS + 1, dtype=torch.int64, device="cuda:0")
+    with pytest.raises(xsg.XsgError) as e:  # the stream-ordered entry point may not wait for the host: it says so
+        gs.shard.count_async(xsg.COUNT_LINES, 0, ctr.data_ptr())
+    assert e.value.code == xsg.ENOTSUP
+
+
+def test_patterns_up_to_32_kib(gs, oracle):
+    """XSG_MAX_PATTERN is 32 KiB since round 4 (the reference takes any std::string): the scan kernel keeps the first KiB
+    of a long pattern in LDS and verifies the rest of a candidate from the pattern's device copy; the end-of-chunk walk
+    reads it from there anyway."""
+    rng = np.random.default_rng(5)
+    base = corpus.text_block(31, 0, 400_000, needle_rate=1e-4)
+    for n in (1025, 2000, 5000, 20000, xsg.MAX_PATTERN):
+        o = int(rng.integers(0, base.size - n))
+        pat = base[o:o + n].tobytes()
+        # the pattern occurs where it was cut from; planted again twice, once in the chunk's last bytes (the lossy tail zone)
+        blocks = [base.copy(), np.concatenate([base[:100_000], base[o:o + n], base[100_000:150_000], base[o:o + n], base[:17]]),
+                  base[o:o + n].copy(), base[o:o + n - 1].copy()]
+        gs.bind(blocks)
+        for exact in (False, True):
+            got = gs.all_modes(pat, xsg.FLAG_EXACT_TAIL if exact else 0)
+            want = oracle_all_modes(oracle, blocks, pat, exact)
+            assert want["count_matches"] >= 3
+            assert_same(got, want, f"plen={n} exact={exact}")
+        near = pat[:-1] + bytes([pat[-1] ^ 1])  # differs in its last byte: every candidate is verified to the end and dropped
+        assert_same(gs.all_modes(near), oracle_all_modes(oracle, blocks, near), f"plen={n} near miss")
+
+
+def test_async_count_with_a_status_word(gs, oracle):
+    """xsg_count_async_status: what xsg_count_async reports by poisoning all four counters (UINT64_MAX) arrives as a
+    status word, and the counters read zero -- a caller that sums or all-reduces them cannot mistake it for a count."""
+    import torch
+    blocks = [corpus.text_block(21, i, 1 << 20, needle_rate=2e-4) for i in range(3)]
+    gs.bind(blocks)
+    buf = torch.full((xsg.NUM_COUNTERS + 1,), 77, dtype=torch.int64, device="cuda:0")
+    st = torch.cuda.Stream()
+    for pat, flags, mode in ((b"Sherlock", 0, xsg.COUNT_MATCHES | xsg.WITH_NEWLINES), (b"the", 0, xsg.COUNT_LINES), (b"abab", 0, xsg.COUNT_MATCHES)):
+        gs.ctx.set_pattern(pat, flags)
+        gs.shard.count_async_status(mode, st.cuda_stream, buf.data_ptr(), buf.data_ptr() + 8 * xsg.NUM_COUNTERS)
+        st.synchronize()
+        got = buf.cpu().numpy().astype(np.uint64)
+        assert int(got[xsg.NUM_COUNTERS]) == xsg.STATUS_OK
+        want = gs.shard.count(mode)
+        assert [int(x) for x in got[:xsg.NUM_COUNTERS]] == [int(x) for x in want], pat
+    # more raw occurrences of `aa` than the device-side list holds: status OVERFLOW, counters zero
+    run = np.full(2_500_000, ord("a"), dtype=np.uint8)
+    gs2 = GpuSearch()
+    gs2.bind([run])
+    gs2.ctx.set_pattern(b"aa")
+    gs2.shard.count_async_status(xsg.COUNT_MATCHES, st.cuda_stream, buf.data_ptr(), buf.data_ptr() + 8 * xsg.NUM_COUNTERS)
+    st.synchronize()
+    got = buf.cpu().numpy().astype(np.uint64)
+    assert int(got[xsg.NUM_COUNTERS]) == xsg.STATUS_OVERFLOW and not got[:xsg.NUM_COUNTERS].any()
+    # an ascii-only expression on data with a byte >= 0x80: status NONASCII, counters zero
+    gs2.bind([np.frombuffer("caf\u00e9 Sherlock\n".encode() * 50, dtype=np.uint8)])
+    gs2.ctx.set_pattern(b"S.erlock", xsg.FLAG_REGEX)
+    gs2.shard.count_async_status(xsg.COUNT_MATCHES, st.cuda_stream, buf.data_ptr(), buf.data_ptr() + 8 * xsg.NUM_COUNTERS)
+    st.synchronize()
+    got = buf.cpu().numpy().astype(np.uint64)
+    assert int(got[xsg.NUM_COUNTERS]) == xsg.STATUS_NONASCII and not got[:xsg.NUM_COUNTERS].any()

@@ -102,14 +102,28 @@ def test_job_errors(files, tmp_path):
     with pytest.raises(xsg.XsgError) as e:
         xsg.Job(b"x", files["txt"], xsg.COUNT_MATCHES, meta_path=str(bad))
     assert e.value.code == xsg.EIO
-    with pytest.raises(xsg.XsgError) as e:
-        xsg.Job(b"a\nb", files["txt"], xsg.LINES)
+    with pytest.raises(xsg.XsgError) as e:  # an EXPRESSION that can match '\n': the line tags refuse (a literal is served)
+        xsg.Job(b"a[^x]b", files["txt"], xsg.LINES, flags=xsg.FLAG_REGEX)
     assert e.value.code == xsg.ENOTSUP
     empty = tmp_path / "empty.txt"
     empty.write_bytes(b"")
     j = xsg.Job(b"x", str(empty), xsg.COUNT_MATCHES)
     assert j.result() == 0 and list(j) == []
     j.close()
+
+
+def test_job_with_a_pattern_that_contains_a_newline(files, oracle):
+    """every tag through the file pipeline for a literal with '\\n' in it (the reference's walk takes any string)"""
+    data = np.fromfile(files["txt"], dtype=np.uint8)
+    plan = xsg.plan_chunks(files["txt"], CHUNK)
+    chunks = [data[int(c["original_offset"]):int(c["original_offset"] + c["original_size"])] for c in plan]
+    for pat in (b"e\nthe", b"\nShe"):
+        want = oracle_all_modes(oracle, chunks, pat)
+        assert want["count_lines"] > 0
+        for tag in TAGS:
+            j = xsg.Job(pat, files["txt"], TAGS[tag], num_threads=2, num_max_readers=2, chunk_bytes=CHUNK)
+            assert as_py(tag, j.result()) == want[KEY[tag]], (pat, tag)
+            j.close()
 
 
 def run_cli(*args, env=None):

@@ -201,3 +201,72 @@ def test_generated_ignore_case_vectors(oracle):
         assert oracle.line_indices(low, p, 0).tolist() == e["line_indices"], ctx
         n += 1
     assert n >= 40
+
+
+def _py_walks(ref_or_oracle, data: bytes, pat: bytes):
+    """search_wrappers.h:29-52, 111-123, 149-154, 163-207 typed out in Python on top of findNext / findNextNewLine
+    (the reference's compiled primitives when `ref_or_oracle` is the Reference): what the reference's walks return for
+    ANY pattern, one that contains '\\n' included -- count(skip_to_nl), byte_offsets_line, line."""
+    n = len(data)
+
+    def prev_nl_rel(v):  # :111-123 (uint64 arithmetic: a match whose first byte is '\n' returns 2^64 - 1)
+        rel = 0
+        while True:
+            if data[v - rel] == 10:
+                return (rel - 1) & 0xFFFFFFFFFFFFFFFF
+            if rel >= v:
+                return v
+            rel += 1
+
+    count, line_offs, lines = 0, [], []
+    shift = 0
+    while shift < n:  # :163-185 with skip_to_nl and :29-52 with the line-start functor (:149-154)
+        m = ref_or_oracle.find_next(pat, data, shift)
+        if m == -1:
+            break
+        count += 1
+        line_offs.append((m - prev_nl_rel(m)) & 0xFFFFFFFFFFFFFFFF)
+        shift = m + len(pat)
+        nl = ref_or_oracle.find_next_newline(data, shift)
+        if nl == -1:
+            break
+        shift = nl + 1
+    shift = 0
+    while shift < n:  # :187-207
+        m = ref_or_oracle.find_next(pat, data, shift)
+        if m == -1:
+            break
+        begin = (m - prev_nl_rel(m)) & 0xFFFFFFFFFFFFFFFF
+        shift = m + len(pat)
+        end = ref_or_oracle.find_next_newline(data, shift)
+        if end == -1:
+            break
+        shift = end + 1
+        lines.append(data[begin:end])
+    return count, line_offs, lines
+
+
+def test_line_walks_of_patterns_that_contain_a_newline(oracle, reference):
+    """The reference's line walks are defined for any std::string (search_wrappers.h:29-50, 163-207): after a match, on to
+    the first '\\n' at or behind its END.  With a '\\n' inside the pattern an occurrence reaches into the next line and the
+    reported "line" spans several; a pattern that BEGINS with '\\n' gets its line start one byte behind the match start
+    (previous_new_line_offset_relative_to_match looks at the match's first byte first and wraps, :111-123).  The oracle's
+    C walks must equal the walks typed out above on the reference's own compiled findNext / findNextNewLine."""
+    rng = np.random.default_rng(4242)
+    pats = [b"a\n", b"\na", b"\n", b"\n\n", b"b\nb", b"ab\nab", b"a\nb\na", b"\nab\n", b"b\n\nb"]
+    cases = 0
+    for it in range(600):
+        n = int(rng.integers(0, 400))
+        data = bytes(np.frombuffer(b"ab\n", dtype=np.uint8)[rng.integers(0, 3, size=n)]) + b"a" * int(rng.integers(0, 80)) * int(rng.integers(0, 2))
+        if rng.random() < 0.5 and data:
+            data = data[:-1] + b"\n"
+        arr = np.frombuffer(data, dtype=np.uint8)
+        for p in pats:
+            want = _py_walks(reference, data, p)
+            assert oracle.count(arr, p, True) == want[0], (data, p)
+            assert [int(x) for x in oracle.byte_offsets_line(arr, p)] == want[1], (data, p)
+            assert oracle.lines(arr, p) == want[2], (data, p)
+            # xs::line_indices has no reference implementation (SURVEY 8a row a13): the newlines before the line start
+            assert [int(x) for x in oracle.line_indices(arr, p, 7)] == [7 + data[:b].count(b"\n") for b in want[1]], (data, p)
+            cases += 1
+    assert cases == 600 * len(pats)

@@ -37,6 +37,10 @@ int fail(int code, const char* fmt, ...) {
 const char* last_error_message() { return g_err; }
 
 static const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
+bool test_hooks() {
+  static const bool on = [] { const char* e = getenv("XSG_TEST_HOOKS"); return e && *e == '1'; }();
+  return on;
+}
 bool trace_on() {
   static const bool on = [] { const char* e = getenv("XSG_TRACE"); return e && *e && *e != '0'; }();
   return on;
@@ -286,7 +290,7 @@ static void class_fields(const xsg::ClassExpr& ex, bool icase, PatternDev* Pout,
     mw[i >> 2] |= (uint32_t)agree[koff + i] << (8 * (i & 3));
   }
   constexpr size_t kSetBytes = xsg::kMaxAltSets * sizeof(xsg::ByteSet);
-  blob->assign(std::max<size_t>(XSG_MAX_PATTERN, kSetBytes) + 16, 0);
+  blob->assign(std::max<size_t>(XSG_MAX_REGEX, kSetBytes) + 16, 0);
   for (size_t a = 0; a < ex.alts.size(); ++a)
     memcpy(blob->data() + a * plen * sizeof(xsg::ByteSet), ex.alts[a].data(), plen * sizeof(xsg::ByteSet));
   PatternDev& P = *Pout;
@@ -297,7 +301,7 @@ static void class_fields(const xsg::ClassExpr& ex, bool icase, PatternDev* Pout,
   P.p0 = pw[0], P.m0 = mw[0], P.p1 = pw[1], P.m1 = mw[1];
   P.q0 = (P.p0 | 0x20202020u) & P.m0, P.q1 = (P.p1 | 0x20202020u) & P.m1;
   {
-    const char* cf = getenv("XSG_CLS_FAST");
+    const char* cf = XSG_TOGGLE("XSG_CLS_FAST");
     P.cls_fast = (P.m1 == 0xffffffffu && (P.m0 & 0xffffu) == 0xffffu && !(cf && *cf == '0')) ? 1u : 0u;
   }
   P.exact_tail = 1u;
@@ -309,7 +313,7 @@ static void class_fields(const xsg::ClassExpr& ex, bool icase, PatternDev* Pout,
   // compare) -- and, under the 16 + 32 bit filter, the position is not one of the two that filter leaves out.
   // With several alternatives only a position that is one byte in all of them is decided (the compare sees the union).
   {
-    const char* ir = getenv("XSG_CLS_INREG");
+    const char* ir = XSG_TOGGLE("XSG_CLS_INREG");
     P.cls_chk = 0;
     for (size_t k = 0; k < plen && k < 8; ++k) {
       bool decided = true;
@@ -360,7 +364,7 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   memcpy(blob.data(), dfa.class_of, 256);
   // Trigger bytes: those that move the forward automaton out of its start state (a byte that cannot begin a match
   // leaves it there), and '\n'.  Flagged in bit 7 of the class table; k_rx_scan's walks jump from trigger to trigger.
-  const char* skip_env = getenv("XSG_RX_SKIP");
+  const char* skip_env = XSG_TOGGLE("XSG_RX_SKIP");
   bool skip = dfa.ncls <= 128 && !dfa.multiline && !(skip_env && *skip_env == '0');
   if (skip && !(skip_env && *skip_env == '1')) {
     // skipping pays when triggers are rare in the data; an expression that can begin with most letters (`\\w+ing`)
@@ -375,7 +379,7 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
       if (b == '\n' || dfa.fwd[(size_t)dfa.fwd_start * dfa.ncls + dfa.class_of[b]] != dfa.fwd_start * dfa.ncls) blob[b] |= 0x80u;
   memcpy(blob.data() + 256, dfa.fwd.data(), 2 * dfa.fwd.size());
   memcpy(blob.data() + rev_off, dfa.rev.data(), 2 * dfa.rev.size());
-  XSG_TRY(c->d_pat.ensure(std::max<size_t>(bytes, XSG_MAX_PATTERN + 16)));
+  XSG_TRY(c->d_pat.ensure(std::max<size_t>(bytes, XSG_MAX_REGEX + 16)));
   HIP_TRY(hipMemcpyAsync(c->d_pat.p, blob.data(), bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   PatternDev& P = c->pat;
@@ -399,7 +403,7 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   // few trigger byte values (`Sherlock|Holmes`: S, H; `Sher.*mes`: S; closed under case: up to four): k_rx_scan looks for
   // them with byte-parallel compares on its loads and does not stage a tile that holds none (XSG_RX_TRIG=0 switches it off)
   if (skip) {
-    const char* te = getenv("XSG_RX_TRIG");
+    const char* te = XSG_TOGGLE("XSG_RX_TRIG");
     uint32_t n = 0, packed = 0;
     for (uint32_t b = 0; b < 256; ++b)
       if (b != '\n' && (blob[b] & 0x80u)) {
@@ -417,7 +421,7 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   P.rx_anc_acc = dfa.anc_first_acc * dfa.ncls;
   // A selective start: the synchronous entry points find candidates with the class-sequence matcher and verify them
   // (rx_pre_matches); xsg_count_async, which may not wait for the host, keeps k_rx_scan.  XSG_RX_PRE=0 switches it off.
-  const char* pre_env = getenv("XSG_RX_PRE");
+  const char* pre_env = XSG_TOGGLE("XSG_RX_PRE");
   c->rx_pre = dfa.prefix.npos != 0 && !(pre_env && *pre_env == '0');
   c->rx_pre_forced = pre_env && *pre_env == '1';  // on shards of any size (tests; by default only where it pays, use_prefilter)
   if (c->rx_pre) {
@@ -431,7 +435,7 @@ static int set_dfa_pattern(xsg_ctx* c, const uint8_t* re, size_t n, uint32_t fla
   }
   // No selective start, but a factor every match contains (`\\w+ing`: `\\wing`): lines without it have no match, and the
   // synchronous entry points first mark the tiles in which a line with an occurrence starts (ensure_factor_mask).
-  const char* fac_env = getenv("XSG_RX_FAC");
+  const char* fac_env = XSG_TOGGLE("XSG_RX_FAC");
   c->rx_fac = !c->rx_pre && dfa.factor.npos != 0 && !(fac_env && *fac_env == '0');
   c->rx_fac_forced = fac_env && *fac_env == '1';
   if (c->rx_fac) {
@@ -497,7 +501,7 @@ static int dfa_route_serves(const void* expr, size_t n, uint32_t flags, const st
 extern "C" int xsg_regex_dfa_info(const void* expr, size_t n, uint32_t flags, xsg_regex_dfa* info, uint16_t* fwd,
                                   uint16_t* rev, size_t cap_entries) {
   if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
-  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  if (n > XSG_MAX_REGEX) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_REGEX);
   if (!info) return fail(XSG_EINVAL, "info is null");
   xsg::RegexDfa dfa;
   std::string err;
@@ -519,7 +523,7 @@ extern "C" int xsg_regex_dfa_info(const void* expr, size_t n, uint32_t flags, xs
 extern "C" int xsg_regex_prefix(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* alternatives,
                                 uint32_t* sets) {
   if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
-  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  if (n > XSG_MAX_REGEX) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_REGEX);
   xsg::RegexDfa dfa;
   std::string err;
   if (!xsg::compile_regex_dfa(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &dfa, &err))
@@ -534,7 +538,7 @@ extern "C" int xsg_regex_prefix(const void* expr, size_t n, uint32_t flags, uint
 
 extern "C" int xsg_regex_factor(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets) {
   if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
-  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  if (n > XSG_MAX_REGEX) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_REGEX);
   xsg::RegexDfa dfa;
   std::string err;
   if (!xsg::compile_regex_dfa(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &dfa, &err))
@@ -546,7 +550,7 @@ extern "C" int xsg_regex_factor(const void* expr, size_t n, uint32_t flags, uint
 
 extern "C" int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* sets) {
   if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
-  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  if (n > XSG_MAX_REGEX) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_REGEX);
   xsg::ClassExpr ex;
   std::string err;
   if (!xsg::compile_class_expr(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &ex, &err)) {
@@ -563,7 +567,7 @@ extern "C" int xsg_regex_check(const void* expr, size_t n, uint32_t flags, uint3
 extern "C" int xsg_regex_info(const void* expr, size_t n, uint32_t flags, uint32_t* positions, uint32_t* alternatives,
                               uint32_t* ascii_only, uint32_t* sets) {
   if (!expr || n == 0) return fail(XSG_EINVAL, "empty expression");
-  if (n > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_PATTERN);
+  if (n > XSG_MAX_REGEX) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_REGEX);
   xsg::ClassExpr ex;
   std::string err;
   if (!xsg::compile_class_expr(static_cast<const uint8_t*>(expr), n, (flags & XSG_FLAG_IGNORE_CASE) != 0, &ex, &err)) {
@@ -589,7 +593,10 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   if (plen > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "pattern longer than %u bytes", XSG_MAX_PATTERN);
   if (flags & ~(XSG_FLAG_EXACT_TAIL | XSG_FLAG_IGNORE_CASE | XSG_FLAG_REGEX))
     return fail(XSG_EINVAL, "unknown pattern flags 0x%x", flags);
-  if (flags & XSG_FLAG_REGEX) return set_class_pattern(c, static_cast<const uint8_t*>(pattern), plen, flags);
+  if (flags & XSG_FLAG_REGEX) {
+    if (plen > XSG_MAX_REGEX) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_REGEX);
+    return set_class_pattern(c, static_cast<const uint8_t*>(pattern), plen, flags);
+  }
   HIP_TRY(hipSetDevice(c->device));
   c->pattern.assign(static_cast<const uint8_t*>(pattern), static_cast<const uint8_t*>(pattern) + plen);
   if (flags & XSG_FLAG_IGNORE_CASE)  // simd::toLower on the pattern (string_utils.cpp:11-33)
@@ -618,13 +625,16 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   }
 
   // padded device copy (the long-pattern verify and the tail walk read it)
-  XSG_TRY(c->d_pat.ensure(XSG_MAX_PATTERN + 16));
-  std::vector<uint8_t> padded(XSG_MAX_PATTERN + 16, 0);
+  // (at least a KiB: the long-pattern kernel stages min(plen, 1 KiB) into LDS, the tail kernels read a few bytes past short patterns)
+  const size_t pat_bytes = std::max<size_t>(plen, 1024) + 16;
+  XSG_TRY(c->d_pat.ensure(pat_bytes));
+  std::vector<uint8_t> padded(pat_bytes, 0);
   memcpy(padded.data(), p, plen);
   HIP_TRY(hipMemcpyAsync(c->d_pat.p, padded.data(), padded.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
 
   PatternDev& P = c->pat;
+  P = PatternDev{};
   P.plen = (uint32_t)plen;
   window_fields(p, plen, pick_filter_window(p, plen), &P);  // koff 0 unless plen > 8
   c->koff_cands = window_candidates(p, plen);
@@ -634,6 +644,7 @@ extern "C" int xsg_set_pattern(xsg_ctx* c, const void* pattern, size_t plen, uin
   P.d_pat = c->d_pat.as<uint8_t>();
   P.exact_tail = (flags & XSG_FLAG_EXACT_TAIL) ? 1u : 0u;
   P.has_newline = memchr(p, '\n', plen) != nullptr;
+  P.nl_first = p[0] == '\n' ? 1u : 0u;
   P.icase = (flags & XSG_FLAG_IGNORE_CASE) ? 1u : 0u;
   return XSG_OK;
 }
@@ -971,7 +982,9 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st, bool want_nl = false,
     for (uint32_t hot = 0; hot < 2 && rc == XSG_OK; ++hot) {
       ScanArgs a = scan_args(s);
       a.pat.hot = hot;
-      a.tune = 0;
+      // (with the wave stagger the variant's real launches use: round 3 timed with the stagger off, which is how the
+      // newline-counting variant runs anyway -- but count_lines runs with 16, and there the aligned trigger wins by 3.7 %
+      // where it ties with the stagger off: profiles/r04_dense_variants.txt)
       a.ntiles = std::min<uint64_t>(a.ntiles, 131072);
       // one timed launch per round (0.3 ms on the 2 GiB prefix); the first round warms up first (that pulls the code in)
       hipError_t e = round == 0 ? launch_scan_count(a, want_nl, want_lines, st) : hipSuccess;
@@ -987,7 +1000,7 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st, bool want_nl = false,
   }
   // the aligned trigger has to win: by 2 % where the variant is VALU-bound and the stakes are 12 %; by any margin the
   // probe can see where the kernel waits for memory (the plain count: 1.7 % either way, measured with the stagger off)
-  s->hot_v[v] = ms[1] < (v == 0 ? 0.995f : 0.98f) * ms[0] ? 1u : 0u;
+  s->hot_v[v] = ms[1] < (v == 0 ? 0.995f : 0.985f) * ms[0] ? 1u : 0u;
   s->hot_known |= (uint8_t)(1u << v);
   static const bool probe_log = getenv("XSG_PROBE_LOG") != nullptr;
   if (probe_log)
@@ -1043,7 +1056,8 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st, bool want_nl = false,
 }
 
 static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool want_nl, hipStream_t st,
-                         uint64_t* d_counters, uint64_t* host_counters, const PatternDev* other_pattern = nullptr) {
+                         uint64_t* d_counters, uint64_t* host_counters, const PatternDev* other_pattern = nullptr,
+                         uint64_t* d_status = nullptr) {
   if (want_nl) XSG_TRY(ensure_tile_nl(s));
   const uint64_t nchunks = s->chunks.size();
   // kDfa: k_rx_scan counts matching lines directly into tile_cnt (a line is one lane's work): no line summaries
@@ -1078,6 +1092,7 @@ static int enqueue_count(xsg_shard* s, bool want_matches, bool want_lines, bool 
   f.tile_bytes = s->tile_bytes;
   f.counters = d_counters;
   f.host_counters = host_counters;
+  f.status = d_status;
   f.partials = s->d_finish.as<uint64_t>();
   f.ticket = reinterpret_cast<uint32_t*>(s->d_finish.as<uint64_t>() + 3 * (size_t)kFinishBlocks);
   f.flags = a.flags;
@@ -1109,9 +1124,9 @@ static int ensure_overlap_check(xsg_shard* s) {
   s->overlap_free = false;
   if (!c->bordered || c->overlap_words.empty() || s->ntiles == 0) return XSG_OK;
   hipStream_t st = c->stream;
-  XSG_TRY(c->d_aux_pat.ensure(XSG_MAX_PATTERN + 16));
   for (const std::vector<uint8_t>& w : c->overlap_words) {
-    std::vector<uint8_t> padded(XSG_MAX_PATTERN + 16, 0);
+    std::vector<uint8_t> padded(std::max<size_t>(w.size(), 1024) + 16, 0);
+    XSG_TRY(c->d_aux_pat.ensure(padded.size()));
     memcpy(padded.data(), w.data(), w.size());
     HIP_TRY(hipMemcpyAsync(c->d_aux_pat.p, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // (`padded` leaves scope)
@@ -1139,7 +1154,7 @@ static int ensure_overlap_check(xsg_shard* s) {
 // from tile_off[ntiles], and a final kernel adds up keep[] and the tail counts.  More occurrences than capacity
 // -> all four counters UINT64_MAX (like the ascii_only refusal): the caller takes xsg_count, which also teaches
 // the shard the size for next time.
-static int enqueue_count_bordered(xsg_shard* s, hipStream_t st, uint64_t* d_counters) {
+static int enqueue_count_bordered(xsg_shard* s, hipStream_t st, uint64_t* d_counters, uint64_t* d_status) {
   xsg_ctx* c = s->ctx;
   const uint64_t nchunks = s->chunks.size();
   const uint64_t ntiles = s->ntiles;
@@ -1186,7 +1201,7 @@ static int enqueue_count_bordered(xsg_shard* s, hipStream_t st, uint64_t* d_coun
   HIP_TRY(launch_chunk_shift0(l, st));
   HIP_TRY(launch_tail_list(l, st));
   HIP_TRY(hipMemsetAsync(d_counters, 0, 8 * XSG_NUM_COUNTERS, st));
-  HIP_TRY(launch_bordered_total(l, d_counters, s->total_bytes, a.flags, st));
+  HIP_TRY(launch_bordered_total(l, d_counters, s->total_bytes, a.flags, d_status, st));
   s->last_mode = -1;
   return XSG_OK;
 }
@@ -1200,7 +1215,7 @@ static int refuse_if_poisoned(const uint64_t counters[XSG_NUM_COUNTERS]) {
   return XSG_OK;
 }
 
-extern "C" int xsg_count_async(xsg_shard* s, uint32_t mode, void* stream, uint64_t* d_counters) {
+static int count_async_impl(xsg_shard* s, uint32_t mode, void* stream, uint64_t* d_counters, uint64_t* d_status) {
   XSG_TRY(check_ready(s));
   if (!d_counters) return fail(XSG_EINVAL, "d_counters is null");
   const uint32_t m = mode & 0xffu;
@@ -1213,18 +1228,34 @@ extern "C" int xsg_count_async(xsg_shard* s, uint32_t mode, void* stream, uint64
     if (c->bordered && !overlap_free_known(s)) {  // (known from an earlier synchronous call: this entry point may not wait)
       if (want_nl)
         return fail(XSG_ENOTSUP, "pattern can overlap itself: XSG_WITH_NEWLINES next to its match count needs xsg_count()");
-      return enqueue_count_bordered(s, st, d_counters);
+      return enqueue_count_bordered(s, st, d_counters, d_status);
     }
-    return enqueue_count(s, true, false, want_nl, st, d_counters, nullptr);
+    return enqueue_count(s, true, false, want_nl, st, d_counters, nullptr, nullptr, d_status);
   }
   if (m == XSG_COUNT_LINES) {
-    if (c->pat.has_newline) return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
-    return enqueue_count(s, false, true, want_nl, st, d_counters, nullptr);
+    if (c->pat.has_newline)
+      return fail(XSG_ENOTSUP, "count_lines of a pattern that contains '\\n' walks a chain of occurrences: the stream-ordered entry "
+                               "point does not serve it, xsg_count() does");
+    return enqueue_count(s, false, true, want_nl, st, d_counters, nullptr, nullptr, d_status);
   }
   return fail(XSG_EINVAL, "xsg_count_async: mode %u is not a count mode", m);
 }
 
+extern "C" int xsg_count_async(xsg_shard* s, uint32_t mode, void* stream, uint64_t* d_counters) {
+  return count_async_impl(s, mode, stream, d_counters, nullptr);
+}
+
+extern "C" int xsg_count_async_status(xsg_shard* s, uint32_t mode, void* stream, uint64_t* d_counters, uint64_t* d_status) {
+  if (!d_status) return fail(XSG_EINVAL, "d_status is null");
+  return count_async_impl(s, mode, stream, d_counters, d_status);
+}
+
 static int run_list(xsg_shard* s, uint32_t mode, bool outputs);
+// A LITERAL that contains '\n': its line tags are a chain of occurrences (k_nlpat_links), resolved on the exact list
+// route.  (An EXPRESSION that can match '\n' keeps being refused by the line tags: RE2's walk over a re-sliced input is
+// not restated for it.)
+static bool newline_literal(const xsg_ctx* c) { return c->pat.has_newline && c->pat.kind != kClass && c->pat.kind != kDfa; }
+static const char* const kNewlineExprMsg = "line modes do not accept an expression that can match '\\n'";
 // The prefilter route is half a dozen kernels and three trips to the host where k_rx_scan is one pass: it pays on
 // shards where a pass takes longer than that (the file pipeline's 16 MiB chunks are walked by k_rx_scan in tens of
 // microseconds).
@@ -1321,8 +1352,7 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
     // the prefilter route of the automaton family: candidates, verification and the walk produce the list; its
     // length is the count (the newline total, if asked for, comes from the cached per-tile counts)
     if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
-    if (m == XSG_COUNT_LINES && c->pat.has_newline)
-      return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+    if (m == XSG_COUNT_LINES && c->pat.has_newline) return fail(XSG_ENOTSUP, "%s", kNewlineExprMsg);
     s->want_nl_total = (mode & XSG_WITH_NEWLINES) != 0;
     const int r = run_list(s, m == XSG_COUNT_MATCHES ? XSG_MATCH_BYTE_OFFSETS : XSG_LINE_BYTE_OFFSETS, false);
     s->want_nl_total = false;
@@ -1338,12 +1368,14 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
     // too many candidates for the list route to pay: the count passes below walk every line (k_rx_scan)
   }
   if (m == XSG_COUNT_MATCHES && c->bordered) XSG_TRY(ensure_overlap_check(s));
-  if (m == XSG_COUNT_MATCHES && c->bordered && !overlap_free_known(s)) {
-    // greedy non-overlap needs the ordered occurrence list
-    XSG_TRY(run_list(s, XSG_MATCH_BYTE_OFFSETS, false));
+  const bool chain_lines = m == XSG_COUNT_LINES && newline_literal(c);  // the line walk of a literal with '\n' in it
+  if ((m == XSG_COUNT_MATCHES && c->bordered && !overlap_free_known(s)) || chain_lines) {
+    // greedy non-overlap (and the line walk of a pattern that holds a newline) needs the ordered occurrence list
+    if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
+    XSG_TRY(run_list(s, chain_lines ? XSG_LINE_BYTE_OFFSETS : XSG_MATCH_BYTE_OFFSETS, false));
     note_density(s, s->total);
     memset(counters, 0, 8 * XSG_NUM_COUNTERS);
-    counters[XSG_CTR_MATCHES] = s->total;
+    counters[chain_lines ? XSG_CTR_LINES : XSG_CTR_MATCHES] = s->total;
     counters[XSG_CTR_BYTES] = s->total_bytes;
     if (mode & XSG_WITH_NEWLINES) {
       XSG_TRY(enqueue_count(s, false, false, true, c->stream, s->d_counters.as<uint64_t>(), s->h_counters));
@@ -1356,8 +1388,7 @@ extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_
   }
   const bool want_nl = (mode & XSG_WITH_NEWLINES) != 0;
   if (mode & ~(0xffu | XSG_WITH_NEWLINES)) return fail(XSG_EINVAL, "unknown mode bits 0x%x", mode);
-  if (m == XSG_COUNT_LINES && c->pat.has_newline)
-    return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+  if (m == XSG_COUNT_LINES && c->pat.has_newline) return fail(XSG_ENOTSUP, "%s", kNewlineExprMsg);
   // the finish kernel writes the four values straight into pinned host memory: no copy, one sync
   XSG_TRY(enqueue_count(s, m == XSG_COUNT_MATCHES, m == XSG_COUNT_LINES, want_nl, c->stream,
                         s->d_counters.as<uint64_t>(), s->h_counters));
@@ -1380,13 +1411,13 @@ extern "C" int xsg_count_begin(xsg_shard* s, uint32_t mode) {
   s->begin_sync_result = false;
   XSG_TRY(ensure_factor_mask(s));
   if (m == XSG_COUNT_MATCHES && c->bordered) XSG_TRY(ensure_overlap_check(s));
-  if ((m == XSG_COUNT_MATCHES && c->bordered && !overlap_free_known(s)) || (use_prefilter(s) && s->pre_dense_serial != c->pattern_serial)) {  // needs the ordered list: done synchronously, handed out by _end
+  if ((m == XSG_COUNT_MATCHES && c->bordered && !overlap_free_known(s)) || (m == XSG_COUNT_LINES && newline_literal(c)) ||
+      (use_prefilter(s) && s->pre_dense_serial != c->pattern_serial)) {  // needs the ordered list: done synchronously, handed out by _end
     XSG_TRY(xsg_count(s, mode, s->begin_counters));
     s->begin_sync_result = true;
     return XSG_OK;
   }
-  if (m == XSG_COUNT_LINES && c->pat.has_newline)
-    return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+  if (m == XSG_COUNT_LINES && c->pat.has_newline) return fail(XSG_ENOTSUP, "%s", kNewlineExprMsg);
   XSG_TRY(enqueue_count(s, m == XSG_COUNT_MATCHES, m == XSG_COUNT_LINES, (mode & XSG_WITH_NEWLINES) != 0, c->stream,
                         s->d_counters.as<uint64_t>(), s->h_counters));
   HIP_TRY(hipEventRecord(s->table_ev, c->stream));  // doubles as "pass done": it covers the table upload too
@@ -1532,7 +1563,7 @@ static int d2h_u64(xsg_ctx* c, const uint64_t* d, uint64_t* h) {
 constexpr int kFastOverflow = 2;  // run_list_fast: capacity exceeded, tile counts in place -> the exact route from step 2
 
 static uint64_t fast_capacity(const xsg_shard* s) {
-  if (const char* e = getenv("XSG_LIST_CAP")) {  // tests: tiny capacities force the fallback
+  if (const char* e = XSG_TOGGLE("XSG_LIST_CAP")) {  // tests: tiny capacities force the fallback
     const long long v = atoll(e);
     if (v > 0) return (uint64_t)v;
   }
@@ -1542,13 +1573,37 @@ static uint64_t fast_capacity(const xsg_shard* s) {
 
 static bool fast_route_serves(const xsg_shard* s, uint32_t mode, bool outputs) {
   const xsg_ctx* c = s->ctx;
-  const char* e = getenv("XSG_LIST_FAST");  // 0: every list search takes the exact route (tests, A/B)
+  const char* e = XSG_TOGGLE("XSG_LIST_FAST");  // 0: every list search takes the exact route (tests, A/B)
   if ((e && *e == '0') || !outputs || s->ntiles == 0 || s->want_nl_total) return false;
   if (c->pat.kind == kDfa) return false;                                // k_rx_scan / the prefilter route: exact route
+  if (mode != XSG_MATCH_BYTE_OFFSETS && c->pat.has_newline) return false;  // the line walk of a literal with '\n': a chain, exact route
   if (mode == XSG_MATCH_BYTE_OFFSETS && c->bordered && !overlap_free_known(s)) return false;  // greedy keep: exact route
   if (s->chunks.size() > (1u << 20)) return false;                      // the tail prefix is one workgroup's work
   if (s->ntiles >= (1ull << 32)) return false;                          // hit list: uint32 tile numbers
-  return s->fast_dense_serial != c->pattern_serial;
+  return s->fast_dense_serial != c->pattern_serial && c->fast_dense_serial != c->pattern_serial;
+}
+
+// The pinned mirrors of list results only grow while results grow: one needle in most lines of a large shard leaves
+// gigabytes page-locked (offsets, line lengths, line bytes).  A search that needs less than a sixteenth of what is
+// retained gives the large buffers back before it runs (they come again on demand; a caller that repeats the dense
+// search keeps them: its results keep needing them).  Sizes in bytes.
+static void trim_pinned(xsg_shard* s, size_t need_u64, size_t need_len, size_t need_bytes) {
+  constexpr size_t kKeep = 64u << 20;
+  if (s->h_result && s->h_result_cap > kKeep && need_u64 < s->h_result_cap / 16) {
+    (void)hipHostFree(s->h_result);
+    s->h_result = nullptr;
+    s->h_result_cap = 0;
+  }
+  if (s->hp_line_len && 8 * s->hp_line_len_cap > kKeep && need_len < 8 * s->hp_line_len_cap / 16) {
+    (void)hipHostFree(s->hp_line_len);
+    s->hp_line_len = nullptr;
+    s->hp_line_len_cap = 0;
+  }
+  if (s->hp_line_bytes && s->hp_line_bytes_cap > kKeep && need_bytes < s->hp_line_bytes_cap / 16) {
+    (void)hipHostFree(s->hp_line_bytes);
+    s->hp_line_bytes = nullptr;
+    s->hp_line_bytes_cap = 0;
+  }
 }
 
 template <typename T>
@@ -1602,12 +1657,14 @@ static int run_list_fast(xsg_shard* s, uint32_t mode) {
     XSG_TRY(s->d_f_match.ensure(8 * fcap));
     XSG_TRY(s->d_f_chunk.ensure(4 * fcap));
   }
+  trim_pinned(s, 8 * (size_t)fcap, 8 * (size_t)fcap, (size_t)bytes_cap);  // what an earlier dense result left page-locked
   {
     size_t have = s->h_result_cap / 8;
     uint64_t* hp = static_cast<uint64_t*>(s->h_result);
-    XSG_TRY(ensure_pinned(&hp, &have, (size_t)fcap));
-    s->h_result = hp;
+    const int pr = ensure_pinned(&hp, &have, (size_t)fcap);
+    s->h_result = hp;  // (written back on failure too: the old buffer is gone then)
     s->h_result_cap = have * 8;
+    XSG_TRY(pr);
   }
   if (mode == XSG_LINES) {
     XSG_TRY(s->d_line_len.ensure(8 * fcap));
@@ -1790,6 +1847,7 @@ static int run_list_fast(xsg_shard* s, uint32_t mode) {
   }
   if (s->h_tot[kTotOverflow]) {
     s->fast_dense_serial = c->pattern_serial;  // later searches of this pattern on this binding: the exact route at once
+    c->fast_dense_serial = c->pattern_serial;  // ... and on later bindings of this context (the next chunks of a file)
     return kFastOverflow;
   }
   const uint64_t total = s->h_tot[kTotFinal];
@@ -1815,8 +1873,8 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   const bool want_nl = mode == XSG_LINE_INDICES || s->want_nl_total;
   const uint64_t nchunks = s->chunks.size();
   const uint64_t ntiles = s->ntiles;
-  if (line_mode && c->pat.has_newline)
-    return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
+  if (line_mode && c->pat.has_newline && !newline_literal(c)) return fail(XSG_ENOTSUP, "%s", kNewlineExprMsg);
+  const bool chain_lines = line_mode && newline_literal(c);
 
   s->last_mode = -1;
   s->total = 0;
@@ -1974,13 +2032,37 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
   l.tail_pre = s->d_tail_pre.as<uint64_t>();
   l.line_mode = line_mode ? 1u : 0u;
 
-  if (line_mode) {
+  // words behind the finish kernel's ticket and the scan flags: [0] "a chain outran its walker", [1] "a round marked something"
+  uint32_t* words = reinterpret_cast<uint32_t*>(s->d_finish.as<uint64_t>() + 3 * (size_t)kFinishBlocks) + 2;
+  // closure of the marked entries under the links J (J2: scratch): pointer jumping, log2(longest chain) rounds of
+  // "mark J(marked), square J" until a round marks nothing new (xsg_list_kernels.hip: k_greedy_jump)
+  auto close_chains = [&](uint32_t* J, uint32_t* J2) -> int {
+    for (int round = 0; round < 40; ++round) {  // 2^40 entries would not fit the index type anyway
+      uint32_t changed = 0;
+      HIP_TRY(hipMemsetAsync(words + 1, 0, 4, st));
+      HIP_TRY(launch_greedy_jump(l, J, J2, words + 1, st));
+      HIP_TRY(hipMemcpyAsync(&changed, words + 1, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (!changed) break;
+      std::swap(J, J2);
+    }
+    return XSG_OK;
+  };
+  if (chain_lines) {
+    // a literal that contains '\n': line starts, chunk heads and the walk's links, then the closure (see k_nlpat_links)
+    if (M >= 0xffffffffull) return fail(XSG_ENOTSUP, "more than 2^32 occurrences of a pattern that contains '\\n': its line walk is not served");
+    if (M) {
+      XSG_TRY(s->d_c_pos.ensure(4 * M));  // the link arrays borrow the prefilter route's candidate buffers (unused by literals)
+      XSG_TRY(s->d_c_pre.ensure(4 * M));
+      HIP_TRY(launch_nlpat_links(l, s->d_c_pos.as<uint32_t>(), st));
+      XSG_TRY(close_chains(s->d_c_pos.as<uint32_t>(), s->d_c_pre.as<uint32_t>()));
+    }
+  } else if (line_mode) {
     HIP_TRY(launch_line_starts_keep(l, st));
   } else if (c->bordered && !overlap_free_known(s)) {
     // chain heads walk their chains (a few entries at text densities); a chain over the budget -- a long run of one
     // byte searched for `aa` is ONE chain per chunk -- raises a flag and is finished by pointer jumping, log2(length)
     // parallel rounds (xsg_list_kernels.hip: k_greedy_links / k_greedy_jump)
-    uint32_t* words = reinterpret_cast<uint32_t*>(s->d_finish.as<uint64_t>() + 3 * (size_t)kFinishBlocks) + 2;  // behind ticket and scan flags
     const bool can_jump = M < 0xffffffffull;
     if (M) HIP_TRY(hipMemsetAsync(l.keep, 0, 4 * M, st));
     HIP_TRY(hipMemsetAsync(words, 0, 8, st));
@@ -1994,18 +2076,8 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     if (is_long) {
       XSG_TRY(s->d_c_pos.ensure(4 * M));  // the link arrays borrow the prefilter route's candidate buffers (unused by literals)
       XSG_TRY(s->d_c_pre.ensure(4 * M));
-      uint32_t* J = s->d_c_pos.as<uint32_t>();
-      uint32_t* J2 = s->d_c_pre.as<uint32_t>();
-      HIP_TRY(launch_greedy_links(l, J, st));
-      for (int round = 0; round < 40; ++round) {  // 2^40 entries would not fit the index type anyway
-        uint32_t changed = 0;
-        HIP_TRY(hipMemsetAsync(words + 1, 0, 4, st));
-        HIP_TRY(launch_greedy_jump(l, J, J2, words + 1, st));
-        HIP_TRY(hipMemcpyAsync(&changed, words + 1, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (!changed) break;
-        std::swap(J, J2);
-      }
+      HIP_TRY(launch_greedy_links(l, s->d_c_pos.as<uint32_t>(), st));
+      XSG_TRY(close_chains(s->d_c_pos.as<uint32_t>(), s->d_c_pre.as<uint32_t>()));
     }
   } else {
     HIP_TRY(launch_keep_all(l, st));
@@ -2126,6 +2198,7 @@ extern "C" int xsg_search(xsg_shard* s, uint32_t mode, uint64_t* n_results) {
     return fail(XSG_EINVAL, "xsg_search: mode %u is not a list mode", mode);
   HIP_TRY(hipSetDevice(s->ctx->device));
   XSG_TRY(run_list(s, mode, true));
+  if (!s->fast_result) trim_pinned(s, 8 * (size_t)s->total, 8 * (size_t)s->total, (size_t)s->line_bytes);  // (an exact-route result is still on the device)
   if (n_results) *n_results = s->total;
   return XSG_OK;
 }
@@ -2270,9 +2343,10 @@ extern "C" int xsg_result_lines_view(xsg_shard* s, const uint64_t** lengths, con
     {
       size_t have = s->h_result_cap / 8;
       uint64_t* hp = static_cast<uint64_t*>(s->h_result);
-      XSG_TRY(ensure_pinned(&hp, &have, (size_t)raw));
+      const int pr = ensure_pinned(&hp, &have, (size_t)raw);
       s->h_result = hp;
       s->h_result_cap = have * 8;
+      XSG_TRY(pr);
     }
     if (raw) HIP_TRY(hipMemcpyAsync(s->h_result, s->d_out_u64.p, 8 * raw, hipMemcpyDeviceToHost, c->stream));
     if (s->line_bytes) HIP_TRY(hipMemcpyAsync(s->hp_line_bytes, s->d_line_bytes.p, s->line_bytes, hipMemcpyDeviceToHost, c->stream));

@@ -318,6 +318,16 @@ static int need_zstd() {
   return XSG_OK;
 }
 
+extern "C" const char* xsg_codec_name(int32_t compression) {
+  if (compression == XSG_COMPRESSION_NONE) return "none";
+  if (compression == XSG_COMPRESSION_LZ4) {
+    if (need_lz4() != XSG_OK) return "";
+    return codecs().lz4 == &g_builtin_lz4_token ? "built-in LZ4 block codec" : "liblz4";
+  }
+  if (compression == XSG_COMPRESSION_ZSTD) return need_zstd() == XSG_OK ? "libzstd" : "";
+  return "";
+}
+
 static int decompress_chunk(int32_t type, const uint8_t* src, uint64_t src_n, uint8_t* dst, uint64_t dst_n) {
   if (type == XSG_COMPRESSION_LZ4) {
     // raw LZ4 block per chunk, decoded to exactly original_size bytes
@@ -739,7 +749,7 @@ static int device_pci_file(int device, const char* leaf, char* buf, size_t cap) 
 
 // CPUs local to the device that this process may run on; false = no usable information (or XSG_NUMA=0)
 static bool device_cpuset(int device, cpu_set_t* out) {
-  const char* env = getenv("XSG_NUMA");
+  static const char* const env = getenv("XSG_NUMA");
   if (env && *env == '0') return false;
   char text[1024];
   if (device_pci_file(device, "local_cpulist", text, sizeof text) != 0) return false;
@@ -1141,6 +1151,7 @@ static int job_start_impl(const void* pattern, size_t plen, const char* file_pat
   if (!opts || opts->struct_size != sizeof(xsg_job_opts)) return fail(XSG_EINVAL, "bad xsg_job_opts (struct_size)");
   if (!pattern || plen == 0 || plen > XSG_MAX_PATTERN) return fail(XSG_EINVAL, "pattern must be 1..%u bytes",
                                                                   XSG_MAX_PATTERN);
+  if ((opts->pattern_flags & XSG_FLAG_REGEX) && plen > XSG_MAX_REGEX) return fail(XSG_EINVAL, "expression longer than %u bytes", XSG_MAX_REGEX);
   if (opts->mode > XSG_LINES) return fail(XSG_EINVAL, "bad mode %u", opts->mode);
   if (opts->num_threads < 1 || opts->num_max_readers < 1) return fail(XSG_EINVAL, "num_threads/num_max_readers < 1");
   const bool line_mode = opts->mode != XSG_COUNT_MATCHES && opts->mode != XSG_MATCH_BYTE_OFFSETS;
@@ -1155,9 +1166,7 @@ static int job_start_impl(const void* pattern, size_t plen, const char* file_pat
       XSG_TRY(xsg_regex_dfa_info(pattern, plen, opts->pattern_flags & XSG_FLAG_IGNORE_CASE, &info, nullptr, nullptr, 0));
       if (info.multiline) return fail(XSG_ENOTSUP, "line modes do not accept a pattern that can match '\\n'");
     }
-  } else if (line_mode && memchr(pattern, '\n', plen) != nullptr) {
-    return fail(XSG_ENOTSUP, "line modes do not accept a pattern containing '\\n'");
-  }
+  }  // (a LITERAL that contains '\n' is served by every tag since round 4: xsg.h, xsg_set_pattern)
   std::unique_ptr<xsg_job> j(new (std::nothrow) xsg_job());
   if (!j) return fail(XSG_ENOMEM, "host allocation failed");
   j->opts = *opts;

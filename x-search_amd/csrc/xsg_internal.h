@@ -55,6 +55,8 @@ struct PatternDev {
   uint32_t koff;            // kLong, kClass: offset of the 8-byte filter window inside the pattern (0 for the other kinds)
   const uint8_t* d_pat;     // device copy of the pattern
   uint32_t exact_tail;      // XSG_FLAG_EXACT_TAIL
+  uint32_t nl_first;        // literal whose FIRST byte is '\n': the reference's line start of a match then lies one byte behind the
+                            // match's first byte (previous_new_line_offset_relative_to_match looks at that byte first, :111-123)
   uint32_t has_newline;     // pattern contains '\n'
   uint32_t icase;           // XSG_FLAG_IGNORE_CASE: data bytes are ASCII-lowered before every compare (pattern is lowered on the host)
   uint32_t lazy_exact;      // ignore_case: every byte of the filter window is a letter, so the hot filter on (data | 0x20) IS the
@@ -142,6 +144,8 @@ struct FinishArgs {
   uint32_t tile_bytes;
   uint64_t* counters;       // device, XSG_NUM_COUNTERS: overwritten (no zeroing needed)
   uint64_t* host_counters;  // optional: pinned host mirror of the same four values
+  uint64_t* status;         // optional (xsg_count_async_status): receives XSG_STATUS_* bits; a refusal then ZEROES the counters
+                            // instead of poisoning them
   uint64_t* partials;       // scratch: 3 x kFinishBlocks
   uint32_t* ticket;         // zero at rest: the last workgroup to arrive does the final sum and resets it
   uint32_t* flags;          // ScanArgs::flags: read and cleared by that workgroup; bit 0 poisons the counters (UINT64_MAX)
@@ -279,6 +283,9 @@ hipError_t launch_greedy_keep(const ListArgs& a, hipStream_t s);
 // long chains: J[i] = nxt(i) (uint32 index or 0xffffffff), then rounds of "mark J(marked), square J" until *changed stays 0
 hipError_t launch_greedy_links(const ListArgs& a, uint32_t* J, hipStream_t s);
 hipError_t launch_greedy_jump(const ListArgs& a, const uint32_t* J, uint32_t* J2, uint32_t* changed, hipStream_t s);
+// line tags of a literal that contains '\n': line start of every raw occurrence, the chunk heads, and the links of the
+// reference's walk (next = the first occurrence behind the first '\n' at or behind this one's end)
+hipError_t launch_nlpat_links(const ListArgs& a, uint32_t* J, hipStream_t s);
 hipError_t launch_line_starts_keep(const ListArgs& a, hipStream_t s);
 hipError_t launch_keep_all(const ListArgs& a, hipStream_t s);
 hipError_t launch_chunk_shift0(const ListArgs& a, hipStream_t s);
@@ -287,7 +294,9 @@ hipError_t launch_assemble(const ListArgs& a, hipStream_t s);
 // counters[XSG_CTR_MATCHES] = sum of keep[0..M) + sum of tail_cnt, counters[XSG_CTR_BYTES] = total_bytes, the other two 0;
 // all four UINT64_MAX if *M_dev exceeds the capacity (the caller falls back to the synchronous route) or the scan
 // raised flags bit 0 (ascii_only expression on non-ASCII data).  counters must be zero on entry.
-hipError_t launch_bordered_total(const ListArgs& a, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, hipStream_t s);
+// status (optional): as FinishArgs::status
+hipError_t launch_bordered_total(const ListArgs& a, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, uint64_t* status,
+                                 hipStream_t s);
 // one-sync route: chunk_shift0 + tail walk by one wave per chunk, the prefix of the tail counts and kTotFinal by the
 // last workgroup to arrive; then the final list (k_assemble + k_globalize in one)
 hipError_t launch_chunk_tail(const ListArgs& a, hipStream_t s);

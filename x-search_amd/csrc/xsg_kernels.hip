@@ -22,6 +22,7 @@
 // summaries) lives in a wave-uniform slow path.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "xsg_devutil.h"
 #include "xsg_linesum.h"
@@ -30,6 +31,8 @@
 namespace xsg {
 
 // (cross-lane helpers, byte tests and newline searches: xsg_devutil.h)
+
+constexpr uint32_t kLdsPattern = 1024;  // bytes of a long pattern kept in LDS (k_scan<kLong>); the rest is read from its device copy
 
 // w[b] = the 4 bytes starting at byte b of the lane's 32-byte view (own unit + neighbour's)
 // simd::toLower on 4 bytes at once (src/utils/string_utils.cpp:11-33): bytes in
@@ -150,7 +153,7 @@ __device__ __forceinline__ uint32_t match_mask16_from(uint32_t m, const uint32_t
 #pragma unroll
         for (uint32_t j = 0; j < 8u; ++j) {
           const uint32_t k = k0 + j;
-          if (k < P.plen && (k < koff || k >= koff + 8u)) diff |= (uint32_t)(fold(s[k], ICASE) ^ lds_pat[k]);
+          if (k < P.plen && (k < koff || k >= koff + 8u)) diff |= (uint32_t)(fold(s[k], ICASE) ^ (k < kLdsPattern ? lds_pat[k] : P.d_pat[k]));
         }
       }
       if (diff) m &= ~(1u << b);
@@ -288,8 +291,9 @@ struct WaveState {
   bool run_nl = false;    // the current run of match-less loads holds a newline (wave-uniform)
   uint32_t masks[4] = {0, 0, 0, 0};
   uint32_t hi = 0;        // OR of the lane's bytes (ascii_only expressions: bit 7 of any byte set = non-ASCII data)
-  // count_lines of a 1..3-byte needle (lines_flag_step): matching lines counted per lane, the line state carried on the scalar unit
-  uint32_t lacc = 0;      // segments whose FIRST match start this lane saw
+  // count_lines of a 1..3-byte needle (lines_flag_step): lines are counted where their closing newline stands
+  uint32_t lacc = 0;      // newline-closed lines with a match counted by this lane
+  uint32_t lsacc = 0;     // ... and on the scalar unit (a wave-load without a match start whose first newline closes one) (wave-uniform)
   uint32_t lcin = 0;      // the line that is open at this point of the span already holds a match (wave-uniform 0 / 1)
   uint32_t lseen = 0;     // the span has shown a newline (wave-uniform)
   uint32_t lF = 0;        // a match start before the span's first newline (wave-uniform)
@@ -297,37 +301,40 @@ struct WaveState {
   uint32_t count_on = 1;  // (wave-uniform)
   uint32_t track_last = 1;  // kMask1: last_rel is needed (the finish kernel walks the end of the chunk: plen > 1, lossy tail)
   // kMask1, counting: where the wave's last match ends is worked out ONCE, in the epilogue, from the flags of the last
-  // wave-load that held a match (positions ascend with load, lane, byte: the highest lane of that load holds it) --
-  // per unit that is four register copies where the per-lane bookkeeping took a dozen instructions
-  uint32_t lnf[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-  unsigned long long lMm = 0;  // its ballot (wave-uniform); 0 = no match in the span
-  uint32_t lrel0 = 0;          // tile-relative offset of lane 0's unit of that load (wave-uniform)
+  // wave-load that held a match (positions ascend with load, lane, byte: the highest lane of that load holds it).  Every
+  // wave-load leaves its flags in its OWN registers (no copy: round 3 moved four registers per wave-load that held a
+  // match) and its ballot on the scalar side; the epilogue picks the last load with a match.
+  uint32_t lnf[4][4] = {{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu},
+                        {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
+  unsigned long long lMm[4] = {0, 0, 0, 0};  // their ballots (wave-uniform); all 0 = no match in the span
 };
 
 // ---------------------------------------------------------------------------
-// count_lines for needles of 1..3 bytes (kMask1), which are in most lines of a text: the per-unit summaries of
-// xsg_linesum.h (two flag->bit conversions, sum_of_unit, six ballots per wave-load: ~120 VALU instructions per
-// 16 bytes and lane) made that variant run at 0.41 of peak.  Here the unit stays in the byte-flag domain the matcher
-// works in (0x80 per byte, the 16 bytes of the unit read as one 128-bit number):
-//   * a line holds a match iff it holds a FIRST match; with E = M | N (match starts, newlines) and B = the segment
-//     starts (one byte above every newline, plus the unit's first byte), E - B borrows from every segment start up
-//     to the segment's first event, so M & ~(E - B) flags exactly the first match of every segment that has one
-//     (a segment whose first event is its closing newline flags nothing);
-//   * the unit's first segment continues the line that is open when the unit begins: if that line already holds a
-//     match, the unit's first byte is NOT a segment start.  "The open line holds a match" is a carry through the 64
-//     units of the wave-load -- generate: the unit's last event is a match (M > N as numbers); propagate: no newline in
-//     the unit -- and the carries of a 64-bit add ARE that recurrence: two ballots, one s_add, one mask back to the lanes.
-// ~45 VALU instructions per unit on top of the matcher's (DESIGN.md 3.1 has the steps that got it there); the wave's
-// summary (F, L, C of xsg_linesum.h) falls out at the end of the span: T = all counted segments, F = a match before the span's first newline, L = the final carry.
+// count_lines for needles of 1..3 bytes (kMask1), which are in most lines of a text.  The unit stays in the byte-flag
+// domain the matcher works in (0x80 per byte, the 16 bytes of the unit read as one 128-bit number, flags INVERTED: nf /
+// nn are all ones except bit 7 of a byte where the pattern starts / that is a newline).
+//
+// Round 4: a line is counted where its CLOSING NEWLINE stands, by one 128-bit addition.  Read nn as 16 digits: a plain
+// byte is 0xff, a newline 0x7f.  Add M = ~nf (0x80 at every match start) and a carry-in "the line that is open when
+// the unit begins already holds a match":
+//     plain byte   0xff + carry        -> passes a carry on                       (the open line still holds its match)
+//     match start  0xff + 0x80 + carry -> always carries out                      (now it holds one)
+//     newline      0x7f + carry        -> absorbs it; bit 7 of the digit = carry  (this line held a match: counted)
+// so lines closed in the unit = popcount(S & ~nn) with S = nn + ~nf + cin = nn - nf - (1 - cin): four v_subb_co_u32,
+// the carry-in as the first borrow-in, and the carry out of the last byte is "the open line holds a match" for the
+// next unit.  Across the 64 units of a wave-load that carry is the generate / propagate recurrence round 3 already
+// solved with ONE 64-bit scalar add: generate = the chain's carry-out with no carry-in (a first pass of the four
+// subtractions, results unused), propagate = no newline in the unit.  25 VALU instructions per unit behind the
+// newline flags where the first-match formulation of round 3 (M & ~(E - B), a select for the segment start, three
+// 64-bit compares for the generate bit) took 41 -- `the`: 464 -> ~350 VALU instructions per 4 KiB wave
+// (profiles/r04_dense_variants.txt).  The wave's summary (F, L, C of xsg_linesum.h) falls out at the end of the span:
+// T = lines closed with a match, F = a match before the span's first newline (the first of them), L = the final carry.
 // ---------------------------------------------------------------------------
-// `nf`: the matcher's flags INVERTED (all ones except bit 7 of a byte where the pattern starts), as it leaves them; the
-// newline flags are computed in the same form (the final NOT of the zero-byte test saved on both: everything below works
-// on the complements -- ~(M | N) = nM & nN;  M > N  <=>  nM < nN;  ~(E - B) = ~E + B = ~E - ~B - 1, a subtraction with
-// the borrow-in set;  firsts = M & ~(E - B) = ~nM & that).
 __device__ __forceinline__ void lines_flag_step(const uint32_t (&nf)[4], const unsigned long long Mm, const uint32_t (&src)[8],
                                                 uint32_t lane, WaveState& st) {
-  // the line state is wave-uniform and lives on the scalar unit (readfirstlane: the compiler is told so)
-  const uint32_t lcin0 = __builtin_amdgcn_readfirstlane(st.lcin), lseen0 = __builtin_amdgcn_readfirstlane(st.lseen);
+  // the line state is wave-uniform and lives on the scalar unit: everything it is computed from is a ballot or was
+  // declared uniform (Gm below) -- no readfirstlane on the state itself (that parks it in a vector register)
+  const uint32_t lcin0 = st.lcin, lseen0 = st.lseen;
   if (Mm != 0 || lcin0 != 0 || lseen0 == 0) {  // otherwise nothing here can change the state or the counts
     uint32_t nn[4];
 #pragma unroll
@@ -336,19 +343,14 @@ __device__ __forceinline__ void lines_flag_step(const uint32_t (&nf)[4], const u
       nn[q] = ((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu;
     }
     const unsigned long long Nm = __ballot((nn[0] & nn[1] & nn[2] & nn[3]) != 0xffffffffu);  // units with a newline
-    uint32_t lcin = Nm ? 0u : lcin0;  // no match start in the wave-load: a newline closes the open line
-    if (Mm != 0) {
-      // the unit's last event is a match start (no newline: any match start): M > N as 128-bit numbers = nM < nN, spelled
-      // out as three 64-bit compares into scalar masks (the compiler's own 128-bit compare went through VGPR booleans)
-      const unsigned long long nMh = ((unsigned long long)nf[3] << 32) | nf[2], nMl = ((unsigned long long)nf[1] << 32) | nf[0];
-      const unsigned long long nNh = ((unsigned long long)nn[3] << 32) | nn[2], nNl = ((unsigned long long)nn[1] << 32) | nn[0];
-      const unsigned long long Gm = __ballot(nMh < nNh) | (__ballot(nMh == nNh) & __ballot(nMl < nNl));
-      // carries of a + b + cin with generate = Gm, propagate = no newline in the unit (carry flags, not 64-bit compares:
-      // the scalar unit has no unsigned 64-bit less-than)
-      const unsigned long long a = Gm | ~Nm, b = Gm;
-      const unsigned long long s2 = a + b + lcin0;
-      const unsigned long long C = s2 ^ a ^ b;  // bit l: the line open at the start of lane l's unit already holds a match
-      lcin = (uint32_t)(((a & b) | ((a | b) & ~s2)) >> 63);  // the carry out of bit 63 (majority of a, b, carry-in there)
+    uint32_t lcin = lcin0;
+    if (Mm == 0) {
+      // no match start in the wave-load: its first newline closes the open line -- counted now if it holds a match
+      if (Nm != 0) {
+        st.lsacc += lcin0;
+        lcin = 0;
+      }
+    } else {
       if (lseen0 == 0) {  // a match start before the span's first newline?  (once per span; scalar)
         uint32_t f = 1;  // no newline yet: any match start (Mm != 0 here)
         if (Nm != 0) {
@@ -364,42 +366,146 @@ __device__ __forceinline__ void lines_flag_step(const uint32_t (&nf)[4], const u
             open = open && nq == 0;
           }
         }
-        st.lF = __builtin_amdgcn_readfirstlane(st.lF | f);
+        st.lF |= f;
       }
-      // ~B: B = one byte above every newline, plus the unit's first byte unless it continues a line that already holds a match
-      uint32_t lowb;  // 0xff where bit `lane` of C is set (the unit's first byte starts no segment), 0x7f otherwise: one select on the scalar mask
-      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lowb) : "v"(0x7fu), "v"(0xffu), "s"(C));
-      const uint32_t nb0 = (nn[0] << 8) | lowb;
-      const uint32_t nb1 = __builtin_amdgcn_alignbyte(nn[1], nn[0], 3), nb2 = __builtin_amdgcn_alignbyte(nn[2], nn[1], 3);
-      const uint32_t nb3 = __builtin_amdgcn_alignbyte(nn[3], nn[2], 3);
-      const uint32_t e0 = nf[0] & nn[0], e1 = nf[1] & nn[1], e2 = nf[2] & nn[2], e3 = nf[3] & nn[3];  // ~E
-      uint32_t x0, x1, x2, x3;  // ~E - ~B - 1 = ~(E - B): four subtractions, the first with its borrow-in set
+      // One block of assembly, so that nothing between the two passes has to be "declared uniform" again (an asm result
+      // counts as divergent whatever its constraint says, and every readfirstlane of a scalar costs a v_mov and a
+      // v_readfirstlane):
+      //   pass 1  nn - nf - 1 (borrow-in set everywhere; differences unused): no borrow out = the unit carries out on its
+      //           own = its last event is a match start: generate, G = ~vcc
+      //   scalar  carries of a + b + cin with a = G | ~N (generate or propagate: no newline in the unit), b = G, through
+      //           the scalar carry flag -- s_cmp sets it to cin, two s_addc_u32 thread it through, the second leaves the
+      //           carry out of bit 63 = "the line open at the end of the wave-load holds a match"; C = sum ^ a ^ b = the
+      //           carry INTO every lane's unit; vcc = ~C
+      //   pass 2  nn - nf - (1 - cin): the sums with the true carry-in
+      uint32_t x0, x1, x2, x3, glo, ghi, alo, ahi, slo, shi, cout;
       asm("s_mov_b64 vcc, -1\n\t"
-          "v_subb_co_u32_e32 %0, vcc, %4, %8, vcc\n\t"
-          "v_subb_co_u32_e32 %1, vcc, %5, %9, vcc\n\t"
-          "v_subb_co_u32_e32 %2, vcc, %6, %10, vcc\n\t"
-          "v_subb_co_u32_e32 %3, vcc, %7, %11, vcc"
-          : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-          : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(nb0), "v"(nb1), "v"(nb2), "v"(nb3)
-          : "vcc");
-      st.lacc += (uint32_t)__popc(~nf[0] & x0) + (uint32_t)__popc(~nf[1] & x1) + (uint32_t)__popc(~nf[2] & x2) +
-                 (uint32_t)__popc(~nf[3] & x3);
+          "v_subb_co_u32_e32 %0, vcc, %11, %15, vcc\n\t"
+          "v_subb_co_u32_e32 %0, vcc, %12, %16, vcc\n\t"
+          "v_subb_co_u32_e32 %0, vcc, %13, %17, vcc\n\t"
+          "v_subb_co_u32_e32 %0, vcc, %14, %18, vcc\n\t"
+          "s_not_b32 %4, vcc_lo\n\t"
+          "s_not_b32 %5, vcc_hi\n\t"
+          "s_orn2_b32 %6, %4, %19\n\t"
+          "s_orn2_b32 %7, %5, %20\n\t"
+          "s_cmp_lg_u32 %21, 0\n\t"
+          "s_addc_u32 %8, %6, %4\n\t"
+          "s_addc_u32 %9, %7, %5\n\t"
+          "s_cselect_b32 %10, 1, 0\n\t"
+          "s_xor_b32 %8, %8, %6\n\t"
+          "s_xor_b32 %9, %9, %7\n\t"
+          "s_xnor_b32 vcc_lo, %8, %4\n\t"
+          "s_xnor_b32 vcc_hi, %9, %5\n\t"
+          "v_subb_co_u32_e32 %0, vcc, %11, %15, vcc\n\t"
+          "v_subb_co_u32_e32 %1, vcc, %12, %16, vcc\n\t"
+          "v_subb_co_u32_e32 %2, vcc, %13, %17, vcc\n\t"
+          "v_subb_co_u32_e32 %3, vcc, %14, %18, vcc"
+          : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&s"(glo), "=&s"(ghi), "=&s"(alo), "=&s"(ahi), "=&s"(slo), "=&s"(shi),
+            "=&s"(cout)
+          : "v"(nn[0]), "v"(nn[1]), "v"(nn[2]), "v"(nn[3]), "v"(nf[0]), "v"(nf[1]), "v"(nf[2]), "v"(nf[3]), "s"((uint32_t)Nm),
+            "s"((uint32_t)(Nm >> 32)), "s"(lcin0)
+          : "vcc", "scc");
+      lcin = (uint32_t)__builtin_amdgcn_readfirstlane((int)cout);
+      // (v_bcnt_u32_b32 adds to an accumulator: four instructions, the lane's count threaded through them)
+      uint32_t acc = st.lacc;
+      asm("v_bcnt_u32_b32 %0, %1, %0\n\t"
+          "v_bcnt_u32_b32 %0, %2, %0\n\t"
+          "v_bcnt_u32_b32 %0, %3, %0\n\t"
+          "v_bcnt_u32_b32 %0, %4, %0"
+          : "+v"(acc)
+          : "v"(x0 & ~nn[0]), "v"(x1 & ~nn[1]), "v"(x2 & ~nn[2]), "v"(x3 & ~nn[3]));
+      st.lacc = acc;
     }
-    st.lcin = __builtin_amdgcn_readfirstlane(lcin);
-    st.lseen = __builtin_amdgcn_readfirstlane(lseen0 | (Nm != 0 ? 1u : 0u));
+    // (all of this is derived from ballots and from Gm, which was declared uniform above: it stays on the scalar unit
+    // without a readfirstlane -- with one, the compiler built the value in a vector register first: four VALU
+    // instructions per wave-load for one scalar OR)
+    st.lcin = lcin;
+    st.lseen = lseen0 | (Nm != 0 ? 1u : 0u);
   }
+}
+
+// kMask1: the inverted match flags of one unit (all ones except bit 7 of a byte where the pattern starts).  PL = the
+// pattern's length where it is 1..3 (a template parameter since round 4: the dispatch on the length ran once per
+// wave-load, a dozen scalar instructions and two or three taken branches each time), 0 = 4..8 bytes, read at run time:
+// a needle of the window kinds that an earlier count found DENSE in this data (launch_scan re-routes it here).  Its hot
+// filter would send every wave-load into the slow path; decided byte-parallel, every position costs the same whether it
+// matches or not: (plen + 6) instructions per dword -- three shifted views shared by all pattern bytes, one
+// (view ^ byte) | z per pattern byte, the zero-byte test -- and the scan stays bound by memory.
+// z has a zero byte at byte i of dword q iff the pattern starts at position 4q+i; the zero-byte test stops before its
+// final NOT (counting and the line arithmetic work on the complement as well, lines_flag_step).
+template <int PL>
+__device__ __forceinline__ void mask1_flags(const uint32_t (&d)[8], const PatternDev& P, uint32_t (&nf)[4]) {
+  const uint32_t c0 = (P.p0 & 0xffu) * 0x01010101u;
+  const uint32_t c1 = ((P.p0 >> 8) & 0xffu) * 0x01010101u;
+  const uint32_t c2 = ((P.p0 >> 16) & 0xffu) * 0x01010101u;
+  uint32_t z[4];
+  if (PL == 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = d[q] ^ c0;
+  } else if (PL == 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)  // (a ^ c) | b in one v_bitop3_b32 (0xde)
+      z[q] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1), d[q] ^ c0, c1, 0xde);
+  } else if (PL == 3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t u = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1), d[q] ^ c0, c1, 0xde);
+      z[q] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbyte(d[q + 1], d[q], 2), u, c2, 0xde);
+    }
+  } else {
+    const uint32_t c3 = (P.p0 >> 24) * 0x01010101u;
+    uint32_t a1[5], a2[5], a3[5];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a1[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+      a2[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+      a3[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+      z[q] = (d[q] ^ c0) | (a1[q] ^ c1) | (a2[q] ^ c2) | (a3[q] ^ c3);
+    }
+    if (P.plen > 4) {
+      asm volatile("");  // (keeps the branch a branch: as selects, a four-byte needle paid for an eight-byte one)
+      const uint32_t c4 = (P.p1 & 0xffu) * 0x01010101u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) z[q] |= d[q + 1] ^ c4;
+      if (P.plen > 5) {
+        asm volatile("");
+        const uint32_t c5 = ((P.p1 >> 8) & 0xffu) * 0x01010101u;
+        a1[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] |= a1[q + 1] ^ c5;
+        if (P.plen > 6) {
+          asm volatile("");
+          const uint32_t c6 = ((P.p1 >> 16) & 0xffu) * 0x01010101u;
+          a2[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z[q] |= a2[q + 1] ^ c6;
+          if (P.plen > 7) {
+            asm volatile("");
+            const uint32_t c7 = (P.p1 >> 24) * 0x01010101u;
+            a3[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] |= a3[q + 1] ^ c7;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) nf[q] = ((z[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z[q] | 0x7f7f7f7fu;
 }
 
 // One wave-load (1 KiB): `cur` is this lane's 16-byte unit, `nx` the unit that
 // follows the wave-load (lane 0's unit of the next load, or the bytes after the
 // span).  CAREFUL: the wave-load may reach past the end of the chunk.
 // Returns the lane's exact match-start bits (also accumulated into `st`).
-template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool CAREFUL, bool ALIGNED>
+// PL: kMask1 only -- the pattern length where it is 1..3, 0 = read at run time (mask1_flags); j: the load's number in
+// the wave's span (a constant once the caller's loop is unrolled: it names the registers the load's flags stay in).
+template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool CAREFUL, bool ALIGNED, int PL = 0>
 __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, bool nx_is_vgpr, uint64_t unit_off,
                                               uint32_t unit_rel, uint32_t lane, uint64_t L, uint64_t limit,
                                               const PatternDev& P,
                                               const uint8_t* cbase, const uint8_t* s_pat, uint8_t* s_view,
-                                              WaveState& st, const bool near_limit = true) {
+                                              WaveState& st, const bool near_limit, const int j) {
   // ignore_case, patterns of 4+ bytes (LAZY): the hot filter does not need the exact fold.  (x | 0x20) == (p | 0x20)
   // holds for every byte x that folds to the pattern byte p (exactly those when p is a letter, one more byte value
   // otherwise), so the candidate test runs on data OR-ed with 0x20 -- one op per dword instead of fold4's seven --
@@ -459,86 +565,14 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
     // is no cheap "nothing here" case to filter for: decide all 16 positions byte-parallel instead.  z has a zero byte at
     // byte i of dword q iff the pattern starts at position 4q+i; fl[q] flags exactly
     // those bytes with 0x80 (5 to 11 ops per dword instead of ~24 for windows + masks).
-    const uint32_t c0 = (P.p0 & 0xffu) * 0x01010101u;
-    const uint32_t c1 = ((P.p0 >> 8) & 0xffu) * 0x01010101u;
-    const uint32_t c2 = ((P.p0 >> 16) & 0xffu) * 0x01010101u;
-    // nf: the flags INVERTED -- all ones except bit 7 of the byte where the pattern starts (the zero-byte test without its
-    // final NOT: counting and the line arithmetic work on the complement as well, lines_flag_step)
-    // One body per pattern length behind a scalar branch: written as `if (plen >= 2) z |= ...` the compiler turned the
-    // branches into selects and a one-byte needle paid the alignbyte / xor / cndmask work of a three-byte one (13
-    // instructions per dword where 4 do; the empty asm keeps the branch a branch).
+    // nf: the flags INVERTED -- all ones except bit 7 of the byte where the pattern starts
     uint32_t nf[4];
-    if (P.plen == 1) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t z = d[q] ^ c0;
-        nf[q] = ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu;
-      }
-    } else if (P.plen == 2) {
-      asm volatile("");
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t z = (d[q] ^ c0) | (__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) ^ c1);
-        nf[q] = ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu;
-      }
-    } else if (P.plen == 3) {
-      asm volatile("");
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t z = (d[q] ^ c0) | (__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) ^ c1) |
-                           (__builtin_amdgcn_alignbyte(d[q + 1], d[q], 2) ^ c2);
-        nf[q] = ((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu;
-      }
-    } else {
-      // 4..8 bytes: a needle of the window kinds that an earlier count found DENSE in this data (launch_scan re-routes
-      // it here).  Its hot filter would send every wave-load into the slow path; decided byte-parallel, every position
-      // costs the same whether it matches or not: (plen + 6) instructions per dword -- three shifted views shared by
-      // all pattern bytes, one (view ^ byte) | z per pattern byte, the zero-byte test -- and the scan stays bound by memory.
-      asm volatile("");
-      const uint32_t c3 = (P.p0 >> 24) * 0x01010101u;
-      uint32_t a1[5], a2[5], a3[5], z[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a1[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
-        a2[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
-        a3[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
-        z[q] = (d[q] ^ c0) | (a1[q] ^ c1) | (a2[q] ^ c2) | (a3[q] ^ c3);
-      }
-      if (P.plen > 4) {
-        asm volatile("");
-        const uint32_t c4 = (P.p1 & 0xffu) * 0x01010101u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) z[q] |= d[q + 1] ^ c4;
-        if (P.plen > 5) {
-          asm volatile("");
-          const uint32_t c5 = ((P.p1 >> 8) & 0xffu) * 0x01010101u;
-          a1[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 1);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) z[q] |= a1[q + 1] ^ c5;
-          if (P.plen > 6) {
-            asm volatile("");
-            const uint32_t c6 = ((P.p1 >> 16) & 0xffu) * 0x01010101u;
-            a2[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 2);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) z[q] |= a2[q + 1] ^ c6;
-            if (P.plen > 7) {
-              asm volatile("");
-              const uint32_t c7 = (P.p1 >> 24) * 0x01010101u;
-              a3[4] = __builtin_amdgcn_alignbyte(d[5], d[4], 3);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) z[q] |= a3[q + 1] ^ c7;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) nf[q] = ((z[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z[q] | 0x7f7f7f7fu;
-    }
+    mask1_flags<PL>(d, P, nf);
     bool has = (nf[0] & nf[1] & nf[2] & nf[3]) != 0xffffffffu;
     unsigned long long Mm = __ballot(has);
     // positions at or beyond the limit belong to the tail walk.  A span that ends below the limit (wave-uniform; all
     // but a chunk's last) does not look.
-    if (near_limit && Mm != 0) {
+    if (CAREFUL && near_limit && Mm != 0) {  // (the fast body only runs spans that end below the limit: scan_tile)
       asm volatile("");  // (a branch, not a mask on the per-lane test)
       if (unit_off + kUnit > limit) {
 #pragma unroll
@@ -562,18 +596,15 @@ __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, b
     } else {
       if (Mm != 0) {
         // counting needs no bit mask at all: popcount(nf) = 32 - matches of the dword, chained through v_bcnt's accumulator
-        if (st.count_on) {
+        if (!(WANT_LINES && !EMIT)) {
           const uint32_t n = 128u - ((uint32_t)__popc(nf[0]) + (uint32_t)__popc(nf[1]) + (uint32_t)__popc(nf[2]) + (uint32_t)__popc(nf[3]));
           st.cnt += n;
         }
-        // where the last match ends: only the end-of-chunk walk asks, and a one-byte pattern has none (strchr is
-        // exact everywhere, xsg_tail.h); see WaveState::lnf
-        if (st.track_last) {
-          st.lnf[0] = nf[0], st.lnf[1] = nf[1], st.lnf[2] = nf[2], st.lnf[3] = nf[3];
-          st.lMm = Mm;
-          st.lrel0 = __builtin_amdgcn_readfirstlane(unit_rel - lane * kUnit);
-        }
       }
+      // where the last match ends: only the end-of-chunk walk asks (a one-byte pattern has none: strchr is exact
+      // everywhere, xsg_tail.h).  The flags stay where they are, the ballot goes to the scalar side: WaveState::lnf
+      st.lnf[j][0] = nf[0], st.lnf[j][1] = nf[1], st.lnf[j][2] = nf[2], st.lnf[j][3] = nf[3];
+      st.lMm[j] = Mm;
       if (WANT_LINES) lines_flag_step(nf, Mm, nlsrc, lane, st);
       return 0;
     }
@@ -733,7 +764,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   constexpr uint32_t kTile = kWaveSpan * kWaves;         // bytes per workgroup
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
-  __shared__ __attribute__((aligned(16))) uint8_t s_pat[is_cls(KIND) ? 2048 : KIND == kLong ? XSG_MAX_PATTERN : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_pat[is_cls(KIND) ? 2048 : KIND == kLong ? kLdsPattern : 16];
   __shared__ __attribute__((aligned(16))) uint8_t s_view[is_cls(KIND) ? kBlock * 48 : 16];  // match_mask16<kClass>
 
   if (tile >= A.ntiles) return;
@@ -746,8 +777,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps wbase and the branches on it scalar
 
-  if (KIND == kLong) {
-    for (uint32_t k = tid; k < P.plen; k += kBlock) s_pat[k] = P.d_pat[k];
+  if (KIND == kLong) {  // the first KiB of the pattern; a candidate of a longer one is verified against the device copy beyond it
+    for (uint32_t k = tid; k < P.plen && k < kLdsPattern; k += kBlock) s_pat[k] = P.d_pat[k];
     __syncthreads();
   }
 
@@ -834,27 +865,42 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   WaveState st;
   if (KIND == kMask1) {
     st.track_last = (!P.exact_tail && P.plen > 1) ? 1u : 0u;
-    st.count_on = (WANT_LINES && !EMIT && A.lines_only) ? 0u : 1u;
+    // (xs::count_lines never asks for the number of matches: ScanArgs::lines_only is set by every caller of the WANT_LINES
+    // variant of this kind, so the instantiation does not look at it wave-load by wave-load)
+    st.count_on = (WANT_LINES && !EMIT) ? 0u : 1u;
   }
   const bool near_limit = wbase + kWaveSpan > limit;  // wave-uniform: only a chunk's last spans reach the tail walk's zone
+  // the wave's loads, one after the other; PL: see scan_load (kMask1: the dispatch on the pattern length sits OUTSIDE the loop)
+  auto run_loads = [&](auto careful_tag, auto pl_tag) {
+    constexpr bool kCareful = decltype(careful_tag)::value;
+    constexpr int kPl = decltype(pl_tag)::value;
+#pragma unroll
+    for (int j = 0; j < kLoads; ++j) {
+      const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
+      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, kCareful, ALIGNED, kPl>(
+          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit,
+          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st, near_limit, j);
+    }
+  };
+  auto run_body = [&](auto careful_tag) {
+    if (KIND == kMask1) {
+      const uint32_t pl = __builtin_amdgcn_readfirstlane(P.plen);
+      if (pl == 1) run_loads(careful_tag, std::integral_constant<int, 1>{});
+      else if (pl == 2) run_loads(careful_tag, std::integral_constant<int, 2>{});
+      else if (pl == 3) run_loads(careful_tag, std::integral_constant<int, 3>{});
+      else run_loads(careful_tag, std::integral_constant<int, 0>{});
+    } else {
+      run_loads(careful_tag, std::integral_constant<int, 0>{});
+    }
+  };
   if (EMIT && !wave_on) {
     // nothing to decide
-  } else if (!EMIT && wbase + kWaveSpan <= L) {
-#pragma unroll
-    for (int j = 0; j < kLoads; ++j) {
-      const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
-      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, false, ALIGNED>(
-          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit,
-          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st, near_limit);
-    }
+  } else if (!EMIT && wbase + kWaveSpan <= L && !(KIND == kMask1 && near_limit)) {
+    // the fast body: the whole span lies inside the chunk -- and, for the byte-parallel kinds, below the limit beyond which
+    // positions belong to the end-of-chunk walk, so that it tests neither (the other kinds apply the limit in their slow path)
+    run_body(std::false_type{});
   } else {
-#pragma unroll
-    for (int j = 0; j < kLoads; ++j) {
-      const uint4 nx = j + 1 < kLoads ? v[j + 1 < kLoads ? j + 1 : j] : edge;
-      st.masks[j < 4 ? j : 0] = scan_load<KIND, WANT_NL, WANT_LINES, EMIT, ICASE, true, ALIGNED>(
-          v[j], nx, j + 1 < kLoads, wbase + (uint64_t)j * kWaveLoad + (uint64_t)lane * kUnit,
-          wave * kWaveSpan + (uint32_t)j * kWaveLoad + lane * kUnit, lane, L, limit, P, cbase, s_pat, s_view, st, near_limit);
-    }
+    run_body(std::true_type{});
   }
   const uint32_t cnt = st.cnt, nlc = st.nlc;
   uint32_t wsum = st.wsum;
@@ -864,14 +910,16 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   for (int j = 0; j < kLoads; ++j) masks[j] = st.masks[j < 4 ? j : 0];
   if (WANT_LINES && !EMIT && run_nl) wsum = sum_combine(wsum, kSumNl);
   if (WANT_LINES && !EMIT && KIND == kMask1) {
-    // lines_flag_step's state -> the span's summary (xsg_linesum.h): T segments with a match in all; the first one is F
-    // (it lies before the first newline), the last one L (the final carry: the open line holds a match)
-    const uint32_t T = __any(st.lacc != 0) ? wave_sum_u32(st.lacc) : 0u;
+    // lines_flag_step's state -> the span's summary (xsg_linesum.h): T lines closed by a newline of the span hold a match;
+    // the first of them is F (its match lies before the span's first newline), the rest are C; L = the final carry: the
+    // line that is open at the end of the span holds a match.  Without a newline in the span nothing was closed and that
+    // carry says whether the span holds a match at all.
     if (!st.lseen) {
-      const uint32_t f = T != 0 ? 1u : 0u;
+      const uint32_t f = st.lcin;
       wsum = (f << 1) | (f << 2);
     } else {
-      wsum = kSumNl | (st.lF << 1) | (st.lcin << 2) | ((T - st.lF - st.lcin) << kSumCShift);
+      const uint32_t T = (__any(st.lacc != 0) ? wave_sum_u32(st.lacc) : 0u) + st.lsacc;
+      wsum = kSumNl | (st.lF << 1) | (st.lcin << 2) | ((T - st.lF) << kSumCShift);
     }
   }
 
@@ -886,7 +934,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
     // k_count_finish puts that back as it consumes them) and only waves that
     // found something else write: no LDS, no barrier, no store on the common path.
     bool wave_has;
-    if (KIND == kMask1) wave_has = st.count_on ? __any(cnt != 0) : st.lMm != 0;  // (lines only, no end-of-chunk walk: nothing to report)
+    const unsigned long long any_m = KIND == kMask1 ? (st.lMm[0] | st.lMm[1] | st.lMm[2] | st.lMm[3]) : 0ull;
+    if (KIND == kMask1) wave_has = st.count_on ? __any(cnt != 0) : any_m != 0;  // (lines only, no end-of-chunk walk: nothing to report)
     else wave_has = __any(cnt != 0);
     if (wave_has) {
       const uint32_t wc = wave_sum_u32(cnt);
@@ -896,13 +945,20 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
       uint32_t rel;
       if (KIND == kMask1) {
         rel = 1u;  // no end-of-chunk walk reads it (it must stay inside the tile: tile_last's tag)
-        if (st.lMm != 0) {  // scalar: the highest lane of the last wave-load with a match
-          const int l = 63 - __builtin_clzll(st.lMm);
-          const uint32_t f3 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[3], l), f2 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[2], l);
-          const uint32_t f1 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[1], l), f0 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[0], l);
-          const uint32_t hq = f3 ? 3u : f2 ? 2u : f1 ? 1u : 0u;
-          const uint32_t hf = f3 ? f3 : f2 ? f2 : f1 ? f1 : f0;
-          rel = st.lrel0 + (uint32_t)l * kUnit + 4u * hq + ((31u - (uint32_t)__builtin_clz(hf)) >> 3) + P.plen;
+        if (st.track_last && any_m != 0) {  // scalar: the highest lane of the last wave-load with a match
+          bool found = false;
+#pragma unroll
+          for (int j = 3; j >= 0; --j) {
+            if (j < kLoads && !found && st.lMm[j] != 0) {
+              found = true;
+              const int l = 63 - __builtin_clzll(st.lMm[j]);
+              const uint32_t f3 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[j][3], l), f2 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[j][2], l);
+              const uint32_t f1 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[j][1], l), f0 = ~(uint32_t)__builtin_amdgcn_readlane((int)st.lnf[j][0], l);
+              const uint32_t hq = f3 ? 3u : f2 ? 2u : f1 ? 1u : 0u;
+              const uint32_t hf = f3 ? f3 : f2 ? f2 : f1 ? f1 : f0;
+              rel = wave * kWaveSpan + (uint32_t)j * kWaveLoad + (uint32_t)l * kUnit + 4u * hq + ((31u - (uint32_t)__builtin_clz(hf)) >> 3) + P.plen;
+            }
+          }
         }
       } else {
         rel = wave_max_u32(st.last_rel);
@@ -1056,7 +1112,7 @@ void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, 
   const char* b[2] = {"false", "true"};
   if (a.pat.kind == kDfa) {
     // count passes: one wave per 4 KiB span (k_rx_count); the emit pass: the tile-cooperative k_rx_scan
-    const char* rw = getenv("XSG_RX_WAVE");
+    static const char* const rw = getenv("XSG_RX_WAVE");
     char name[48];
     if (emit || (rw && *rw == '0'))
       snprintf(name, sizeof name, "xsg::k_rx_scan<%s, %s>", b[emit], b[emit ? 0 : want_lines]);
@@ -1267,8 +1323,10 @@ __global__ __launch_bounds__(kBlock) void k_count_finish(const FinishArgs A) {
     const bool refuse = (A.pat.kind == kClass || A.pat.kind == kDfa) && A.pat.ascii_only &&
                         (__hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0;
     if (A.cnt_is_lines) a1 = a0, a0 = 0;  // k_rx_scan counted matching lines into tile_cnt
-    const uint64_t v[XSG_NUM_COUNTERS] = {refuse ? UINT64_MAX : a0, refuse ? UINT64_MAX : a1, refuse ? UINT64_MAX : a2,
-                                          refuse ? UINT64_MAX : A.total_bytes};
+    // a refusal poisons the counters (UINT64_MAX) -- or, for a caller that gave a status word, zeroes them and says why
+    const uint64_t bad = A.status ? 0ull : UINT64_MAX;
+    if (A.status) *A.status = refuse ? (uint64_t)XSG_STATUS_NONASCII : 0ull;
+    const uint64_t v[XSG_NUM_COUNTERS] = {refuse ? bad : a0, refuse ? bad : a1, refuse ? bad : a2, refuse ? bad : A.total_bytes};
     for (int k = 0; k < XSG_NUM_COUNTERS; ++k) {
       A.counters[k] = v[k];
       if (A.host_counters) A.host_counters[k] = v[k];

@@ -386,6 +386,52 @@ __global__ void k_greedy_jump(const ListArgs A, const uint32_t* J, uint32_t* J2,
   J2[i] = jj;
 }
 
+// ---- the line tags of a literal that contains '\n' -------------------------------------------------------------
+// The reference's walk (search_wrappers.h:29-50, 163-207 with skip_to_nl) is defined for any std::string: report the
+// leftmost occurrence at or behind `shift`, then shift = the byte behind the first '\n' at or behind the match's END.
+// When the pattern holds no newline that is "the first occurrence of every line" (k_line_starts_keep).  When it does,
+// an occurrence reaches into the next line(s) and the walk is a chain: the chunk's first occurrence is reported, and
+// nxt(i) = the first occurrence that starts behind the first '\n' at or behind i's end.  Here: every raw occurrence
+// gets its line start as the reference computes it (behind the last '\n' BEFORE the match -- or, when the match's first
+// byte is itself a '\n', one byte behind that: previous_new_line_offset_relative_to_match tests the match's first
+// byte first and wraps, :111-123), the chunk heads are marked, and J = nxt; the closure under nxt is then taken by the
+// pointer jumping that resolves long greedy chains (k_greedy_jump: log2(chain) rounds).
+__global__ __launch_bounds__(kBlock) void k_nlpat_links(const ListArgs A, uint32_t* J) {
+  const uint64_t M = list_count(A);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); i0 < M; i0 += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = i0 + lane;
+    const bool live = i < M;  // no early exit of a lane: the wave finishes long newline searches together
+    const uint32_t c = live ? A.m_chunk[i] : 0u;
+    const ChunkDev ch = A.chunks[c];
+    const uint8_t* d = A.base + ch.offset;
+    const uint64_t pos = live ? A.m_pos[i] : 0;
+    const int64_t before = newline_query<false>(live && !A.pat.nl_first, d, 0, pos, lane);
+    const int64_t behind = newline_query<true>(live, d, pos + A.pat.plen, ch.length, lane);
+    if (!live) continue;
+    A.m_ls[i] = A.pat.nl_first ? pos + 1u : before < 0 ? 0u : (uint64_t)before + 1u;
+    A.keep[i] = (i == 0 || A.m_chunk[i - 1] != c) ? 1u : 0u;
+    uint32_t nxt = kNoLink;
+    if (behind >= 0) {  // (no newline behind the match: the walk ends with it)
+      uint64_t r1 = A.tile_off[A.chunk_tile0[c + 1]];
+      r1 = r1 < M ? r1 : M;
+      uint64_t lo = i + 1, hi = r1;
+      while (lo < hi) {  // first occurrence of the chunk that starts behind that newline
+        const uint64_t mid = (lo + hi) >> 1;
+        if (A.m_pos[mid] > (uint64_t)behind) hi = mid; else lo = mid + 1;
+      }
+      if (lo < r1) nxt = (uint32_t)lo;
+    }
+    J[i] = nxt;
+  }
+}
+
+hipError_t launch_nlpat_links(const ListArgs& a, uint32_t* J, hipStream_t s) {
+  if (!a.M) return hipSuccess;
+  hipLaunchKernelGGL(k_nlpat_links, grid_for(a.M), dim3(kBlock), 0, s, a, J);
+  return hipGetLastError();
+}
+
 hipError_t launch_greedy_links(const ListArgs& a, uint32_t* J, hipStream_t s) {
   if (!a.M) return hipSuccess;
   hipLaunchKernelGGL(k_greedy_links, grid_for(a.M), dim3(kBlock), 0, s, a, J);
@@ -624,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void k_list_out(const ListArgs A) {
         int64_t e = -1;
         if (A.line_len) e = newline_query<true>(live, d, m + A.pat.plen, ch.length, lane);
         if (live) {
-          const uint64_t pos = !lm ? m : nl < 0 ? 0u : (uint64_t)nl + 1u;
+          const uint64_t pos = !lm ? m : A.pat.nl_first ? m + 1u : nl < 0 ? 0u : (uint64_t)nl + 1u;
           if (A.want_f) {
             A.f_pos[dst0 + k] = pos;
             A.f_match[dst0 + k] = m;
@@ -683,7 +729,7 @@ __global__ void k_assemble(const ListArgs A) {
       const uint64_t m = live ? A.tail_pos[c * A.tail_cap + k] : 0;
       const int64_t nl = newline_query<false>(live && A.line_mode != 0, d, 0, m, threadIdx.x & 63u);
       if (live) {
-        A.f_pos[dst0 + k] = !A.line_mode ? m : nl < 0 ? 0u : (uint64_t)nl + 1u;
+        A.f_pos[dst0 + k] = !A.line_mode ? m : A.pat.nl_first ? m + 1u : nl < 0 ? 0u : (uint64_t)nl + 1u;
         A.f_match[dst0 + k] = m;
         A.f_chunk[dst0 + k] = (uint32_t)c;
       }
@@ -703,23 +749,25 @@ __global__ __launch_bounds__(kBlock) void k_bordered_total(const ListArgs A, uin
   const uint64_t t = block_sum_u64(n, sh);
   if (threadIdx.x == 0 && t) atomicAdd((unsigned long long*)&counters[XSG_CTR_MATCHES], (unsigned long long)t);
 }
-__global__ void k_bordered_seal(const ListArgs A, uint64_t* counters, uint64_t total_bytes, uint32_t* flags) {
+__global__ void k_bordered_seal(const ListArgs A, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, uint64_t* status) {
   const bool overflow = A.M_dev && *A.M_dev > A.M;
   const bool refuse = (A.pat.kind == kClass || A.pat.kind == kDfa) && A.pat.ascii_only && (*flags & 1u);
   *flags = 0u;
+  if (status) *status = (overflow ? (uint64_t)XSG_STATUS_OVERFLOW : 0ull) | (refuse ? (uint64_t)XSG_STATUS_NONASCII : 0ull);
   if (overflow || refuse) {
-    for (int k = 0; k < XSG_NUM_COUNTERS; ++k) counters[k] = UINT64_MAX;
+    for (int k = 0; k < XSG_NUM_COUNTERS; ++k) counters[k] = status ? 0ull : UINT64_MAX;
   } else {
     counters[XSG_CTR_BYTES] = total_bytes;
   }
 }
 
-hipError_t launch_bordered_total(const ListArgs& a, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, hipStream_t s) {
+hipError_t launch_bordered_total(const ListArgs& a, uint64_t* counters, uint64_t total_bytes, uint32_t* flags, uint64_t* status,
+                                 hipStream_t s) {
   uint64_t blocks = (std::max<uint64_t>(a.M, a.nchunks) + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_bordered_total, dim3((unsigned)blocks), dim3(kBlock), 0, s, a, counters);
-  hipLaunchKernelGGL(k_bordered_seal, dim3(1), dim3(1), 0, s, a, counters, total_bytes, flags);
+  hipLaunchKernelGGL(k_bordered_seal, dim3(1), dim3(1), 0, s, a, counters, total_bytes, flags, status);
   return hipGetLastError();
 }
 

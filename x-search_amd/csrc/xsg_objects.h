@@ -18,6 +18,16 @@ const char* last_error_message();
 bool trace_on();
 void trace(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 }  // namespace xsg
+// An XSG_* tuning / A-B toggle: read from the environment ONCE per process (getenv next to a host thread that writes the
+// environment is a data race, and the one-sync list route exists to save microseconds).  XSG_TEST_HOOKS=1, set before the
+// library is loaded (tests/conftest.py, scripts/fuzz_campaign.py), re-reads it at every use: the route tests switch
+// toggles between searches.
+namespace xsg {
+bool test_hooks();
+}
+#define XSG_TOGGLE(name) \
+  ([]() -> const char* { static const char* const v = getenv(name); return xsg::test_hooks() ? getenv(name) : v; }())
+
 #define XSG_TRACE(...)                      \
   do {                                      \
     if (xsg::trace_on()) xsg::trace(__VA_ARGS__); \
@@ -103,6 +113,10 @@ struct xsg_ctx {
   uint64_t probe_min_bytes = 64ull << 20;          // shards below this keep the defaults (XSG_PROBE_MIN_BYTES; tests set 0)
   int hot_env = -1;                                // XSG_HOT=0|1 pins the hot filter of the window kinds; -1: measured per shard
   uint64_t pattern_serial = 0;                     // bumped by every xsg_set_pattern
+  // the pattern_serial whose lists did not fit the one-sync list route's capacity on SOME binding of this context: later
+  // bindings (the file pipeline re-binds its shard for every chunk) go to the exact route at once instead of running the
+  // whole one-sync attempt first and then the exact route, chunk after chunk.  A choice, not a result.
+  uint64_t fast_dense_serial = 0;
   std::vector<uint32_t> koff_cands;                // long literal patterns: filter windows worth measuring (first: the heuristic's)
   char arch[128] = "";
   int cus = 0;

@@ -27,7 +27,9 @@ WITH_NEWLINES = 0x100
 CTR_MATCHES, CTR_LINES, CTR_NEWLINES, CTR_BYTES = range(4)
 NUM_COUNTERS = 4
 LINE_BASE_AUTO = (1 << 64) - 1
-MAX_PATTERN = 1024
+MAX_PATTERN = 32768
+MAX_REGEX = 1024
+STATUS_OK, STATUS_OVERFLOW, STATUS_NONASCII = 0, 1, 2
 TILE = 16384
 
 CHUNK_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u8"), ("global_offset", "<u8"), ("line_base", "<u8")])
@@ -118,6 +120,7 @@ def load():
         "xsg_shard_destroy": (None, [vp]),
         "xsg_shard_set_line_base": (ci, [vp, u64]),
         "xsg_count_async": (ci, [vp, u32, vp, vp]),
+        "xsg_count_async_status": (ci, [vp, u32, vp, vp, vp]),
         "xsg_count": (ci, [vp, u32, _u64p]),
         "xsg_count_begin": (ci, [vp, u32]),
         "xsg_count_end": (ci, [vp, _u64p]),
@@ -147,6 +150,7 @@ def load():
         "xsg_meta_read": (ci, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(vp), _u64p, C.POINTER(vp), _u64p]),
         "xsg_meta_write": (ci, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, u64, u64, ci]),
         "xsg_free": (None, [vp]),
+        "xsg_codec_name": (C.c_char_p, [C.c_int32]),
         "xsg_ctx_info": (ci, [vp, C.c_char_p, sz, C.POINTER(ci), _u64p]),
         "xsg_time_scan_kernel": (ci, [vp, u32, ci, C.POINTER(C.c_float)]),
         "xsg_comm_unique_id": (ci, [vp, sz]),
@@ -182,7 +186,7 @@ EXPORTS = ["xsg_abi_version", "xsg_strerror", "xsg_last_error", "xsg_device_coun
            "xsg_count_end", "xsg_comm_unique_id", "xsg_comm_create_rank", "xsg_comm_create_local", "xsg_comm_destroy",
            "xsg_comm_size", "xsg_comm_library", "xsg_reduce_counts_async", "xsg_reduce_counts", "xsg_allgather_u64",
            "xsg_jobs_reduce_total", "xsg_device_numa", "xsg_regex_info", "xsg_regex_dfa_info", "xsg_regex_prefix", "xsg_regex_factor",
-           "xsg_result_u64_view", "xsg_shard_invalidate", "xsg_result_lines_view"]
+           "xsg_result_u64_view", "xsg_shard_invalidate", "xsg_result_lines_view", "xsg_count_async_status", "xsg_codec_name"]
 
 
 def _check(rc):
@@ -344,6 +348,10 @@ class Shard:
 
     def count_async(self, mode: int, stream: int, d_counters: int):
         _check(self._lib.xsg_count_async(self.h, mode, C.c_void_p(stream), C.c_void_p(d_counters)))
+
+    def count_async_status(self, mode: int, stream: int, d_counters: int, d_status: int):
+        """the stream-ordered count with a status word (device uint64): 0, or STATUS_* bits and zeroed counters"""
+        _check(self._lib.xsg_count_async_status(self.h, mode, C.c_void_p(stream), C.c_void_p(d_counters), C.c_void_p(d_status)))
 
     def count(self, mode: int) -> np.ndarray:
         out = np.zeros(NUM_COUNTERS, dtype=np.uint64)
@@ -543,6 +551,11 @@ def meta_read(path: str, with_mappings: bool = False):
     maps = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint64)), shape=(max(nm.value, 1) * 2,))[:nm.value * 2].copy()
     lib.xsg_free(mp)
     return comp.value, chunks, maps.reshape(-1, 2)
+
+
+def codec_name(compression: int) -> str:
+    """which decoder serves a compression type on this host ("liblz4", "built-in LZ4 block codec", "libzstd", "none", "")"""
+    return load().xsg_codec_name(compression).decode()
 
 
 def meta_write(path: str, meta_out: str, data_out: str | None = None, compression: int = COMPRESSION_NONE,
