@@ -328,6 +328,7 @@ struct LineOutArgs {
   uint8_t* line_bytes_host;  // pinned mirror of line_bytes
   uint64_t line_bytes_cap;   // bytes line_bytes (and its mirror) can hold
   uint32_t* dropped;         // k_line_lengths: incremented per line without a terminating newline (may be null)
+  uint64_t slice_begin, slice_end;  // k_line_gather: only the entries [slice_begin, slice_end) (slice_end == 0: all of them)
 };
 hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_nl_delta(const LineOutArgs& a, hipStream_t s);

@@ -295,8 +295,8 @@ struct WaveState {
   uint32_t lacc = 0;      // newline-closed lines with a match counted by this lane
   uint32_t lsacc = 0;     // ... and on the scalar unit (a wave-load without a match start whose first newline closes one) (wave-uniform)
   uint32_t lcin = 0;      // the line that is open at this point of the span already holds a match (wave-uniform 0 / 1)
-  uint32_t lseen = 0;     // the span has shown a newline (wave-uniform)
-  uint32_t lF = 0;        // a match start before the span's first newline (wave-uniform)
+  unsigned long long lseen_m = 0;  // != 0: the span has shown a newline (wave-uniform; the OR of the wave-loads' newline ballots)
+  unsigned long long lFm = 0;      // != 0: a match start before the span's first newline (wave-uniform)
   // kMask1: 0 = nobody asked for the number of matches (count_lines alone, ScanArgs::lines_only): `cnt` stays 0
   uint32_t count_on = 1;  // (wave-uniform)
   uint32_t track_last = 1;  // kMask1: last_rel is needed (the finish kernel walks the end of the chunk: plen > 1, lossy tail)
@@ -332,10 +332,13 @@ struct WaveState {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void lines_flag_step(const uint32_t (&nf)[4], const unsigned long long Mm, const uint32_t (&src)[8],
                                                 uint32_t lane, WaveState& st) {
-  // the line state is wave-uniform and lives on the scalar unit: everything it is computed from is a ballot or was
-  // declared uniform (Gm below) -- no readfirstlane on the state itself (that parks it in a vector register)
-  const uint32_t lcin0 = st.lcin, lseen0 = st.lseen;
-  if (Mm != 0 || lcin0 != 0 || lseen0 == 0) {  // otherwise nothing here can change the state or the counts
+  // The line state is wave-uniform and lives on the scalar unit.  "Seen a newline" and "a match before the first newline"
+  // are kept as 64-bit MASKS (non-zero = true), OR-ed together from ballots: a 0 / 1 flag made from a comparison
+  // (`Nm != 0 ? 1 : 0`) is built by the compiler through v_cndmask / v_cmp / v_readfirstlane -- two to four VALU
+  // instructions per use, per wave-load.
+  const uint32_t lcin0 = st.lcin;
+  const unsigned long long seen0 = st.lseen_m;
+  if (Mm != 0 || lcin0 != 0 || seen0 == 0) {  // otherwise nothing here can change the state or the counts
     uint32_t nn[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -343,84 +346,72 @@ __device__ __forceinline__ void lines_flag_step(const uint32_t (&nf)[4], const u
       nn[q] = ((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu;
     }
     const unsigned long long Nm = __ballot((nn[0] & nn[1] & nn[2] & nn[3]) != 0xffffffffu);  // units with a newline
-    uint32_t lcin = lcin0;
-    if (Mm == 0) {
-      // no match start in the wave-load: its first newline closes the open line -- counted now if it holds a match
+    if (seen0 == 0 && Mm != 0) {  // a match start before the span's first newline?  (once per span; scalar)
+      unsigned long long fm = Mm;  // no newline yet: any match start
       if (Nm != 0) {
-        st.lsacc += lcin0;
-        lcin = 0;
-      }
-    } else {
-      if (lseen0 == 0) {  // a match start before the span's first newline?  (once per span; scalar)
-        uint32_t f = 1;  // no newline yet: any match start (Mm != 0 here)
-        if (Nm != 0) {
-          const int i0 = __builtin_ctzll(Nm);
-          f = (Mm & ((1ull << i0) - 1ull)) != 0 ? 1u : 0u;
-          bool open = true;
+        const int i0 = __builtin_ctzll(Nm);
+        fm = Mm & ((1ull << i0) - 1ull);  // the units before the one with the first newline
+        uint32_t open = 0xffffffffu;      // all ones while no newline has been met inside that unit
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t fq = ~(uint32_t)__builtin_amdgcn_readlane((int)nf[q], i0);
-            const uint32_t nq = ~(uint32_t)__builtin_amdgcn_readlane((int)nn[q], i0);
-            const uint32_t below = nq ? (nq & (0u - nq)) - 1u : 0xffffffffu;  // below the unit's first newline
-            f |= (open && (fq & below) != 0) ? 1u : 0u;
-            open = open && nq == 0;
-          }
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t fq = ~(uint32_t)__builtin_amdgcn_readlane((int)nf[q], i0);
+          const uint32_t nq = ~(uint32_t)__builtin_amdgcn_readlane((int)nn[q], i0);
+          const uint32_t below = (nq & (0u - nq)) - 1u;  // below the dword's first newline (all ones if it has none)
+          fm |= (unsigned long long)(open & fq & below);
+          open &= (uint32_t)(((unsigned long long)nq - 1ull) >> 32);  // all ones iff nq == 0, by arithmetic (no compare + select)
         }
-        st.lF |= f;
       }
-      // One block of assembly, so that nothing between the two passes has to be "declared uniform" again (an asm result
-      // counts as divergent whatever its constraint says, and every readfirstlane of a scalar costs a v_mov and a
-      // v_readfirstlane):
-      //   pass 1  nn - nf - 1 (borrow-in set everywhere; differences unused): no borrow out = the unit carries out on its
-      //           own = its last event is a match start: generate, G = ~vcc
-      //   scalar  carries of a + b + cin with a = G | ~N (generate or propagate: no newline in the unit), b = G, through
-      //           the scalar carry flag -- s_cmp sets it to cin, two s_addc_u32 thread it through, the second leaves the
-      //           carry out of bit 63 = "the line open at the end of the wave-load holds a match"; C = sum ^ a ^ b = the
-      //           carry INTO every lane's unit; vcc = ~C
-      //   pass 2  nn - nf - (1 - cin): the sums with the true carry-in
-      uint32_t x0, x1, x2, x3, glo, ghi, alo, ahi, slo, shi, cout;
-      asm("s_mov_b64 vcc, -1\n\t"
-          "v_subb_co_u32_e32 %0, vcc, %11, %15, vcc\n\t"
-          "v_subb_co_u32_e32 %0, vcc, %12, %16, vcc\n\t"
-          "v_subb_co_u32_e32 %0, vcc, %13, %17, vcc\n\t"
-          "v_subb_co_u32_e32 %0, vcc, %14, %18, vcc\n\t"
-          "s_not_b32 %4, vcc_lo\n\t"
-          "s_not_b32 %5, vcc_hi\n\t"
-          "s_orn2_b32 %6, %4, %19\n\t"
-          "s_orn2_b32 %7, %5, %20\n\t"
-          "s_cmp_lg_u32 %21, 0\n\t"
-          "s_addc_u32 %8, %6, %4\n\t"
-          "s_addc_u32 %9, %7, %5\n\t"
-          "s_cselect_b32 %10, 1, 0\n\t"
-          "s_xor_b32 %8, %8, %6\n\t"
-          "s_xor_b32 %9, %9, %7\n\t"
-          "s_xnor_b32 vcc_lo, %8, %4\n\t"
-          "s_xnor_b32 vcc_hi, %9, %5\n\t"
-          "v_subb_co_u32_e32 %0, vcc, %11, %15, vcc\n\t"
-          "v_subb_co_u32_e32 %1, vcc, %12, %16, vcc\n\t"
-          "v_subb_co_u32_e32 %2, vcc, %13, %17, vcc\n\t"
-          "v_subb_co_u32_e32 %3, vcc, %14, %18, vcc"
-          : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&s"(glo), "=&s"(ghi), "=&s"(alo), "=&s"(ahi), "=&s"(slo), "=&s"(shi),
-            "=&s"(cout)
-          : "v"(nn[0]), "v"(nn[1]), "v"(nn[2]), "v"(nn[3]), "v"(nf[0]), "v"(nf[1]), "v"(nf[2]), "v"(nf[3]), "s"((uint32_t)Nm),
-            "s"((uint32_t)(Nm >> 32)), "s"(lcin0)
-          : "vcc", "scc");
-      lcin = (uint32_t)__builtin_amdgcn_readfirstlane((int)cout);
-      // (v_bcnt_u32_b32 adds to an accumulator: four instructions, the lane's count threaded through them)
-      uint32_t acc = st.lacc;
-      asm("v_bcnt_u32_b32 %0, %1, %0\n\t"
-          "v_bcnt_u32_b32 %0, %2, %0\n\t"
-          "v_bcnt_u32_b32 %0, %3, %0\n\t"
-          "v_bcnt_u32_b32 %0, %4, %0"
-          : "+v"(acc)
-          : "v"(x0 & ~nn[0]), "v"(x1 & ~nn[1]), "v"(x2 & ~nn[2]), "v"(x3 & ~nn[3]));
-      st.lacc = acc;
+      st.lFm |= fm;
     }
-    // (all of this is derived from ballots and from Gm, which was declared uniform above: it stays on the scalar unit
-    // without a readfirstlane -- with one, the compiler built the value in a vector register first: four VALU
-    // instructions per wave-load for one scalar OR)
-    st.lcin = lcin;
-    st.lseen = lseen0 | (Nm != 0 ? 1u : 0u);
+    // One block of assembly, so that nothing between the two passes has to be "declared uniform" again (an asm result
+    // counts as divergent whatever its constraint says, and every readfirstlane of a scalar costs a v_mov and a
+    // v_readfirstlane).  It also serves a wave-load WITHOUT a match start: no unit generates, the carry-in runs up to the
+    // first newline, which is counted if the open line held a match.
+    //   pass 1  nn - nf - 1 (borrow-in set everywhere; differences unused): no borrow out = the unit carries out on its
+    //           own = its last event is a match start: generate, G = ~vcc
+    //   scalar  carries of a + b + cin with a = G | ~N (generate or propagate: no newline in the unit), b = G, through
+    //           the scalar carry flag -- s_cmp sets it to cin, two s_addc_u32 thread it through, the second leaves the
+    //           carry out of bit 63 = "the line open at the end of the wave-load holds a match"; C = sum ^ a ^ b = the
+    //           carry INTO every lane's unit; vcc = ~C
+    //   pass 2  nn - nf - (1 - cin): the sums with the true carry-in; popcount(S & ~nn) = lines closed here with a match
+    //           (v_bcnt_u32_b32 adds to an accumulator: the lane's count is threaded through the four)
+    uint32_t x0, x1, x2, x3, glo, ghi, alo, ahi, slo, shi, cout;
+    asm("s_mov_b64 vcc, -1\n\t"
+        "v_subb_co_u32_e32 %0, vcc, %12, %16, vcc\n\t"
+        "v_subb_co_u32_e32 %0, vcc, %13, %17, vcc\n\t"
+        "v_subb_co_u32_e32 %0, vcc, %14, %18, vcc\n\t"
+        "v_subb_co_u32_e32 %0, vcc, %15, %19, vcc\n\t"
+        "s_not_b32 %4, vcc_lo\n\t"
+        "s_not_b32 %5, vcc_hi\n\t"
+        "s_orn2_b32 %6, %4, %20\n\t"
+        "s_orn2_b32 %7, %5, %21\n\t"
+        "s_cmp_lg_u32 %22, 0\n\t"
+        "s_addc_u32 %8, %6, %4\n\t"
+        "s_addc_u32 %9, %7, %5\n\t"
+        "s_cselect_b32 %10, 1, 0\n\t"
+        "s_xor_b32 %8, %8, %6\n\t"
+        "s_xor_b32 %9, %9, %7\n\t"
+        "s_xnor_b32 vcc_lo, %8, %4\n\t"
+        "s_xnor_b32 vcc_hi, %9, %5\n\t"
+        "v_subb_co_u32_e32 %0, vcc, %12, %16, vcc\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %13, %17, vcc\n\t"
+        "v_subb_co_u32_e32 %2, vcc, %14, %18, vcc\n\t"
+        "v_subb_co_u32_e32 %3, vcc, %15, %19, vcc\n\t"
+        "v_bitop3_b32 %0, %0, %12, %0 bitop3:0x30\n\t"
+        "v_bitop3_b32 %1, %1, %13, %1 bitop3:0x30\n\t"
+        "v_bitop3_b32 %2, %2, %14, %2 bitop3:0x30\n\t"
+        "v_bitop3_b32 %3, %3, %15, %3 bitop3:0x30\n\t"
+        "v_bcnt_u32_b32 %11, %0, %11\n\t"
+        "v_bcnt_u32_b32 %11, %1, %11\n\t"
+        "v_bcnt_u32_b32 %11, %2, %11\n\t"
+        "v_bcnt_u32_b32 %11, %3, %11"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&s"(glo), "=&s"(ghi), "=&s"(alo), "=&s"(ahi), "=&s"(slo), "=&s"(shi),
+          "=&s"(cout), "+v"(st.lacc)
+        : "v"(nn[0]), "v"(nn[1]), "v"(nn[2]), "v"(nn[3]), "v"(nf[0]), "v"(nf[1]), "v"(nf[2]), "v"(nf[3]), "s"((uint32_t)Nm),
+          "s"((uint32_t)(Nm >> 32)), "s"(lcin0)
+        : "vcc", "scc");
+    st.lcin = (uint32_t)__builtin_amdgcn_readfirstlane((int)cout);
+    st.lseen_m = seen0 | Nm;
   }
 }
 
@@ -914,12 +905,13 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
     // the first of them is F (its match lies before the span's first newline), the rest are C; L = the final carry: the
     // line that is open at the end of the span holds a match.  Without a newline in the span nothing was closed and that
     // carry says whether the span holds a match at all.
-    if (!st.lseen) {
+    if (st.lseen_m == 0) {
       const uint32_t f = st.lcin;
       wsum = (f << 1) | (f << 2);
     } else {
+      const uint32_t lF = st.lFm != 0 ? 1u : 0u;
       const uint32_t T = (__any(st.lacc != 0) ? wave_sum_u32(st.lacc) : 0u) + st.lsacc;
-      wsum = kSumNl | (st.lF << 1) | (st.lcin << 2) | ((T - st.lF) << kSumCShift);
+      wsum = kSumNl | (lF << 1) | (st.lcin << 2) | ((T - lF) << kSumCShift);
     }
   }
 

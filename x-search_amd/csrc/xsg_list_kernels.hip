@@ -987,9 +987,10 @@ __global__ __launch_bounds__(kBlock) void k_line_gather(const LineOutArgs A) {
   const uint32_t lane = threadIdx.x & 63u;
   if (A.line_bytes_cap && A.line_out_off[total] > A.line_bytes_cap) return;
   uint8_t* const mirror = A.line_bytes_host;
-  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); i0 < total; i0 += (uint64_t)gridDim.x * kBlock) {
+  const uint64_t first = A.slice_end ? A.slice_begin : 0, stop = A.slice_end ? (A.slice_end < total ? A.slice_end : total) : total;
+  for (uint64_t i0 = first + (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); i0 < stop; i0 += (uint64_t)gridDim.x * kBlock) {
     const uint64_t i = i0 + lane;
-    uint64_t len = i < total ? A.line_len[i] : UINT64_MAX;
+    uint64_t len = i < stop ? A.line_len[i] : UINT64_MAX;
     const bool live = len != UINT64_MAX;  // UINT64_MAX: no terminating newline -> not reported
     const uint8_t* src = live ? A.base + A.chunks[A.f_chunk[i]].offset + A.f_pos[i] : nullptr;
     const uint64_t doff = live ? A.line_out_off[i] : 0;
@@ -1060,7 +1061,9 @@ hipError_t launch_line_index_waves(const LineOutArgs& a, hipStream_t s) {
 }
 hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s) {
   if (!a.total) return hipSuccess;
-  hipLaunchKernelGGL(k_line_gather, a.tot_dev ? grid_capped(a.total) : grid_for(a.total), dim3(kBlock), 0, s, a);
+  const uint64_t n = a.slice_end ? a.slice_end - a.slice_begin : a.total;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_line_gather, a.tot_dev ? grid_capped(n) : grid_for(n), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 
