@@ -34,6 +34,13 @@ CASES = {
     "one_that": ("that", 0, "count"),
     "mask2_Holmes": ("Holmes", 0, "count"),
     "mask2_Sherl": ("Sherl", 0, "count"),
+    "lines_Holmes": ("Holmes", 0, "count_lines"),
+    "lines_Sherl": ("Sherl", 0, "count_lines"),
+    "lines_that": ("that", 0, "count_lines"),
+    "two_detectiv": ("detectiv", 0, "count"),
+    "lines_detectiv": ("detectiv", 0, "count_lines"),
+    "mask2_detecti": ("detecti", 0, "count"),
+    "lines_detecti": ("detecti", 0, "count_lines"),
     "long_Sherlock_Holmes": ("Sherlock Holmes", 0, "count"),
     "long_detective_street": ("detective street", 0, "count"),
     "class_She_r_lock": ("She[r ]lock", "regex", "count"),

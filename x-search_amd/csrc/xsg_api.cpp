@@ -817,7 +817,7 @@ static ScanArgs scan_args(xsg_shard* s, uint32_t variant = 0) {
   a.tune = s->ctx->tune != kTuneAuto ? s->ctx->tune
                                      : (s->tune_serial == s->ctx->pattern_serial || s->tune_serial == 0) ? s->tune : kTuneAuto;
   a.epoch = s->epoch;
-  a.dense_hint = (s->density_serial == s->ctx->pattern_serial && s->dense) ? 1u : 0u;
+  a.dense_hint = s->density_serial == s->ctx->pattern_serial ? s->dense : 0u;
   a.pat = s->ctx->pat;
   a.pat.hot = s->ctx->hot_env >= 0 ? (uint32_t)s->ctx->hot_env
               : (s->hot_serial == s->ctx->pattern_serial && ((s->hot_known >> variant) & 1u)) ? s->hot_v[variant] : 0u;
@@ -1337,7 +1337,12 @@ constexpr int kDenseCandidates = 1;  // run_list(outputs = false) on the prefilt
 static void note_density(xsg_shard* s, uint64_t results) {
   if (results == UINT64_MAX) return;
   s->density_serial = s->ctx->pattern_serial;
-  s->dense = results > s->total_bytes / 2048u;
+  // 2: the wave stagger that pays for a sparse needle costs such a scan (pick_stagger); 1: already at one result per 8 KiB a
+  // 4..8-byte needle sends a quarter of its wave-loads into the slow path and is cheaper decided byte-parallel
+  // (dense_bytes_route; natural text, 10 GiB: `return`, one per 4 KiB, 0.72 of peak on the hot filter -- profiles/r04_natural_variants.txt)
+  uint64_t per = 8192u;
+  if (const char* e = XSG_TOGGLE("XSG_DENSE_PER")) per = std::max<uint64_t>(strtoull(e, nullptr, 10), 1u);  // A/B: scripts/natural_density.py
+  s->dense = results > s->total_bytes / 2048u ? 2u : results > s->total_bytes / per ? 1u : 0u;
 }
 
 extern "C" int xsg_count(xsg_shard* s, uint32_t mode, uint64_t counters[XSG_NUM_COUNTERS]) {

@@ -104,7 +104,8 @@ struct ScanArgs {
   uint32_t* tile_nl;                   // '\n' in the tile              (WANT_NL; every tile is written)
   uint32_t* tile_sum;                  // line summary PER WAVE (4 per tile), stored XOR kSumNl (WANT_LINES)
   uint32_t* tile_last;                 // (epoch << 16) | max (match offset + plen) in the tile, relative to the tile start
-  uint32_t dense_hint;                 // an earlier count of this pattern over this shard found it dense (pick_stagger)
+  uint32_t dense_hint;                 // an earlier count of this pattern over this shard found it dense: 1 = more than one result
+                                       // per 8 KiB (dense_bytes_route), 2 = more than one per 2 KiB (pick_stagger too)
   uint32_t lines_only;                 // count pass with line summaries, matches not asked for (xs::count_lines): a kMask1
                                        // needle skips its match counting (and, where no end-of-chunk walk exists, tile_cnt /
                                        // tile_last altogether)

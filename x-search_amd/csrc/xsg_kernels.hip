@@ -1078,9 +1078,18 @@ static dim3 tile_grid(uint64_t ntiles) {
 // needles (scan_load, kMask1): no hot filter, no slow path -- every wave-load would take it.  (ignore_case only for
 // needles of letters, which need no fold: folding every byte up front costs more than the slow path does;
 // XSG_DENSE_BYTES=0 switches the re-routing off.)
-static bool dense_bytes_route(const ScanArgs& a) {
+// The matching-lines count of a 4..6-byte needle goes that way at ANY density: those kinds have no aligned-dword trigger,
+// and their window filter plus the line bookkeeping is more VALU work per wave-load than deciding every byte (natural
+// text, 10 GiB, kernel alone: `yield`, one per 100 KiB, 0.864 -> 0.907 of 8 TB/s; `import`, one per 6 KiB, 0.817 -> 0.861;
+// the bench corpus' `Sherl`, one per 1.6 MB, 0.879 -> 0.915; 7 and 8 bytes lose: `finally` 0.865 -> 0.848, `Sherlock`
+// 0.932 -> 0.807 -- profiles/r04_density_routes.txt).
+static bool dense_bytes_route(const ScanArgs& a, bool want_lines, bool emit) {
   static const bool on = [] { const char* e = getenv("XSG_DENSE_BYTES"); return !(e && *e == '0'); }();
-  return on && a.dense_hint && (!a.pat.icase || a.pat.lazy_exact) && (a.pat.kind == kOne || a.pat.kind == kMask2 || a.pat.kind == kTwo);
+  if (!on || (a.pat.icase && !a.pat.lazy_exact)) return false;
+  if (a.pat.kind != kOne && a.pat.kind != kMask2 && a.pat.kind != kTwo) return false;
+  if (a.dense_hint) return true;
+  static const bool lines_rule = [] { const char* e = getenv("XSG_DENSE_LINES"); return !(e && *e == '0'); }();
+  return lines_rule && want_lines && !emit && a.pat.plen <= 6u;
 }
 
 static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, bool emit) {
@@ -1096,7 +1105,7 @@ static uint32_t pick_stagger(const ScanArgs& a, bool want_nl, bool want_lines, b
                      (!a.pat.icase || a.pat.kind == kTwo) && !want_nl && !emit;
   // count_lines too: 7.1 TB/s at 4 against 7.46-7.49 at 16 on the 50 GiB shard.  A needle an earlier count found dense in
   // this data (ScanArgs::dense_hint) keeps the slow path busy: 4 (`that`, 191 M matches in 50 GiB: 8.25 ms at 16, 7.66 at 4)
-  return !light ? 0u : a.dense_hint ? 4u : kDefaultStagger;
+  return !light ? 0u : a.dense_hint >= 2u ? 4u : kDefaultStagger;
 }
 
 void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, char* out, size_t cap) {
@@ -1115,7 +1124,7 @@ void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, 
     return;
   }
   ScanArgs r = a;
-  if (dense_bytes_route(a)) r.pat.kind = kMask1;
+  if (dense_bytes_route(a, want_lines, emit)) r.pat.kind = kMask1;
   const bool window = r.pat.kind == kTwo || r.pat.kind == kLong || r.pat.kind == kClass;
   const int kind = (r.pat.kind == kClass && r.pat.cls_fast && !r.pat.hot) ? (int)kClassFast : (int)r.pat.kind;
   snprintf(out, cap, "xsg::k_scan<%d, %s, %s, %s, 4, %s, %s> stagger=%u%s", kind, b[emit ? 0 : want_nl],
@@ -1126,7 +1135,7 @@ void describe_scan(const ScanArgs& a, bool want_nl, bool want_lines, bool emit, 
 static hipError_t launch_scan(const ScanArgs& a_in, bool want_nl, bool want_lines, bool emit, hipStream_t s) {
   if (a_in.ntiles == 0) return hipSuccess;
   ScanArgs a = a_in;
-  if (dense_bytes_route(a)) a.pat.kind = kMask1;
+  if (dense_bytes_route(a, want_lines, emit)) a.pat.kind = kMask1;
   a.tune = pick_stagger(a, want_nl, want_lines, emit);
   static const uint64_t emit_grid = [] { const char* e = getenv("XSG_EMIT_GRID"); return e && atoll(e) > 0 ? (uint64_t)atoll(e) : 16384ull; }();
   const dim3 grid = (emit && a.hit_tiles) ? dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(a.hit_cap, 1), emit_grid), 1, 1)

@@ -153,7 +153,7 @@ struct xsg_shard {
   uint64_t overlap_serial = 0;     // ctx->pattern_serial for which `overlap_free` was established on this binding
   bool overlap_free = false;       // ... no two occurrences of the (bordered) pattern overlap anywhere in these chunks
   uint64_t density_serial = 0;     // ctx->pattern_serial for which `dense` was observed (a synchronous count's result)
-  bool dense = false;              // ... more than one result per 2 KiB of this data
+  uint32_t dense = 0;              // ... 1: more than one result per 8 KiB of this data, 2: more than one per 2 KiB
   bool tune_probe = false;         // `tune` came from choose_hot_filter's two-way probe (re-measured after a re-bind), not from xsg_shard_tune
   // hot filter of the window kinds for (this binding, the ctx's current pattern): measured once PER KERNEL VARIANT the
   // caller's mode launches (bit 0 of the index: the pass also counts newlines; bit 1: it builds line summaries) -- the

@@ -311,6 +311,15 @@ class Context:
 
 
 class Shard:
+    """Chunks already resident in HBM, bound for searching (xsg_shard_create).
+
+    The bound bytes are IMMUTABLE while the binding lives, as the reference's chunk is a value its searchers only read
+    (concepts.h:36-39).  The library remembers things it derived from them -- newline counts per tile, which hot filter
+    won, and for a literal that can overlap itself (`aa`, `abab`, `that`) whether it DOES overlap in these bytes, which
+    decides how it is counted.  Refill the buffer in place and you must call rebind() or invalidate() before the next
+    search, or such a needle is counted with the old buffer's verdict.
+    """
+
     def __init__(self, ctx: Context, d_base: int, capacity: int, chunks: np.ndarray):
         self._lib = ctx._lib
         self.ctx = ctx
