@@ -8,6 +8,7 @@ REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$REPO/gpurun_out
 TAG=${1:-r03}
 mkdir -p $OUT
+export XSG_BENCH_CLI=0  # the cli block starts fresh xsgrep / grep processes: not under the profiler, not in these runs
 rm -rf $OUT/prof_${TAG}_stats $OUT/prof_${TAG}_fetch* $OUT/prof_${TAG}_write*
 cd $REPO
 timeout -k 10 600 python bench.py --e2e-gib 0 --no-cpu-baseline --configs-gib 0 --no-regex > $OUT/bench_${TAG}_plain.log 2>&1 || { tail -3 $OUT/bench_${TAG}_plain.log; exit 1; }
@@ -29,4 +30,5 @@ cd $REPO
 python3 scripts/pmc_traffic.py $OUT/BENCH_${TAG}_plain.json $TAG $ARGS > $OUT/${TAG}_pmc_traffic.json || exit 1
 python3 -c "import json;d=json.load(open('$OUT/${TAG}_pmc_traffic.json'));[print(k, v['ratio_traffic_over_algorithmic'], v['hbm_bytes_per_launch']) for k,v in d['by_kernel'].items()]"
 for f in $(find $OUT/prof_${TAG}_stats -name '*kernel_stats.csv' | head -1); do cp $f $OUT/${TAG}_bench50g_kernel_stats.csv; head -8 $f | cut -c1-200; done
+for f in $(find $OUT/prof_${TAG}_stats -name '*kernel_trace.csv' | head -1); do python3 scripts/trace_by_grid.py $f > $OUT/${TAG}_bench50g_kernel_trace_by_grid.txt; done
 exit 0
