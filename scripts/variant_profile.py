@@ -62,7 +62,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default="count_Sherlock", help="one case, a comma-separated list (one shard, one process), or 'all'")
     ap.add_argument("--gib", type=float, default=20.0)
-    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=15)
+    ap.add_argument("--warm", type=int, default=20, help="untimed launches first: the clocks of an idle card ramp for several ms, and the\n                    VALU-heavier variants feel it (5 timed launches right after the shard fill read 3-7 %% low)")
     ap.add_argument("--tune", action="store_true")
     ap.add_argument("--lexicon", choices=["bench", "plain", "nosh"], default="bench",
                     help="plain: the bench lexicon without the words that are pieces of the needle (She, lock, locked, Sher)")
@@ -102,6 +103,8 @@ def main():
         # the count first: the timed launches are then what every call after the first one launches (a needle the first
         # count found dense runs with a smaller wave stagger, x-search_amd/csrc/xsg_api.cpp: density_serial)
         cm = int(sh.count(modes[mode])[xsg.CTR_LINES if mode == "count_lines" else xsg.CTR_MATCHES])
+        if a.warm > 0:
+            sh.time_scan_kernel(modes[mode], a.warm)
         ms = sh.time_scan_kernel(modes[mode], a.iters)
         print(json.dumps({"case": name, "pattern": pat, "flags": fl, "mode": mode, "gib": a.gib, "bytes": nbytes, "lexicon": a.lexicon,
                           "result": cm, "bytes_per_result": round(nbytes / max(cm, 1), 1),

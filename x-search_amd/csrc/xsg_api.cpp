@@ -998,9 +998,14 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st, bool want_nl = false,
       ms[hot] = std::min(ms[hot], t);
     }
   }
-  // the aligned trigger has to win: by 2 % where the variant is VALU-bound and the stakes are 12 %; by any margin the
-  // probe can see where the kernel waits for memory (the plain count: 1.7 % either way, measured with the stagger off)
-  s->hot_v[v] = ms[1] < (v == 0 ? 0.995f : 0.985f) * ms[0] ? 1u : 0u;
+  // The plain count waits for memory and the window filter is its better half at every size measured with warm clocks
+  // (10 / 20 / 50 GiB: 0.925 / 0.933 / 0.938 of peak against 0.89-0.90): the aligned trigger has to win visibly.  The
+  // variants that also count newlines or keep line summaries are VALU-bound, the trigger is half the filter work and wins
+  // by 3-6 % at full size (count_lines 0.92-0.94 against 0.89; with newline counts 0.89 against 0.84) -- but on the 2 GiB
+  // prefix the launch ramp dilutes that to ~1 %, inside the probe's noise (a 10 GiB shard: 0.2962 against 0.2993 ms, and a
+  // 1.5 % bar kept the window filter): there the WINDOW filter has to win by 1.5 %, as it does when the trigger's pieces
+  // are common in the text (profiles/r04_dense_variants.txt).
+  s->hot_v[v] = (v == 0 ? ms[1] < 0.995f * ms[0] : ms[1] < 1.015f * ms[0]) ? 1u : 0u;
   s->hot_known |= (uint8_t)(1u << v);
   static const bool probe_log = getenv("XSG_PROBE_LOG") != nullptr;
   if (probe_log)

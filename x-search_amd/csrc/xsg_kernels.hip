@@ -755,6 +755,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
   constexpr uint32_t kTile = kWaveSpan * kWaves;         // bytes per workgroup
   __shared__ uint32_t s_cnt[kWaves];
   __shared__ uint32_t s_nl[kWaves];
+  __shared__ __attribute__((aligned(16))) uint32_t s_ep[KIND == kMask1 ? kWaves : 1][4];  // kMask1's epilogue: one writer per tile
   __shared__ __attribute__((aligned(16))) uint8_t s_pat[is_cls(KIND) ? 2048 : KIND == kLong ? kLdsPattern : 16];
   __shared__ __attribute__((aligned(16))) uint8_t s_view[is_cls(KIND) ? kBlock * 48 : 16];  // match_mask16<kClass>
 
@@ -929,13 +930,16 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
     const unsigned long long any_m = KIND == kMask1 ? (st.lMm[0] | st.lMm[1] | st.lMm[2] | st.lMm[3]) : 0ull;
     if (KIND == kMask1) wave_has = st.count_on ? __any(cnt != 0) : any_m != 0;  // (lines only, no end-of-chunk walk: nothing to report)
     else wave_has = __any(cnt != 0);
-    if (wave_has) {
-      const uint32_t wc = wave_sum_u32(cnt);
-      // the end of the wave's last match, relative to the tile start: it fits 16 bits, so the reduction runs on
-      // 32-bit values (a 64-bit max costs three times the lane exchanges; a needle that is dense in the text pays
-      // this epilogue in every wave)
-      uint32_t rel;
-      if (KIND == kMask1) {
+    if (KIND == kMask1) {
+      // The byte-parallel kind is what DENSE needles run on (1..3 bytes, and 4..8-byte ones found dense): every wave has
+      // something to report, and four waves x three atomics per 16 KiB of text were 2.5-4 % of the scan (20 GiB, `e` / `the` /
+      // `that`: 0.857 of peak, 0.885 with the atomics taken out, 0.88 with one wave's only -- profiles/r04_dense_variants.txt).
+      // So the waves meet in LDS and ONE lane writes the tile's words with plain stores: the tile count (at rest 0, one writer),
+      // the wave marks as the tile's byte of tile_wmask, the end of the last match with this pass's tag, the four line
+      // summaries as one 16-byte store, the newline count.
+      uint32_t wc = 0, rel = 0;
+      if (wave_has) {
+        wc = wave_sum_u32(cnt);
         rel = 1u;  // no end-of-chunk walk reads it (it must stay inside the tile: tile_last's tag)
         if (st.track_last && any_m != 0) {  // scalar: the highest lane of the last wave-load with a match
           bool found = false;
@@ -952,9 +956,44 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
             }
           }
         }
-      } else {
-        rel = wave_max_u32(st.last_rel);
       }
+      uint32_t wn = 0;
+      if (WANT_NL) wn = wave_sum_u32(nlc);
+      if (lane == 0) {
+        s_ep[wave][0] = wc;
+        s_ep[wave][1] = rel;  // 0: this wave reports nothing
+        s_ep[wave][2] = WANT_LINES ? (wsum ^ kSumNl) : 0u;  // 0 = "a newline, no match"
+        s_ep[wave][3] = wn;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t tc = 0, tl = 0, marks = 0, tn = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; ++w) {
+          tc += s_ep[w][0];
+          tl = s_ep[w][1] > tl ? s_ep[w][1] : tl;
+          marks |= s_ep[w][1] ? 1u << w : 0u;
+          tn += s_ep[w][3];
+        }
+        if (marks) {
+          if (tc) A.tile_cnt[tile] = tc;
+          if (A.tile_wmask) reinterpret_cast<uint8_t*>(A.tile_wmask)[tile] = (uint8_t)marks;  // for the emit pass (the tile's byte of its word)
+          // end of the last match relative to the tile start (1 .. tile + plen < 2^16), tagged with this pass's epoch
+          A.tile_last[tile] = (A.epoch << 16) | tl;
+        }
+        if (WANT_LINES) {
+          const uint4 q = make_uint4(s_ep[0][2], s_ep[1][2], s_ep[2][2], s_ep[3][2]);
+          if (q.x | q.y | q.z | q.w) *reinterpret_cast<uint4*>(A.tile_sum + tile * kWaves) = q;
+        }
+        if (WANT_NL) A.tile_nl[tile] = tn;
+      }
+    } else {
+    if (wave_has) {
+      const uint32_t wc = wave_sum_u32(cnt);
+      // the end of the wave's last match, relative to the tile start: it fits 16 bits, so the reduction runs on
+      // 32-bit values (a 64-bit max costs three times the lane exchanges; a needle that is dense in the text pays
+      // this epilogue in every wave)
+      const uint32_t rel = wave_max_u32(st.last_rel);
       if (lane == 0) {
         // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
         // cut dense patterns to a third)
@@ -973,6 +1012,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
       if (lane == 0) s_nl[wave] = wn;
       __syncthreads();
       if (tid == 0) A.tile_nl[tile] = s_nl[0] + s_nl[1] + s_nl[2] + s_nl[3];
+    }
     }
   } else {
     // ---- ordered emission: wave spans are consecutive, loads within a span
