@@ -443,6 +443,14 @@ __device__ __forceinline__ void mask1_flags(const uint32_t (&d)[8], const Patter
       const uint32_t u = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1), d[q] ^ c0, c1, 0xde);
       z[q] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbyte(d[q + 1], d[q], 2), u, c2, 0xde);
     }
+  } else if (PL == 4) {
+    const uint32_t c3 = (P.p0 >> 24) * 0x01010101u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t u = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbyte(d[q + 1], d[q], 1), d[q] ^ c0, c1, 0xde);
+      u = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbyte(d[q + 1], d[q], 2), u, c2, 0xde);
+      z[q] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbyte(d[q + 1], d[q], 3), u, c3, 0xde);
+    }
   } else {
     const uint32_t c3 = (P.p0 >> 24) * 0x01010101u;
     uint32_t a1[5], a2[5], a3[5];
@@ -489,7 +497,7 @@ __device__ __forceinline__ void mask1_flags(const uint32_t (&d)[8], const Patter
 // follows the wave-load (lane 0's unit of the next load, or the bytes after the
 // span).  CAREFUL: the wave-load may reach past the end of the chunk.
 // Returns the lane's exact match-start bits (also accumulated into `st`).
-// PL: kMask1 only -- the pattern length where it is 1..3, 0 = read at run time (mask1_flags); j: the load's number in
+// PL: kMask1 only -- the pattern length where it is 1..4, 0 = read at run time (mask1_flags); j: the load's number in
 // the wave's span (a constant once the caller's loop is unrolled: it names the registers the load's flags stay in).
 template <int KIND, bool WANT_NL, bool WANT_LINES, bool EMIT, bool ICASE, bool CAREFUL, bool ALIGNED, int PL = 0>
 __device__ __forceinline__ uint32_t scan_load(const uint4 cur, const uint4 nx, bool nx_is_vgpr, uint64_t unit_off,
@@ -880,6 +888,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
       if (pl == 1) run_loads(careful_tag, std::integral_constant<int, 1>{});
       else if (pl == 2) run_loads(careful_tag, std::integral_constant<int, 2>{});
       else if (pl == 3) run_loads(careful_tag, std::integral_constant<int, 3>{});
+      else if (pl == 4) run_loads(careful_tag, std::integral_constant<int, 4>{});
       else run_loads(careful_tag, std::integral_constant<int, 0>{});
     } else {
       run_loads(careful_tag, std::integral_constant<int, 0>{});
