@@ -260,8 +260,15 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
             dist.barrier()
         size = os.path.getsize(path)
         want_total = int(sum(tcount[int(c)] for c in plan))
-        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
-        want_local = int(sum(tcount[int(c)] for c in plan[lo:hi]))
+        # The ranks share the file by ranges of the LIBRARY's chunk plan of it (16 MiB extended to just past the next
+        # newline: xsg_plan_chunks), which is not the list of template chunks the file was written from -- a template
+        # ends a few bytes behind the first newline past its 16 MiB, so the plan's cuts drift by tens of bytes.  What a
+        # rank must return is therefore the oracle's result on ITS chunks as the library cuts them: byte offsets global,
+        # line indices counted from the range's first line (xsg_file.cpp: publish).
+        chunk_bytes = args.chunk_mib << 20
+        fplan = xsg.plan_chunks(path, chunk_bytes)
+        nf = len(fplan)
+        lo, hi = (nf * rank) // world, (nf * (rank + 1)) // world
         # threads from the CPU time this process group may use (cgroup quota, else hardware threads), shared by the
         # ranks of the node: 4 device workers + 8 readers per GPU when there is room (one GPU in a 16-CPU cgroup), one
         # of each when 8 ranks share 16 CPUs
@@ -270,12 +277,13 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         nthreads = int(os.environ.get("XSG_E2E_WORKERS", str(max(1, min(4, budget // 3)))))
         nreaders = int(os.environ.get("XSG_E2E_READERS", str(max(1, min(8, budget - max(1, min(4, budget // 3)))))))
 
-        def run(mode, meta=None, data=None, nrd=None):
+        def run(mode, meta=None, data=None, nrd=None, rng=None):
+            rng = rng or (lo, hi)
             if dist is not None:
                 dist.barrier()
             t0 = time.perf_counter()
             j = xsg.Job(pattern, data or path, mode, meta_path=meta, device=dev_index, num_threads=nthreads,
-                        num_max_readers=nrd or nreaders, chunk_range=(lo, hi) if world > 1 else None)
+                        num_max_readers=nrd or nreaders, chunk_bytes=chunk_bytes, chunk_range=rng if world > 1 else None)
             r = j.result()
             dt = time.perf_counter() - t0
             st = j.stats()
@@ -284,21 +292,26 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
                 dt = _allreduce_max_host(dist, dt)
             return r, dt, st
 
-        # what every tag must return for this rank's chunk range, from the oracle's results on the template chunks
-        from xs_oracle import Oracle
-        orc = Oracle()
-        sizes = np.array([blocks[int(c)].size for c in plan], dtype=np.uint64)
-        goff = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
-        nl_t = np.array([orc.count_newlines(b) for b in blocks], dtype=np.uint64)
-        nl_before = np.concatenate([[0], np.cumsum(nl_t[plan])[:-1]]).astype(np.uint64)
-        m_t = [orc.byte_offsets_match(b, pattern) for b in blocks]
-        li_t = [orc.line_indices(b, pattern, 0) for b in blocks]
-        lines_t = [orc.lines(b, pattern) for b in blocks]
-        rng_ = range(lo, hi)
-        want_m = np.concatenate([m_t[int(plan[i])] + goff[i] for i in rng_]) if hi > lo else np.zeros(0, dtype=np.uint64)
-        # (a job over a chunk range numbers its lines from the range's first line: xsg_file.cpp, publish)
-        want_li = np.concatenate([li_t[int(plan[i])] + (nl_before[i] - nl_before[lo]) for i in rng_]) if hi > lo else np.zeros(0, dtype=np.uint64)
-        want_lines = [l for i in rng_ for l in lines_t[int(plan[i])]]
+        def oracle_on(file_path, table, lo_, hi_, lists=True):
+            """the oracle over chunks [lo_, hi_) of `table` (original_offset / original_size) of a plain-text file"""
+            from xs_oracle import Oracle
+            orc = Oracle()
+            mm = np.memmap(file_path, dtype=np.uint8, mode="r")
+            cnt, nl_run, ms, lis, lns = 0, 0, [], [], []
+            for i in range(lo_, hi_):
+                o, ln = int(table[i]["original_offset"]), int(table[i]["original_size"])
+                b = np.array(mm[o:o + ln])
+                cnt += orc.count(b, pattern, False)
+                if lists:
+                    ms.append(orc.byte_offsets_match(b, pattern).astype(np.uint64) + np.uint64(o))
+                    lis.append(orc.line_indices(b, pattern, nl_run).astype(np.uint64))
+                    lns += orc.lines(b, pattern)
+                    nl_run += orc.count_newlines(b)
+            del mm
+            cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, dtype=np.uint64)
+            return cnt, cat(ms), cat(lis), lns
+
+        want_local, want_m, want_li, want_lines = oracle_on(path, fplan, lo, hi)
 
         run(xsg.COUNT_MATCHES)  # warm: thread/buffer pools, page cache
         r, dt, st = run(xsg.COUNT_MATCHES)
@@ -333,11 +346,14 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         if dist is not None:
             dist.barrier()
         nsmall = min(max(world, n // 4), 128)
-        lo, hi = (nsmall * rank) // world, (nsmall * (rank + 1)) // world
-        want_l = int(sum(tcount[int(c)] for c in plan[lo:hi]))
+        small = path + ".part"  # (rank 0 unlinks it at the end; every rank reads its own chunks of it for the oracle)
+        _, mchunks = xsg.meta_read(mp)  # the ranges of THIS leg are ranges of the metafile's chunk table
+        nm = len(mchunks)
+        llo, lhi = (nm * rank) // world, (nm * (rank + 1)) // world
+        want_l = oracle_on(small, mchunks, llo, lhi, lists=False)[0]
         ndecoders = int(os.environ.get("XSG_E2E_DECODERS", str(max(1, min(12, budget - nthreads)))))
-        run(xsg.COUNT_MATCHES, mp, dp, ndecoders)
-        r, dt, st = run(xsg.COUNT_MATCHES, mp, dp, ndecoders)
+        run(xsg.COUNT_MATCHES, mp, dp, ndecoders, (llo, lhi))
+        r, dt, st = run(xsg.COUNT_MATCHES, mp, dp, ndecoders, (llo, lhi))
         if r != want_l:
             raise SystemExit(f"e2e PARITY FAILURE (lz4): count {r} != {want_l}")
         small_bytes = int(sum(blocks[int(c)].size for c in plan[:nsmall]))

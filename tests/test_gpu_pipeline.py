@@ -462,3 +462,23 @@ def test_extern_search_fans_out_over_devices(files, how):
     assert r.returncode == 1 and b"XS_DEVICES" in r.stderr
     r = run_cli("count", "join", "Sherlock", files["txt"], env={"XS_DEVICES": "0,99"})
     assert r.returncode == 1 and b"device" in r.stderr
+
+
+@pytest.mark.parametrize("threads,readers", [(1, 1), (2, 6), (4, 8)])
+@pytest.mark.parametrize("tag", list(TAGS))
+def test_job_over_a_chunk_range(files, oracle, tag, threads, readers):
+    """One rank's share of a file (xsg_job_opts.chunk_begin/_end; bench.py --gpus N, xs::extern_search with XS_DEVICES):
+    byte offsets stay global, line indices count from the range's first line."""
+    data = np.fromfile(files["txt"], dtype=np.uint8)
+    plan = xsg.plan_chunks(files["txt"], CHUNK)
+    chunks = [data[int(c["original_offset"]):int(c["original_offset"] + c["original_size"])] for c in plan]
+    n = len(chunks)
+    goff = [int(c["original_offset"]) for c in plan]
+    for lo, hi in ((0, n), (1, n), (n // 2, n), (2, 4), (n - 1, n)):
+        for pat in (b"Sherlock", b"She"):
+            want = oracle_all_modes(oracle, chunks[lo:hi], pat, global_offsets=goff[lo:hi])
+            j = xsg.Job(pat, files["txt"], TAGS[tag], num_threads=threads, num_max_readers=readers, chunk_bytes=CHUNK,
+                        chunk_range=(lo, hi))
+            got = as_py(tag, j.result())
+            j.close()
+            assert got == want[KEY[tag]], (tag, pat, lo, hi, threads, readers)
