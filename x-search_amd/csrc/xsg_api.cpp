@@ -1524,24 +1524,45 @@ extern "C" int xsg_shard_tune(xsg_shard* s, uint32_t mode, uint32_t* chosen) {
   s->hot_serial = 0;
   XSG_TRY(choose_hot_filter(s, c->stream, tune_nl, tune_lines));
   if (nhot == 2) best_hot = s->hot_v[v];
-  for (uint32_t hot = 0; hot < nhot; ++hot) {
-    if (nhot == 2) {
-      s->hot_v[v] = (uint8_t)hot;
-      s->hot_known |= (uint8_t)(1u << v);
-    }
-    for (uint32_t t : cand) {
-      s->tune = t;
-      float ms = 0;
-      const int r = xsg_time_scan_kernel(s, mode, 3, &ms);
-      if (r != XSG_OK) {
-        s->tune = kTuneAuto;
-        s->hot_serial = 0;
-        s->koff_chosen = false;
-        return r;
+  auto give_up = [&](int r) {
+    s->tune = kTuneAuto;
+    s->hot_serial = 0;
+    s->koff_chosen = false;
+    return r;
+  };
+  // The clocks first: an idle card ramps for several ms and the candidates measured first (the window filter, the small
+  // staggers) would be read 3-7 % low -- one bench run in three came back with the slower filter.  ~150 ms of untimed
+  // launches, then TWO sweeps and every candidate's better time (profiles/r04_dense_variants.txt).
+  {
+    float ms = 0;
+    s->tune = kDefaultStagger;
+    int r = xsg_time_scan_kernel(s, mode, 3, &ms);
+    if (r != XSG_OK) return give_up(r);
+    const int more = (int)std::min(40.0f, std::max(0.0f, 150.0f / std::max(ms, 0.05f) - 3.0f));
+    if (more > 0 && (r = xsg_time_scan_kernel(s, mode, more, &ms)) != XSG_OK) return give_up(r);
+  }
+  constexpr int kCand = (int)(sizeof cand / sizeof cand[0]);
+  float t_ms[2][kCand];
+  for (auto& row : t_ms)
+    for (float& x : row) x = 1e30f;
+  for (int round = 0; round < 2; ++round) {
+    for (uint32_t hot = 0; hot < nhot; ++hot) {
+      if (nhot == 2) {
+        s->hot_v[v] = (uint8_t)hot;
+        s->hot_known |= (uint8_t)(1u << v);
       }
-      if (best == kTuneAuto || ms < best_ms) best_ms = ms, best = t, best_hot = hot;
+      for (int k = 0; k < kCand; ++k) {
+        s->tune = cand[k];
+        float ms = 0;
+        const int r = xsg_time_scan_kernel(s, mode, 3, &ms);
+        if (r != XSG_OK) return give_up(r);
+        t_ms[hot][k] = std::min(t_ms[hot][k], ms);
+      }
     }
   }
+  for (uint32_t hot = 0; hot < nhot; ++hot)
+    for (int k = 0; k < kCand; ++k)
+      if (best == kTuneAuto || t_ms[hot][k] < best_ms) best_ms = t_ms[hot][k], best = cand[k], best_hot = hot;
   s->tune = best;
   s->tune_serial = c->pattern_serial;
   s->tune_probe = false;
