@@ -114,3 +114,32 @@ def test_a_binding_remembers_that_a_pattern_overflowed(oracle):
     got = gs.all_modes(b"the")
     for k in LIST_KEYS:
         assert got[k] == want[k], k
+
+
+def test_xs_lines_of_a_result_of_hundreds_of_thousands_of_lines(oracle):
+    """xs::lines on the exact route with a result large enough for the output-centric gather (k_line_gather_span, from 65 536
+    lines): short lines, empty lines, lines of several KB, an unterminated last line (dropped: search_wrappers.h:199-202),
+    chunk sizes that leave partial 16-byte units at every slice and workgroup boundary."""
+    rng = np.random.default_rng(20260404)
+    words = [b"e", b"be", b"tree", b"x", b"", b"zz", b"seven eleven", b"q", b"the end", b"yyyy"]
+    blocks = []
+    for c in range(3):
+        parts = []
+        for i in range(120_000 + 777 * c):
+            k = int(rng.integers(0, 40))
+            if k == 0:
+                parts.append(b"e" * int(rng.integers(300, 9000)))  # a long line
+            elif k < 8:
+                parts.append(b"")  # an empty line
+            else:
+                parts.append(b" ".join(words[int(j)] for j in rng.integers(0, len(words), size=int(rng.integers(1, 6)))))
+        text = b"\n".join(parts) + (b"\n" if c != 2 else b" e unterminated")
+        blocks.append(np.frombuffer(text, dtype=np.uint8).copy())
+    gs = GpuSearch()
+    gs.bind(blocks)
+    for pat in (b"e", b"ee", b"seven"):
+        want = oracle_all_modes(oracle, blocks, pat)
+        got = gs.all_modes(pat)
+        assert len(want["lines"]) > (65536 if pat == b"e" else 0)
+        for k in want:
+            assert got[k] == want[k], (pat, k)

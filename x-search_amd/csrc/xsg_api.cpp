@@ -2196,21 +2196,17 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
     XSG_TRY(s->d_dropped.ensure(16));
     o.dropped = s->d_dropped.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(o.dropped, 0, 4, st));
-    HIP_TRY(launch_line_lengths(o, st));
-    HIP_TRY(launch_exclusive_scan_u64(o.line_len, s->d_line_off.as<uint64_t>(), total, s->d_scan_tmp.as<uint64_t>(), st));
-    // The result leaves for the shard's pinned mirrors while it is still being produced (what xsg_result_lines_view hands
-    // out; xsg_result_lines copies from there): lengths and offsets go on a second stream as soon as k_line_lengths has
-    // written them, the packed bytes slice by slice behind the gather of each slice.  A needle in most lines of 10 GiB
-    // returns 3 GB -- round 3 moved them in three copies one after the other behind the whole gather, and only when a
-    // result accessor asked: 94 ms a search where the link alone needs 55.
-    constexpr uint64_t kSlices = 8;
-    const bool eager = 16 * total < (16ull << 30);  // (beyond 16 GiB of pinned memory: the accessors copy on demand)
+    // The result leaves for the shard's pinned mirrors AS IT IS PRODUCED (what xsg_result_lines_view hands out;
+    // xsg_result_lines copies from there): k_line_lengths stores lengths and global offsets there as well as on the device,
+    // and the gather writes the packed bytes straight into pinned memory -- the kernels are the copies.  A needle in most
+    // lines of 10 GiB returns 3 GB over a link that moves 57 GB/s: round 3 moved them in three copies one after the other
+    // behind the whole gather (94 ms a search); copies on side streams behind each slice of the gather came to 85 ms, because
+    // a kernel that runs beside a device-to-host copy crawls (the copy is a blit kernel whose waves wait for the link and
+    // hold the compute units: each 250 MB slice of the gather took 7 ms beside one, the first one 19 ms:
+    // profiles/r04_dense_timeline.txt).  Now the link is busy from the moment the list is assembled until the last byte.
+    bool eager = 16 * total < (16ull << 30);  // (beyond 16 GiB of pinned memory: the accessors copy on demand)
+    if (const char* e = XSG_TOGGLE("XSG_LINES_EAGER")) eager = *e != '0';  // tests: the on-demand path on small results
     if (eager) {
-      if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-      if (!s->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream2, hipStreamNonBlocking));
-      for (hipEvent_t& e : s->copy_ev)
-        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      if (!s->h_bounds) HIP_TRY(hipHostMalloc((void**)&s->h_bounds, 8 * (kSlices + 1), hipHostMallocDefault));
       trim_pinned(s, 8 * (size_t)total, 8 * (size_t)total, SIZE_MAX);  // (what a far larger earlier result left page-locked)
       XSG_TRY(ensure_pinned(&s->hp_line_len, &s->hp_line_len_cap, (size_t)total));
       {
@@ -2221,55 +2217,38 @@ static int run_list(xsg_shard* s, uint32_t mode, bool outputs) {
         s->h_result_cap = have * 8;
         XSG_TRY(pr);
       }
-      HIP_TRY(hipEventRecord(s->copy_ev[0], st));  // lengths and offsets are written
-      HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_ev[0], 0));
-      HIP_TRY(hipStreamWaitEvent(s->copy_stream2, s->copy_ev[0], 0));
-      if (total) {  // the two arrays side by side on the two copy streams
-        HIP_TRY(hipMemcpyAsync(s->hp_line_len, s->d_line_len.p, 8 * total, hipMemcpyDeviceToHost, s->copy_stream));
-        HIP_TRY(hipMemcpyAsync(s->h_result, s->d_out_u64.p, 8 * total, hipMemcpyDeviceToHost, s->copy_stream2));
-      }
+      o.line_len_host = s->hp_line_len;
+      o.out_host = static_cast<uint64_t*>(s->h_result);
     }
-    const uint64_t nsl = (eager && total >= (1u << 20)) ? kSlices : 1;  // a small result is one slice
+    HIP_TRY(launch_line_lengths(o, st));
+    HIP_TRY(launch_exclusive_scan_u64(o.line_len, s->d_line_off.as<uint64_t>(), total, s->d_scan_tmp.as<uint64_t>(), st));
     uint64_t nbytes = 0;
     HIP_TRY(hipMemcpyAsync(&s->h_dropped, o.dropped, 4, hipMemcpyDeviceToHost, st));  // (rides on the sync below)
-    if (eager)
-      for (uint64_t k = 0; k < nsl; ++k)  // where every slice's bytes begin (the last entry: their total, fetched below)
-        HIP_TRY(hipMemcpyAsync(s->h_bounds + k, s->d_line_off.as<uint64_t>() + k * total / nsl, 8, hipMemcpyDeviceToHost, st));
     XSG_TRY(d2h_u64(c, s->d_line_off.as<uint64_t>() + total, &nbytes));
-    XSG_TRY(s->d_line_bytes.ensure(std::max<uint64_t>(nbytes, 1)));
     o.line_out_off = s->d_line_off.as<uint64_t>();
-    o.line_bytes = s->d_line_bytes.as<uint8_t>();
     if (!eager) {
+      XSG_TRY(s->d_line_bytes.ensure(std::max<uint64_t>(nbytes, 1)));
+      o.line_bytes = s->d_line_bytes.as<uint8_t>();
       HIP_TRY(launch_line_gather(o, st));
-    } else {
-      trim_pinned(s, SIZE_MAX, SIZE_MAX, (size_t)nbytes);
-      XSG_TRY(ensure_pinned(&s->hp_line_bytes, &s->hp_line_bytes_cap, (size_t)nbytes));
-      s->h_bounds[nsl] = nbytes;
-      for (uint64_t k = 0; k < nsl; ++k) {
-        o.slice_begin = k * total / nsl;
-        o.slice_end = (k + 1) * total / nsl;
-        if (o.slice_end == o.slice_begin) continue;
-        HIP_TRY(launch_line_gather(o, st));
-        hipEvent_t ev = s->copy_ev[k & 1];  // (a wait refers to the record that precedes it: recording the event again later is fine)
-        HIP_TRY(hipEventRecord(ev, st));
-        hipStream_t cs = (k & 1) ? s->copy_stream2 : s->copy_stream;
-        HIP_TRY(hipStreamWaitEvent(cs, ev, 0));
-        const uint64_t b0 = s->h_bounds[k], b1 = s->h_bounds[k + 1];
-        if (b1 > b0) HIP_TRY(hipMemcpyAsync(s->hp_line_bytes + b0, s->d_line_bytes.as<uint8_t>() + b0, b1 - b0, hipMemcpyDeviceToHost, cs));
-      }
-      o.slice_begin = o.slice_end = 0;
-    }
-    s->line_bytes = nbytes;
-    s->fast_raw_lines = total;
-    if (eager) {
-      HIP_TRY(hipStreamSynchronize(s->copy_stream));
-      HIP_TRY(hipStreamSynchronize(s->copy_stream2));
-      s->fast_result = true;  // the result lives in the pinned mirrors: the accessors read it there
-    } else {
       // the lengths stay on the device until a result accessor asks (fetch_line_lengths): how many lines lack their
       // newline -- all the search itself needs to know -- was counted by the kernel
       s->line_len_on_device = true;
+    } else {
+      trim_pinned(s, SIZE_MAX, SIZE_MAX, (size_t)nbytes + 16);
+      XSG_TRY(ensure_pinned(&s->hp_line_bytes, &s->hp_line_bytes_cap, (size_t)nbytes + 16));  // (+16: k_line_gather_edges writes whole units)
+      {
+        const uint64_t nbnd = total / kBlock + 2;
+        XSG_TRY(s->d_scan_tmp.ensure(16 * nbnd));  // (the scan is done with it)
+        HIP_TRY(hipMemsetAsync(s->d_scan_tmp.p, 0, 16 * nbnd, st));
+        o.edge_units = s->d_scan_tmp.as<uint32_t>();
+      }
+      o.line_bytes = nullptr;  // no device copy of the packed bytes: nothing reads one when the mirrors hold the result
+      o.line_bytes_host = s->hp_line_bytes;
+      HIP_TRY(launch_line_gather(o, st));
+      s->fast_result = true;  // the result lives in the pinned mirrors: the accessors read it there
     }
+    s->line_bytes = nbytes;
+    s->fast_raw_lines = total;
   }
   HIP_TRY(hipStreamSynchronize(st));
   if (mode == XSG_LINE_INDICES) s->nl_total = s->last_newlines;

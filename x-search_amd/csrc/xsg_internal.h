@@ -330,6 +330,7 @@ struct LineOutArgs {
   uint64_t line_bytes_cap;   // bytes line_bytes (and its mirror) can hold
   uint32_t* dropped;         // k_line_lengths: incremented per line without a terminating newline (may be null)
   uint64_t slice_begin, slice_end;  // k_line_gather: only the entries [slice_begin, slice_end) (slice_end == 0: all of them)
+  uint32_t* edge_units;      // k_line_gather_span into a pinned mirror: 4 zeroed words per workgroup boundary (total / kBlock + 2), or null
 };
 hipError_t launch_globalize(const LineOutArgs& a, hipStream_t s);
 hipError_t launch_line_nl_delta(const LineOutArgs& a, hipStream_t s);

@@ -969,8 +969,8 @@ __global__ __launch_bounds__(kBlock) void k_line_lengths(const LineOutArgs A) {
     const uint64_t g = ch.global_offset + A.f_pos[i];
     A.line_len[i] = len;
     A.out_u64[i] = g;
-    if (A.line_len_host) A.line_len_host[i] = len;
-    if (A.out_host) A.out_host[i] = g;
+    if (A.line_len_host) __builtin_nontemporal_store(len, A.line_len_host + i);
+    if (A.out_host) __builtin_nontemporal_store(g, A.out_host + i);
     if (e < 0 && A.dropped) atomicAdd(A.dropped, 1u);  // (at most one per chunk: its last line)
   }
 }
@@ -1059,10 +1059,128 @@ hipError_t launch_line_index_waves(const LineOutArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_line_index_waves, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
+// The same gather, OUTPUT-centric, for results of millions of lines (the exact route): a thread per line writes 16 bytes at
+// whatever alignment its line starts at, then up to 15 single bytes -- 66 M lines of ~30 bytes (3 GB of `She` lines on
+// 10 GiB) left at 35 GB/s, 58 ms of a 93 ms search (profiles/r04_dense_timeline.txt).  Here a workgroup takes kBlock
+// consecutive lines = one contiguous span of the packed output, parks their output offsets and source addresses in LDS,
+// and every thread fills ALIGNED 16-byte units of that span: which line a unit starts in by a binary search in LDS, its
+// bytes picked one by one across the line boundaries inside it (source lines are contiguous text: the byte loads hit
+// lines the neighbouring lanes just touched), one 16-byte store.  The span's first and last unit are shared with the
+// neighbouring workgroups and written byte by byte.
+__global__ __launch_bounds__(kBlock) void k_line_gather_span(const LineOutArgs A) {
+  __shared__ uint64_t s_off[kBlock + 1];
+  __shared__ const uint8_t* s_src[kBlock];
+  const uint64_t total = out_count(A);
+  if (A.line_bytes_cap && A.line_out_off[total] > A.line_bytes_cap) return;
+  uint8_t* const mirror = A.line_bytes_host;
+  const uint64_t first = A.slice_end ? A.slice_begin : 0, stop = A.slice_end ? (A.slice_end < total ? A.slice_end : total) : total;
+  for (uint64_t w0 = first + (uint64_t)blockIdx.x * kBlock; w0 < stop; w0 += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t n = (uint32_t)(stop - w0 < (uint64_t)kBlock ? stop - w0 : (uint64_t)kBlock);
+    __syncthreads();  // (the previous round's readers are done with the arrays)
+    if (threadIdx.x < n) {
+      const uint64_t i = w0 + threadIdx.x;
+      s_off[threadIdx.x] = A.line_out_off[i];
+      s_src[threadIdx.x] = A.base + A.chunks[A.f_chunk[i]].offset + A.f_pos[i];
+    }
+    if (threadIdx.x == 0) s_off[n] = A.line_out_off[w0 + n];
+    __syncthreads();
+    const uint64_t B = s_off[0], E = s_off[n];  // a dropped line (no terminating newline) has length 0 here: scan_val
+    for (uint64_t U = (B & ~(uint64_t)15) + 16u * threadIdx.x; U < E; U += 16u * kBlock) {
+      const uint64_t lo = U > B ? U : B, hi = U + 16u < E ? U + 16u : E;
+      // the line that holds output byte lo: the last l with s_off[l] <= lo (lo < E = s_off[n], so l < n and s_off[l + 1] > lo)
+      uint32_t a = 0, b = n;  // invariant: s_off[a] <= lo < s_off[b]
+      while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (s_off[m] <= lo) a = m; else b = m;
+      }
+      uint32_t l = a;
+      uint64_t beg = s_off[l], end = s_off[l + 1];
+      const uint8_t* src = s_src[l];
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      for (uint64_t o = lo; o < hi; ++o) {
+        while (o >= end) {  // (zero-length lines in between are stepped over)
+          ++l;
+          beg = end;
+          end = s_off[l + 1];
+          src = s_src[l];
+        }
+        const uint32_t k = (uint32_t)(o - U);
+        w[k >> 2] |= (uint32_t)src[o - beg] << (8u * (k & 3u));
+      }
+      if (hi - lo == 16u) {
+        const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+        if (A.line_bytes) *reinterpret_cast<uint4*>(A.line_bytes + U) = v;
+        if (mirror) {  // (streaming store: the unit is never read back on the device)
+          typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+          u32x4_t nv = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t*>(mirror + U));
+        }
+      } else {
+        for (uint64_t o = lo; o < hi && A.line_bytes; ++o) {
+          const uint32_t k = (uint32_t)(o - U);
+          A.line_bytes[o] = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
+        }
+        if (mirror) {
+          // a unit shared with the neighbouring workgroup: single bytes over the link are single transactions (two such
+          // units x ~8 bytes x 258 000 workgroups held the gather of 2 GB at 36 GB/s where the link moves 57).  The
+          // bytes meet in a device array, one entry per BOUNDARY between workgroups (head -> this one's, tail -> the next
+          // one's); k_line_gather_edges writes every such unit once, as 16 bytes.
+          const uint64_t bnd = (w0 - first) / kBlock + (lo > U ? 0u : 1u);
+          if (A.edge_units) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (w[q]) atomicOr(A.edge_units + 4 * bnd + q, w[q]);
+          } else {
+            for (uint64_t o = lo; o < hi; ++o) {
+              const uint32_t k = (uint32_t)(o - U);
+              mirror[o] = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// the units k_line_gather_span's workgroups share: boundary b lies at output byte B_b = line_out_off[first + b * kBlock];
+// consecutive boundaries inside one 16-byte unit (workgroups whose whole span is a few bytes) are merged by the first
+__global__ __launch_bounds__(kBlock) void k_line_gather_edges(const LineOutArgs A, const uint64_t nbnd) {
+  const uint64_t total = out_count(A);
+  const uint64_t first = 0, stop = total;
+  const uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b > nbnd) return;
+  auto at = [&](uint64_t k) { const uint64_t i = first + k * kBlock; return A.line_out_off[i < stop ? i : stop]; };
+  const uint64_t Bb = at(b);
+  if ((Bb & 15u) == 0) return;  // the boundary falls between two units: nobody shares one
+  const uint64_t U = Bb & ~(uint64_t)15;
+  if (b > 0) {
+    const uint64_t Bp = at(b - 1);
+    if ((Bp & 15u) != 0 && (Bp & ~(uint64_t)15) == U) return;  // an earlier boundary of the same unit writes it
+  }
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = A.edge_units[4 * b + q];
+  for (uint64_t k = b + 1; k <= nbnd; ++k) {
+    const uint64_t Bk = at(k);
+    if ((Bk & 15u) == 0 || (Bk & ~(uint64_t)15) != U) break;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] |= A.edge_units[4 * k + q];
+  }
+  *reinterpret_cast<uint4*>(A.line_bytes_host + U) = make_uint4(w[0], w[1], w[2], w[3]);  // (the mirror holds 16 bytes beyond the result)
+}
+
 hipError_t launch_line_gather(const LineOutArgs& a, hipStream_t s) {
   if (!a.total) return hipSuccess;
   const uint64_t n = a.slice_end ? a.slice_end - a.slice_begin : a.total;
   if (!n) return hipSuccess;
+  if (!a.tot_dev && (n >= (1u << 16) || !a.line_bytes)) {  // the exact route with a result worth the set-up (or only a pinned destination)
+    const uint64_t nwg = (n + kBlock - 1) / kBlock;
+    const uint64_t blocks = std::min<uint64_t>(nwg, 1u << 20);
+    hipLaunchKernelGGL(k_line_gather_span, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+    if (a.edge_units && a.line_bytes_host && !a.slice_end)  // (edge_units: 16 zeroed bytes per boundary, nwg + 1 of them)
+      hipLaunchKernelGGL(k_line_gather_edges, dim3((unsigned)((nwg + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, nwg);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_line_gather, a.tot_dev ? grid_capped(n) : grid_for(n), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }

@@ -204,11 +204,6 @@ struct xsg_shard {
   DevBuf d_scan2;                  // scratch of the two-launch scans
   DevBuf d_wmask;                  // ScanArgs::tile_wmask
   uint64_t* h_tot = nullptr;       // pinned mirror of the FastTot words (+ one word for the scan flags)
-  uint64_t* h_bounds = nullptr;    // pinned: byte offsets of the slices a dense xs::lines result is gathered and copied in
-  // a second stream and two events, made on first use: an xs::lines result of the exact route leaves the device in slices
-  // while the next slice is still being gathered (xsg_api.cpp: run_list)
-  hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;  // (two: two DMA engines share the link)
-  hipEvent_t copy_ev[2] = {nullptr, nullptr};
   uint64_t* hp_line_len = nullptr; // pinned: xs::lines lengths (UINT64_MAX = dropped)
   size_t hp_line_len_cap = 0;      // entries
   uint8_t* hp_line_bytes = nullptr;
@@ -242,19 +237,6 @@ struct xsg_shard {
     h_result = nullptr;
     h_result_cap = 0;
     if (h_tot) (void)hipHostFree(h_tot);
-    if (h_bounds) (void)hipHostFree(h_bounds);
-    h_bounds = nullptr;
-    for (hipStream_t* cs : {&copy_stream, &copy_stream2}) {
-      if (*cs) {
-        (void)hipStreamSynchronize(*cs);
-        (void)hipStreamDestroy(*cs);
-        *cs = nullptr;
-      }
-    }
-    for (hipEvent_t& e : copy_ev) {
-      if (e) (void)hipEventDestroy(e);
-      e = nullptr;
-    }
     if (hp_line_len) (void)hipHostFree(hp_line_len);
     if (hp_line_bytes) (void)hipHostFree(hp_line_bytes);
     h_tot = nullptr;
