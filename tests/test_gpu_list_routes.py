@@ -116,8 +116,10 @@ def test_a_binding_remembers_that_a_pattern_overflowed(oracle):
         assert got[k] == want[k], k
 
 
-def test_xs_lines_of_a_result_of_hundreds_of_thousands_of_lines(oracle):
-    """xs::lines on the exact route with a result large enough for the output-centric gather (k_line_gather_span, from 65 536
+@pytest.mark.parametrize("env", [{}, {"XSG_LINES_EAGER": 0}], ids=["pinned-mirrors", "on-demand"])
+def test_xs_lines_of_a_result_of_hundreds_of_thousands_of_lines(oracle, env):
+    """(both ways a large result leaves: written into the pinned mirrors by the kernels, or gathered on the device and copied
+    when an accessor asks)  xs::lines on the exact route with a result large enough for the output-centric gather (k_line_gather_span, from 65 536
     lines): short lines, empty lines, lines of several KB, an unterminated last line (dropped: search_wrappers.h:199-202),
     chunk sizes that leave partial 16-byte units at every slice and workgroup boundary."""
     rng = np.random.default_rng(20260404)
@@ -139,7 +141,8 @@ def test_xs_lines_of_a_result_of_hundreds_of_thousands_of_lines(oracle):
     gs.bind(blocks)
     for pat in (b"e", b"ee", b"seven"):
         want = oracle_all_modes(oracle, blocks, pat)
-        got = gs.all_modes(pat)
+        with route(**env):
+            got = gs.all_modes(pat)
         assert len(want["lines"]) > (65536 if pat == b"e" else 0)
         for k in want:
             assert got[k] == want[k], (pat, k)
