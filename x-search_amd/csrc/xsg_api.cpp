@@ -1129,17 +1129,24 @@ static int ensure_overlap_check(xsg_shard* s) {
   s->overlap_free = false;
   if (!c->bordered || c->overlap_words.empty() || s->ntiles == 0) return XSG_OK;
   hipStream_t st = c->stream;
-  for (const std::vector<uint8_t>& w : c->overlap_words) {
-    std::vector<uint8_t> padded(std::max<size_t>(w.size(), 1024) + 16, 0);
-    XSG_TRY(c->d_aux_pat.ensure(padded.size()));
-    memcpy(padded.data(), w.data(), w.size());
-    HIP_TRY(hipMemcpyAsync(c->d_aux_pat.p, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));  // (`padded` leaves scope)
+  // the words go to the device once per PATTERN (every binding of the file pipeline asks again), side by side
+  size_t stride = 0;
+  for (const std::vector<uint8_t>& w : c->overlap_words) stride = std::max(stride, (std::max<size_t>(w.size(), 1024) + 16 + 255) & ~(size_t)255);
+  if (c->aux_serial != c->pattern_serial) {
+    std::vector<uint8_t> all(stride * c->overlap_words.size(), 0);
+    for (size_t k = 0; k < c->overlap_words.size(); ++k) memcpy(all.data() + k * stride, c->overlap_words[k].data(), c->overlap_words[k].size());
+    XSG_TRY(c->d_aux_pat.ensure(all.size()));
+    HIP_TRY(hipMemcpyAsync(c->d_aux_pat.p, all.data(), all.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (`all` leaves scope)
+    c->aux_serial = c->pattern_serial;
+  }
+  for (size_t k = 0; k < c->overlap_words.size(); ++k) {
+    const std::vector<uint8_t>& w = c->overlap_words[k];
     PatternDev P{};
     P.plen = (uint32_t)w.size();
     window_fields(w.data(), w.size(), pick_filter_window(w.data(), w.size()), &P);
     P.kind = w.size() < 4 ? kMask1 : w.size() == 4 ? kOne : w.size() < 8 ? kMask2 : w.size() == 8 ? kTwo : kLong;
-    P.d_pat = c->d_aux_pat.as<uint8_t>();
+    P.d_pat = c->d_aux_pat.as<uint8_t>() + k * stride;
     P.exact_tail = 1u;
     P.has_newline = c->pat.has_newline;
     P.icase = c->pat.icase;

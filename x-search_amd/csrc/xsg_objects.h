@@ -95,7 +95,8 @@ struct xsg_ctx {
   // plen - b apart.  No such word in the data <=> no two occurrences overlap <=> the greedy walk keeps every occurrence
   // (xsg_api.cpp: ensure_overlap_check).  Empty: not checkable (a regex, more than three borders, words too long).
   std::vector<std::vector<uint8_t>> overlap_words;
-  DevBuf d_aux_pat;  // device copy of the word being looked for
+  DevBuf d_aux_pat;  // device copies of the overlap words of the pattern (ensure_overlap_check), side by side
+  uint64_t aux_serial = 0;  // ... of which pattern_serial
   xsg::PatternDev pat{};
   DevBuf d_pat;
   // kDfa with a selective start (xsg_regex.h: RegexDfa::prefix): the class-sequence pattern that finds the candidates
