@@ -997,31 +997,31 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& A, const uint64_t tile
         if (WANT_NL) A.tile_nl[tile] = tn;
       }
     } else {
-    if (wave_has) {
-      const uint32_t wc = wave_sum_u32(cnt);
-      // the end of the wave's last match, relative to the tile start: it fits 16 bits, so the reduction runs on
-      // 32-bit values (a 64-bit max costs three times the lane exchanges; a needle that is dense in the text pays
-      // this epilogue in every wave)
-      const uint32_t rel = wave_max_u32(st.last_rel);
-      if (lane == 0) {
-        // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
-        // cut dense patterns to a third)
-        atomicAdd(A.tile_cnt + tile, wc);
-        if (A.tile_wmask) atomicOr(A.tile_wmask + (tile >> 2), 1u << (((uint32_t)tile & 3u) * 8u + wave));  // for the emit pass
-        // end of the last match relative to the tile start (1 .. tile + plen < 2^16), tagged with this pass's
-        // epoch: a word of an older pass loses the max, so the array is never reset
-        atomicMax(A.tile_last + tile, (A.epoch << 16) | rel);
+      if (wave_has) {
+        const uint32_t wc = wave_sum_u32(cnt);
+        // the end of the wave's last match, relative to the tile start: it fits 16 bits, so the reduction runs on
+        // 32-bit values (a 64-bit max costs three times the lane exchanges; a needle that is dense in the text pays
+        // this epilogue in every wave)
+        const uint32_t rel = wave_max_u32(st.last_rel);
+        if (lane == 0) {
+          // per-TILE words: 4-way contention at most (a per-chunk max was 4000-way and
+          // cut dense patterns to a third)
+          atomicAdd(A.tile_cnt + tile, wc);
+          if (A.tile_wmask) atomicOr(A.tile_wmask + (tile >> 2), 1u << (((uint32_t)tile & 3u) * 8u + wave));  // for the emit pass
+          // end of the last match relative to the tile start (1 .. tile + plen < 2^16), tagged with this pass's
+          // epoch: a word of an older pass loses the max, so the array is never reset
+          atomicMax(A.tile_last + tile, (A.epoch << 16) | rel);
+        }
       }
-    }
-    if (WANT_LINES) {
-      if (lane == 0 && wsum != kSumNl) A.tile_sum[tile * kWaves + wave] = wsum ^ kSumNl;  // 0 = "a newline, no match"
-    }
-    if (WANT_NL) {  // every wave has newlines to report: one store per tile through LDS
-      const uint32_t wn = wave_sum_u32(nlc);
-      if (lane == 0) s_nl[wave] = wn;
-      __syncthreads();
-      if (tid == 0) A.tile_nl[tile] = s_nl[0] + s_nl[1] + s_nl[2] + s_nl[3];
-    }
+      if (WANT_LINES) {
+        if (lane == 0 && wsum != kSumNl) A.tile_sum[tile * kWaves + wave] = wsum ^ kSumNl;  // 0 = "a newline, no match"
+      }
+      if (WANT_NL) {  // every wave has newlines to report: one store per tile through LDS
+        const uint32_t wn = wave_sum_u32(nlc);
+        if (lane == 0) s_nl[wave] = wn;
+        __syncthreads();
+        if (tid == 0) A.tile_nl[tile] = s_nl[0] + s_nl[1] + s_nl[2] + s_nl[3];
+      }
     }
   } else {
     // ---- ordered emission: wave spans are consecutive, loads within a span
