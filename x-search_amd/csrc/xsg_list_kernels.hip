@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(kBlock) void k_line_gather_span(const LineOutArgs A
           // bytes meet in a device array, one entry per BOUNDARY between workgroups (head -> this one's, tail -> the next
           // one's); k_line_gather_edges writes every such unit once, as 16 bytes.
           const uint64_t bnd = (w0 - first) / kBlock + (lo > U ? 0u : 1u);
-          if (A.edge_units) {
+          if (A.edge_units && !A.slice_end) {  // (k_line_gather_edges covers whole results only)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               if (w[q]) atomicOr(A.edge_units + 4 * bnd + q, w[q]);
