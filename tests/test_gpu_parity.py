@@ -626,3 +626,38 @@ def test_async_count_with_a_status_word(gs, oracle):
     st.synchronize()
     got = buf.cpu().numpy().astype(np.uint64)
     assert int(got[xsg.NUM_COUNTERS]) == xsg.STATUS_NONASCII and not got[:xsg.NUM_COUNTERS].any()
+
+
+def test_first_search_of_a_fresh_binding_with_a_long_pattern(oracle, monkeypatch):
+    """A long pattern settles its filter window in the probe of its FIRST pass on a binding, on the newline-counting
+    instantiation -- whose per-tile array a plain count never asked for (round 4: a null store, found by
+    scripts/first_call.py on a 50 GiB shard; gpu_util's all_modes begins with a count that wants newlines and hid it).
+    Fresh context and binding per tag, the probe forced on a small shard."""
+    from gpu_util import upload
+    monkeypatch.setenv("XSG_PROBE_MIN_BYTES", "0")
+    blocks = [corpus.text_block(11, i, 400_000 + 31 * i, needle_rate=3e-4) for i in range(3)]
+    t, chunks = upload(blocks)
+    from gpu_util import oracle_regex_all_modes
+    for pat, flags in ((b"detective street", 0), (b"Sherlock Holmes said", 0), (b"Sherlock", 0), (b"the", 0), (b"Holmes", 0),
+                       (b"sherlock", xsg.FLAG_IGNORE_CASE), (b"She[r ]lock", xsg.FLAG_REGEX), (b"lock(ed|s)?", xsg.FLAG_REGEX)):
+        if flags & xsg.FLAG_REGEX:
+            want, _ = oracle_regex_all_modes(oracle, blocks, pat, False)
+        else:
+            want = oracle_all_modes(oracle, blocks, pat, ignore_case=bool(flags & xsg.FLAG_IGNORE_CASE))
+        for key in ("count_matches", "count_lines", "match_byte_offsets", "line_byte_offsets", "line_indices", "lines"):
+            ctx = xsg.Context(0)  # a fresh context and binding: nothing allocated by an earlier tag
+            sh = xsg.Shard(ctx, t.data_ptr(), t.numel(), chunks)
+            ctx.set_pattern(pat, flags)
+            if key == "count_matches":
+                got = int(sh.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
+            elif key == "count_lines":
+                got = int(sh.count(xsg.COUNT_LINES)[xsg.CTR_LINES])
+            elif key == "lines":
+                got = sh.search_lines()[0]
+            else:
+                mode = {"match_byte_offsets": xsg.MATCH_BYTE_OFFSETS, "line_byte_offsets": xsg.LINE_BYTE_OFFSETS,
+                        "line_indices": xsg.LINE_INDICES}[key]
+                got = sh.search_u64(mode).tolist()
+            assert got == want[key], (pat, key)
+            sh.close()
+            ctx.close()

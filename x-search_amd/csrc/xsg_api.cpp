@@ -946,6 +946,11 @@ static int choose_hot_filter(xsg_shard* s, hipStream_t st, bool want_nl = false,
   // how often the slow path runs (`detective street` on the bench corpus: "ective s" every 4 KiB, "ve stree" every
   // 11 KiB), and no static letter table knows the text.  Each candidate: the window filter on a 1 GiB prefix.
   if (settle_window && c->pat.kind == kLong && c->koff_cands.size() > 1) {
+    // (the candidates are timed on the newline-counting instantiation -- the VALU-heaviest, which shows a window's slow-path
+    // rate best -- whatever variant the caller is about to launch: its per-tile newline array must exist.  Since the probe
+    // became per-variant in round 4 a plain count no longer allocated it, and a long pattern's first count on a fresh binding
+    // stored through a null pointer: tests/test_gpu_parity.py::test_first_search_of_a_fresh_binding_with_a_long_pattern)
+    XSG_TRY(ensure_tile_nl(s));
     float best = 1e30f;
     uint32_t best_koff = c->koff_cands[0];
     for (uint32_t koff : c->koff_cands) {
