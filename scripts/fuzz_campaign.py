@@ -17,7 +17,7 @@ for d in ("", "x-search_amd", "oracle", "tests"):
     sys.path.insert(0, str(ROOT / d))
 import xs_oracle  # noqa: E402
 from gpu_util import GpuSearch  # noqa: E402
-from test_gpu_fuzz import fuzz_rounds  # noqa: E402
+from test_gpu_fuzz import first_call_rounds, fuzz_rounds  # noqa: E402
 from test_gpu_regex import regex_rounds, rx_rounds  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -44,6 +44,8 @@ while time.monotonic() - t0 < a.minutes * 60:
         os.environ["XSG_LIST_FAST"] = "0"
     try:
         fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000 if seed % 4 else 600000)
+        if seed % 4 == 2:  # every search the FIRST call of a fresh context and binding, one random tag per case
+            first_call_rounds(seed, oracle, rounds=4)
         if seed % 3 == 0:
             regex_rounds(seed, oracle, gs, rounds=10)
         if seed % 3 == 1:  # variable-length expressions: the automaton route, prefilter on (default) / off per seed

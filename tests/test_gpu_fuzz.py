@@ -38,8 +38,8 @@ def rand_pattern(rng, data, alphabet):
     return p if p else b"a"
 
 
-def fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000):
-    """`rounds` random shards x 5 random patterns each; raises AssertionError on the first difference."""
+def fuzz_cases(seed, rounds=14, max_chunk=60000):
+    """`rounds` random shards x 5 random patterns each -> (round, blocks, new shard?, pattern, exact, icase)"""
     rng = np.random.default_rng(1000 + seed)
     alphabets = [np.frombuffer(b"ab", dtype=np.uint8), np.frombuffer(b"ab\n", dtype=np.uint8),
                  np.frombuffer(b"abcAB \n\n", dtype=np.uint8), np.arange(256, dtype=np.uint8),
@@ -60,18 +60,65 @@ def fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000):
             if n and rng.random() < 0.6:
                 b[-1] = 10
             blocks.append(b)
-        gs.bind(blocks)
         big = max(blocks, key=lambda x: x.size)
-        for _ in range(5):
+        for k in range(5):
             p = rand_pattern(rng, big, alphabet)
             exact = bool(rng.integers(0, 2))
             icase = bool(rng.integers(0, 2))
+            yield it, blocks, k == 0, p, exact, icase
+
+
+def fuzz_rounds(seed, oracle, gs, rounds=14, max_chunk=60000):
+    """every tag for every case of fuzz_cases on one context and shard; raises AssertionError on the first difference."""
+    for it, blocks, fresh, p, exact, icase in fuzz_cases(seed, rounds, max_chunk):
+        if fresh:
+            gs.bind(blocks)
+        flags = (xsg.FLAG_EXACT_TAIL if exact else 0) | (xsg.FLAG_IGNORE_CASE if icase else 0)
+        got = gs.all_modes(p, flags)
+        want = oracle_all_modes(oracle, blocks, p, exact, ignore_case=icase)
+        for k in want:
+            assert got[k] == want[k], (f"seed={seed} it={it} pat={p!r} exact={exact} icase={icase} "
+                                       f"sizes={[b.size for b in blocks]} key={k}")
+
+
+def first_call_rounds(seed, oracle, rounds=6):
+    """The same cases, but every search is the FIRST call of a fresh context and binding, one random tag per case, the
+    probe forced on: nothing an earlier tag allocated, measured or cached is there (round 4: a long pattern's first plain
+    count stored through a null pointer -- gpu_util's all_modes begins with a count that wants newlines and hid it)."""
+    import os
+    from gpu_util import upload
+    rng = np.random.default_rng(77 + seed)
+    tags = ["count_matches", "count_lines", "match_byte_offsets", "line_byte_offsets", "line_indices", "lines"]
+    old = os.environ.get("XSG_PROBE_MIN_BYTES")
+    os.environ["XSG_PROBE_MIN_BYTES"] = "0"
+    try:
+        for it, blocks, fresh, p, exact, icase in fuzz_cases(seed, rounds):
+            if sum(b.size for b in blocks) == 0:
+                continue
+            t, chunks = upload(blocks)
+            key = tags[int(rng.integers(0, len(tags)))]
             flags = (xsg.FLAG_EXACT_TAIL if exact else 0) | (xsg.FLAG_IGNORE_CASE if icase else 0)
-            got = gs.all_modes(p, flags)
             want = oracle_all_modes(oracle, blocks, p, exact, ignore_case=icase)
-            for k in want:
-                assert got[k] == want[k], (f"seed={seed} it={it} pat={p!r} exact={exact} icase={icase} "
-                                           f"sizes={[b.size for b in blocks]} key={k}")
+            ctx = xsg.Context(0)
+            sh = xsg.Shard(ctx, t.data_ptr(), t.numel(), chunks)
+            ctx.set_pattern(p, flags)
+            if key == "count_matches":
+                got = int(sh.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
+            elif key == "count_lines":
+                got = int(sh.count(xsg.COUNT_LINES)[xsg.CTR_LINES])
+            elif key == "lines":
+                got = sh.search_lines()[0]
+            else:
+                got = sh.search_u64({"match_byte_offsets": xsg.MATCH_BYTE_OFFSETS, "line_byte_offsets": xsg.LINE_BYTE_OFFSETS,
+                                     "line_indices": xsg.LINE_INDICES}[key]).tolist()
+            sh.close()
+            ctx.close()
+            assert got == want[key], f"seed={seed} it={it} pat={p!r} exact={exact} icase={icase} key={key} (first call of a fresh binding)"
+    finally:
+        if old is None:
+            os.environ.pop("XSG_PROBE_MIN_BYTES", None)
+        else:
+            os.environ["XSG_PROBE_MIN_BYTES"] = old
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
@@ -91,3 +138,8 @@ def test_fuzz_with_the_probe_choosing(seed, oracle):
     """hot filter and, for long patterns, the filter window picked by the library's measurement (on shards this small:
     at random) -- results must not depend on the choice"""
     fuzz_rounds(seed, oracle, GpuSearch(probe=True))
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_fuzz_where_every_search_is_a_first_call(seed, oracle):
+    first_call_rounds(seed, oracle)
