@@ -183,3 +183,43 @@ def test_regex_routes_10gib(shard10, oracle):
     tlc = np.array([oracle.regex_count(b, cs, True) for b in s["blocks"]], dtype=np.int64)
     assert int(s["shard"].count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == int(tm[plan].sum()) > 0
     assert int(s["shard"].count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == int(tlc[plan].sum())
+
+
+def test_first_calls_at_a_size_where_the_library_measures(oracle):
+    """Every tag as the FIRST call of a fresh context and binding on a 1.5 GiB shard -- above the sizes at which the library
+    starts to measure on its own (hot-filter and filter-window probes from 64 MiB, the regex prefilter from 512 MiB, the tuner
+    from 1 GiB) and with nothing an earlier call allocated or cached.  Round 4: a long pattern's first plain count on such a
+    binding stored through a null pointer; the small-shard suites reached that probe only behind other calls."""
+    from gpu_util import oracle_all_modes, oracle_regex_all_modes
+    t, blocks, plan, chunks, goffs, cap = build_shard(1.5, templates=4)
+    nl_t = np.array([oracle.count_newlines(b) for b in blocks], dtype=np.uint64)
+    nl_before = np.concatenate([[0], np.cumsum(nl_t[plan])[:-1]]).astype(np.uint64)
+    modes = {"match_byte_offsets": xsg.MATCH_BYTE_OFFSETS, "line_byte_offsets": xsg.LINE_BYTE_OFFSETS, "line_indices": xsg.LINE_INDICES}
+    for pat, flags in ((b"Sherlock", 0), (b"detective street", 0), (b"Sherlock Holmes", 0), (b"Holmes", 0), (b"She", 0),
+                       (b"sherlock holmes", xsg.FLAG_IGNORE_CASE), (b"[Ss]herlock", xsg.FLAG_REGEX), (b"colou?r|Sherlock", xsg.FLAG_REGEX)):
+        per = []
+        for b in blocks:  # the oracle per template chunk (local offsets, local line indices)
+            if flags & xsg.FLAG_REGEX:
+                per.append(oracle_regex_all_modes(oracle, [b], pat, False)[0])
+            else:
+                per.append(oracle_all_modes(oracle, [b], pat, ignore_case=bool(flags & xsg.FLAG_IGNORE_CASE)))
+        want = {"count_matches": sum(per[int(c)]["count_matches"] for c in plan),
+                "count_lines": sum(per[int(c)]["count_lines"] for c in plan)}
+        for k in ("match_byte_offsets", "line_byte_offsets"):
+            want[k] = np.concatenate([np.asarray(per[int(c)][k], dtype=np.uint64) + goffs[i] for i, c in enumerate(plan)])
+        want["line_indices"] = np.concatenate([np.asarray(per[int(c)]["line_indices"], dtype=np.uint64) + nl_before[i] for i, c in enumerate(plan)])
+        want["lines"] = [l for c in plan for l in per[int(c)]["lines"]]
+        for key in ("count_matches", "count_lines", "match_byte_offsets", "line_byte_offsets", "line_indices", "lines"):
+            ctx = xsg.Context(0)
+            sh = xsg.Shard(ctx, t.data_ptr(), cap, chunks)
+            ctx.set_pattern(pat, flags)
+            if key == "count_matches":
+                assert int(sh.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES]) == want[key], (pat, key)
+            elif key == "count_lines":
+                assert int(sh.count(xsg.COUNT_LINES)[xsg.CTR_LINES]) == want[key], (pat, key)
+            elif key == "lines":
+                assert sh.search_lines()[0] == want[key], (pat, key)
+            else:
+                assert np.array_equal(sh.search_u64(modes[key]), want[key]), (pat, key)
+            sh.close()
+            ctx.close()

@@ -644,10 +644,29 @@ def test_first_search_of_a_fresh_binding_with_a_long_pattern(oracle, monkeypatch
             want, _ = oracle_regex_all_modes(oracle, blocks, pat, False)
         else:
             want = oracle_all_modes(oracle, blocks, pat, ignore_case=bool(flags & xsg.FLAG_IGNORE_CASE))
-        for key in ("count_matches", "count_lines", "match_byte_offsets", "line_byte_offsets", "line_indices", "lines"):
+        for key in ("count_matches", "count_lines", "match_byte_offsets", "line_byte_offsets", "line_indices", "lines",
+                    "count_async", "count_begin"):
             ctx = xsg.Context(0)  # a fresh context and binding: nothing allocated by an earlier tag
             sh = xsg.Shard(ctx, t.data_ptr(), t.numel(), chunks)
             ctx.set_pattern(pat, flags)
+            if key == "count_async":  # the stream-ordered entry point as the first call
+                import torch
+                d = torch.zeros(xsg.NUM_COUNTERS + 1, dtype=torch.int64, device="cuda:0")
+                st = torch.cuda.Stream()
+                sh.count_async_status(xsg.COUNT_MATCHES, st.cuda_stream, d.data_ptr(), d.data_ptr() + 8 * xsg.NUM_COUNTERS)
+                st.synchronize()
+                h = d.cpu().numpy().astype(np.uint64)
+                if int(h[xsg.NUM_COUNTERS]) == 0:
+                    assert int(h[xsg.CTR_MATCHES]) == want["count_matches"], (pat, key)
+                sh.close()
+                ctx.close()
+                continue
+            if key == "count_begin":
+                sh.count_begin(xsg.COUNT_LINES)
+                assert int(sh.count_end()[xsg.CTR_LINES]) == want["count_lines"], (pat, key)
+                sh.close()
+                ctx.close()
+                continue
             if key == "count_matches":
                 got = int(sh.count(xsg.COUNT_MATCHES)[xsg.CTR_MATCHES])
             elif key == "count_lines":
