@@ -196,6 +196,7 @@ def test_first_calls_at_a_size_where_the_library_measures(oracle):
     nl_before = np.concatenate([[0], np.cumsum(nl_t[plan])[:-1]]).astype(np.uint64)
     modes = {"match_byte_offsets": xsg.MATCH_BYTE_OFFSETS, "line_byte_offsets": xsg.LINE_BYTE_OFFSETS, "line_indices": xsg.LINE_INDICES}
     for pat, flags in ((b"Sherlock", 0), (b"detective street", 0), (b"Sherlock Holmes", 0), (b"Holmes", 0), (b"She", 0),
+                       (b"\nShe", 0), (b"e\nS", 0),  # literals that contain a newline: the chain walk, at a size no small shard has
                        (b"sherlock holmes", xsg.FLAG_IGNORE_CASE), (b"[Ss]herlock", xsg.FLAG_REGEX), (b"colou?r|Sherlock", xsg.FLAG_REGEX)):
         per = []
         for b in blocks:  # the oracle per template chunk (local offsets, local line indices)
