@@ -351,7 +351,7 @@ def e2e_leg(args, blocks, pattern: bytes, tcount, rank, world, dist, dev_index):
         nm = len(mchunks)
         llo, lhi = (nm * rank) // world, (nm * (rank + 1)) // world
         want_l = oracle_on(small, mchunks, llo, lhi, lists=False)[0]
-        ndecoders = int(os.environ.get("XSG_E2E_DECODERS", str(max(1, min(12, budget - nthreads)))))
+        ndecoders = int(os.environ.get("XSG_E2E_DECODERS", str(max(1, min(16, budget)))))  # the decoders are the work; the device workers mostly sleep
         run(xsg.COUNT_MATCHES, mp, dp, ndecoders, (llo, lhi))
         r, dt, st = run(xsg.COUNT_MATCHES, mp, dp, ndecoders, (llo, lhi))
         if r != want_l:

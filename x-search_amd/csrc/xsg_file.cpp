@@ -1234,10 +1234,19 @@ static int job_start_impl(const void* pattern, size_t plen, const char* file_pat
   j->piece_bytes = std::max<uint64_t>(env_u64("XSG_READ_PIECE", 4u << 20), 1u << 16);
   uint64_t pieces = 0;
   for (const xsg_file_chunk& c : j->plan) pieces += pieces_of(j.get(), c);
-  const int nreaders = (int)std::min<uint64_t>((uint64_t)std::max(opts->num_max_readers, auto_readers()), std::max<uint64_t>(pieces, 1));
+  // (readers of a compressed file DECODE: that is what its rate is made of -- 3.5 GiB/s of text per LZ4 thread -- and the device
+  // workers mostly sleep, so they get the whole CPU budget, 16 at most)
+  const int want_readers = j->compression != XSG_COMPRESSION_NONE && !env_u64("XSG_MIN_READERS", 0)
+                               ? (int)std::min<uint64_t>(std::max<uint64_t>(cpu_budget(), 2), 16)
+                               : auto_readers();
+  const int nreaders = (int)std::min<uint64_t>((uint64_t)std::max(opts->num_max_readers, want_readers), std::max<uint64_t>(pieces, 1));
   // the ring: two chunks per worker (one being scanned, one whose copy is queued behind it), the one the readers are
   // filling, and two complete ones in between -- never more buffers than chunks.  Allocated on demand by the readers.
-  j->bufs_max = (int)std::min<uint64_t>((uint64_t)(2 * nworkers + 3), nch);
+  // A COMPRESSED chunk is one piece: every reader decodes a whole chunk into a buffer of its own, so the ring also needs one
+  // buffer per reader -- with 2 * workers + 3 twelve LZ4 decoders found three to seven buffers free and ran at 25 GiB/s of
+  // text where 12 x 3.5 GiB/s were there (bench.py e2e.lz4, profiles/r04_lz4_threads.txt).
+  const uint64_t ring = j->compression != XSG_COMPRESSION_NONE ? (uint64_t)(2 * nworkers + nreaders + 1) : (uint64_t)(2 * nworkers + 3);
+  j->bufs_max = (int)std::min<uint64_t>(ring, nch);
   j->active = nworkers;
   j->readers_running = nreaders;
   XSG_TRACE("job: starting %d readers + %d workers, ring of up to %d pinned buffers, %llu pieces", nreaders, nworkers,
